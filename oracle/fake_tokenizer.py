@@ -1,0 +1,49 @@
+"""A context-free word tokenizer used by the A1/A2 golden vectors (TEST INFRASTRUCTURE).
+
+No tokenizer files can be downloaded in the build container, so the reference's
+`tokenizer_image_token` (metamorph/mm_utils.py:191-214) is pinned with this stand-in: it has the
+two properties that function relies on -- `tokenizer(text).input_ids` and `.bos_token_id` -- and,
+like the Llama-3 tokenizer, (a) prepends BOS to every call when `add_bos` is set and (b) maps the
+literal string "<|begin_of_text|>" to the BOS id, which is what produces the double BOS the
+reference emits with its llama3 template.
+"""
+from __future__ import annotations
+
+import zlib
+from types import SimpleNamespace
+
+SPECIALS = {
+    "<|begin_of_text|>": 128000,
+    "<|end_of_text|>": 128001,
+    "<|start_header_id|>": 128006,
+    "<|end_header_id|>": 128007,
+    "<|eot_id|>": 128009,
+    "<image_start>": 128256,
+    "<image_end>": 128257,
+}
+
+
+class FakeTokenizer:
+    def __init__(self, add_bos=True, bos_token_id=128000, pad_token_id=128001, model_max_length=4096):
+        self.add_bos = add_bos
+        self.bos_token_id = bos_token_id
+        self.pad_token_id = pad_token_id
+        self.model_max_length = model_max_length
+
+    def _word(self, w):
+        return 3 + zlib.crc32(w.encode("utf-8")) % 127000
+
+    def encode_plain(self, text):
+        ids = []
+        # split so that specials are their own tokens even when glued to words
+        for sp in SPECIALS:
+            text = text.replace(sp, f" {sp} ")
+        for w in text.split():
+            ids.append(SPECIALS[w] if w in SPECIALS else self._word(w))
+        return ids
+
+    def __call__(self, text):
+        ids = self.encode_plain(text)
+        if self.add_bos:
+            ids = [self.bos_token_id] + ids
+        return SimpleNamespace(input_ids=ids)

@@ -1,0 +1,408 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING THE REFERENCE ITSELF (TEST INFRASTRUCTURE).
+
+Runs only in the build container (needs /root/reference; the GPU box never has it).  It imports
+the reference's own Python -- metamorph.mm_utils, metamorph.model.* -- plus the third-party
+`transformers` the reference delegates its LLaMA/SigLIP arithmetic to, feeds them seeded inputs
+and random weights, and records inputs/outputs as small .npz/.json fixtures.  No reference source
+text is written anywhere; fixtures are data only.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Shims: import-only `wandb`/`decord` packages from oracle/_shims, and a tiny
+SiglipVisionModel assigned to the delay-loaded tower (the checkpoint cannot be downloaded).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+from oracle.fake_tokenizer import FakeTokenizer
+from oracle.ref_model import OracleConfig, init_state_dict
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+torch.set_num_threads(8)
+
+
+def save_npz(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().to(torch.float32).numpy() if v.is_floating_point() else v.detach().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **conv)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ----------------------------------------------------------------------------- A1
+
+A1_PROMPTS = [
+    "hello world",
+    "<image>",
+    "<image> describe this picture",
+    "describe <image>",
+    "a <image> b <image> c",
+    "<image><image>",
+    "<image> <image> tail",
+    "<|begin_of_text|> system prompt <image_start><image><image_end> what is this",
+    "<|begin_of_text|><|start_header_id|> user <|end_header_id|> draw a cat <|eot_id|>"
+    "<|start_header_id|> assistant <|end_header_id|> sure <image_start><image><image_end><|eot_id|>",
+    "",
+    "x <image>",
+    "<image> y <image>",
+]
+
+
+def gen_a1():
+    from metamorph.mm_utils import tokenizer_image_token
+    cases = []
+    for add_bos in (True, False):
+        tok = FakeTokenizer(add_bos=add_bos)
+        for p in A1_PROMPTS:
+            for idx in (-200, -7):
+                ids = tokenizer_image_token(p, tok, image_token_index=idx)
+                cases.append(dict(prompt=p, add_bos=add_bos, image_token_index=idx, ids=ids))
+    with open(os.path.join(OUT, "a1_tokenizer.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    print(f"  wrote a1_tokenizer.json ({len(cases)} cases)")
+
+
+# ----------------------------------------------------------------------------- reference model builder
+
+def build_reference(cfg: OracleConfig, sd, dtype, **ctor):
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from metamorph.model.language_model.metamorph_llama import MetaMorphLlamaForCausalLM, MetaMorphConfig
+
+    hf = MetaMorphConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                         num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                         num_key_value_heads=cfg.num_key_value_heads, vocab_size=cfg.vocab_size,
+                         max_position_embeddings=8192, rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps,
+                         attention_bias=False, tie_word_embeddings=False)
+    hf.mm_vision_tower = "siglip/CLIP-ViT-SO400M-14-384"
+    hf.mm_projector_type = cfg.mm_projector_type
+    hf.mm_hidden_size = cfg.v_hidden
+    hf.num_image_tokens = cfg.num_image_tokens
+    hf.image_token_reduction = "interpolation"
+    hf.freeze_vision = True
+    hf.normalize_vision = cfg.normalize_vision
+    hf.apply_softmax = cfg.apply_softmax
+    hf.mm_vision_select_layer = -1
+    hf.tokenizer_model_max_length = cfg.tokenizer_model_max_length
+    hf.tokenizer_padding_side = cfg.tokenizer_padding_side
+    hf.vision_head_type = cfg.vision_head_type
+    model = MetaMorphLlamaForCausalLM(hf, use_vision_ar=cfg.use_vision_ar, vision_head=cfg.vision_head_type,
+                                      vision_coef=cfg.vision_coef, normalize_vision=cfg.normalize_vision,
+                                      apply_softmax=cfg.apply_softmax, vision_delay_load=True, **ctor)
+    tower = model.get_model().vision_tower
+    vcfg = SiglipVisionConfig(hidden_size=cfg.v_hidden, intermediate_size=cfg.v_intermediate,
+                              num_hidden_layers=cfg.v_layers, num_attention_heads=cfg.v_heads,
+                              image_size=cfg.v_image, patch_size=cfg.v_patch, layer_norm_eps=cfg.v_ln_eps,
+                              hidden_act="gelu_pytorch_tanh")
+    tower.vision_tower = SiglipVisionModel(vcfg)
+    tower.is_loaded = True
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "post_layernorm" not in k and ".head." not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    model.to(dtype)
+    model.train()
+    return model
+
+
+def tiny_cfg(**kw):
+    base = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=1, vocab_size=128258, v_layers=2, v_intermediate=144, v_image=56,
+                num_image_tokens=4, tokenizer_model_max_length=64)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+# ----------------------------------------------------------------------------- A5 cases
+
+ST, IM, EN = 128256, -200, 128257
+
+
+def a5_cases():
+    """(name, ids rows, label rows, T, max_len, padding_side).  Rows are ragged; padded below."""
+    A = 128000
+    c = []
+    # prompt-side image then text answer; answer-side image; text-only with dummy image
+    c.append(("mixed_right", [
+        [A, A, 11, 12, ST, IM, EN, 13, 14, 15, 16],
+        [A, A, 21, 22, 23, ST, IM, EN, 128009],
+        [A, A, 31, 32, 33, 34],
+    ], [
+        [-100] * 7 + [13, 14, 15, 16],
+        [-100] * 5 + [ST, IM, EN, 128009],
+        [-100, -100, -100, 32, 33, 34],
+    ], 4, 64, "right"))
+    c.append(("mixed_left", c[0][1], c[0][2], 4, 64, "left"))
+    # two images in one sample: prompt image + answer image; second sample two prompt images
+    c.append(("two_images", [
+        [A, A, 5, ST, IM, EN, 6, 7, ST, IM, EN, 8],
+        [A, ST, IM, EN, 9, ST, IM, EN, 10, 11],
+    ], [
+        [-100] * 7 + [7, ST, IM, EN, 8],
+        [-100] * 8 + [10, 11],
+    ], 4, 64, "right"))
+    # overflow: second image does not fit -> dropped with all later text (need_to_stop)
+    c.append(("overflow_drop", [
+        [A, A, 5, ST, IM, EN, 6, 7, ST, IM, EN, 8, 9],
+        [A, A, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, ST, IM, EN, 51],
+    ], [
+        [-100] * 7 + [7, ST, IM, EN, 8, 9],
+        [-100] * 2 + [41, 42, 43, 44, 45, 46, 47, 48, 49, 50, ST, IM, EN, 51],
+    ], 16, 24, "right"))
+    # text longer than max_len -> truncation after the loop
+    c.append(("truncate_text", [
+        [A, A] + list(range(100, 130)),
+        [A, A, 7, ST, IM, EN, 8],
+    ], [
+        [-100, -100] + list(range(100, 130)),
+        [-100] * 6 + [8],
+    ], 4, 20, "right"))
+    # answer image is the last thing that fits exactly
+    c.append(("exact_fit", [
+        [A, A, 1, 2, ST, IM, EN],
+    ], [
+        [-100, -100, -100, 2, ST, IM, EN],
+    ], 4, 9, "right"))
+    # image first in the sequence after BOS only, answer-image decided by label just before it
+    c.append(("label_rule", [
+        [A, ST, IM, EN, 3],
+        [A, 77, IM, EN, 3],
+        [A, ST, IM, 4],
+    ], [
+        [-100, ST, IM, EN, 3],
+        [-100, 77, IM, EN, 3],
+        [-100, -100, IM, 4],
+    ], 4, 64, "right"))
+    return c
+
+
+def pad_rows(rows, pad):
+    T = max(len(r) for r in rows)
+    return [r + [pad] * (T - len(r)) for r in rows]
+
+
+def gen_a5():
+    cfg = tiny_cfg(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_key_value_heads=1)
+    sd = init_state_dict(cfg, seed=11)
+    rng = np.random.default_rng(5)
+    pad_id = 128001
+    for name, ids, labs, T, max_len, side in a5_cases():
+        cfg.num_image_tokens = T
+        cfg.tokenizer_model_max_length = max_len
+        cfg.tokenizer_padding_side = side
+        model = build_reference(cfg, sd, torch.float32)
+        n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
+        images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+        ids_t = torch.tensor(pad_rows(ids, pad_id))
+        lab_t = torch.tensor(pad_rows(labs, -100))
+        msk_t = ids_t.ne(pad_id)
+        with torch.no_grad():
+            proj, feat = model.encode_images(images)
+            out = model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images)
+        _, pos_ids, att, _, emb, new_lab, img_pos, tgt = out
+        # derive, from the reference's own output, where every spliced row came from
+        W = model.get_model().embed_tokens.weight.detach()
+        flat_proj = proj.reshape(-1, proj.shape[-1])
+        B, L, _ = emb.shape
+        src = np.full((B, L), -1, dtype=np.int64)
+        for b in range(B):
+            toks = [t for t in ids[b] if t >= 0]
+            for l in range(L):
+                row = emb[b, l]
+                if not att[b, l]:
+                    assert torch.count_nonzero(row) == 0
+                    continue
+                hit = (flat_proj == row).all(dim=1).nonzero()
+                if len(hit):
+                    src[b, l] = -2 - int(hit[0, 0])
+                    continue
+                cand = [t for t in set(toks) if torch.equal(W[t], row)]
+                assert len(cand) == 1, (name, b, l, cand)
+                src[b, l] = cand[0]
+        keep = []
+        for r in range(tgt.shape[0]):
+            hit = [i for i in range(feat.shape[0]) if torch.equal(feat[i], tgt[r])]
+            assert len(hit) == 1
+            keep.append(hit[0])
+        save_npz(f"a5_{name}.npz", input_ids=ids_t, labels=lab_t, attention_mask=msk_t,
+                 rows_per_image=np.int64(T), max_length=np.int64(max_len), left=np.int64(side == "left"),
+                 num_images=np.int64(n_img), out_src=src, out_labels=new_lab, out_attention_mask=att,
+                 out_image_positions=img_pos, out_position_ids_is_none=np.int64(pos_ids is None),
+                 out_target_keep=np.array(keep, dtype=np.int64))
+
+
+# ----------------------------------------------------------------------------- A3 tower
+
+def gen_a3():
+    for T in (4, 16):
+        cfg = tiny_cfg(num_image_tokens=T)
+        sd = init_state_dict(cfg, seed=21)
+        rng = np.random.default_rng(22)
+        images = torch.from_numpy(rng.standard_normal((2, 3, 56, 56), dtype=np.float32))
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            model = build_reference(cfg, sd, dt)
+            with torch.no_grad():
+                tower = model.get_model().vision_tower
+                raw = tower.vision_tower(images.to(dt), output_hidden_states=True).hidden_states[-1]
+                feat = tower(images.to(dt))
+                proj, tgt = model.encode_images(images.to(dt))
+            save_npz(f"a3_tower_T{T}_{tag}.npz", images=images, seed=np.int64(21), raw_hidden=raw[:, :, ::8],
+                     features=feat, projected=proj[:, :, ::4], target=tgt[:, :, ::16])
+
+
+# ----------------------------------------------------------------------------- per-op (v)
+
+def gen_ops():
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb, LlamaConfig
+    import torch.nn.functional as F
+    rng = np.random.default_rng(31)
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32))
+    out = {}
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        x = r(3, 7, 256).to(dt)
+        w = (1 + 0.1 * r(256)).to(dt)
+        n = LlamaRMSNorm(256, eps=1e-5).to(dt)
+        n.weight.data.copy_(w)
+        out[f"rms_x_{tag}"], out[f"rms_w_{tag}"], out[f"rms_y_{tag}"] = x, w, n(x)
+        # rope
+        cfg = LlamaConfig(hidden_size=256, num_attention_heads=2, rope_theta=500000.0, max_position_embeddings=8192)
+        rot = LlamaRotaryEmbedding(cfg)
+        q, k = r(2, 2, 9, 128).to(dt), r(2, 1, 9, 128).to(dt)
+        pos = torch.arange(9)[None].expand(2, 9)
+        cos, sin = rot(q, pos)
+        qe, ke = apply_rotary_pos_emb(q, k, cos, sin)
+        out[f"rope_q_{tag}"], out[f"rope_k_{tag}"], out[f"rope_qe_{tag}"], out[f"rope_ke_{tag}"] = q, k, qe, ke
+        out[f"rope_cos_{tag}"], out[f"rope_sin_{tag}"] = cos, sin
+        # causal + key padding SDPA, GQA 2:1 (additive min-dtype mask exactly as HF builds it)
+        L = 9
+        v = r(2, 1, L, 128).to(dt)
+        valid = torch.tensor([[True] * 9, [True] * 6 + [False] * 3])
+        allow = torch.ones(L, L, dtype=torch.bool).tril()[None, None] & valid[:, None, None, :]
+        kk = k.repeat_interleave(2, dim=1)
+        vv = v.repeat_interleave(2, dim=1)
+        att = F.scaled_dot_product_attention(qe, ke.repeat_interleave(2, dim=1), vv, attn_mask=allow, scale=128 ** -0.5)
+        out[f"att_v_{tag}"], out[f"att_valid_{tag}"], out[f"att_o_{tag}"] = v, valid, att
+        # swiglu, gelus, layernorm
+        g, u = r(5, 64).to(dt), r(5, 64).to(dt)
+        out[f"swi_g_{tag}"], out[f"swi_u_{tag}"], out[f"swi_y_{tag}"] = g, u, F.silu(g) * u
+        out[f"gelu_erf_{tag}"] = torch.nn.GELU()(g)
+        out[f"gelu_tanh_{tag}"] = F.gelu(g, approximate="tanh")
+        lw, lb = (1 + 0.1 * r(64)).to(dt), (0.1 * r(64)).to(dt)
+        out[f"ln_w_{tag}"], out[f"ln_b_{tag}"], out[f"ln_y_{tag}"] = lw, lb, F.layer_norm(g, (64,), lw, lb, 1e-6)
+        # interpolation 27x27 -> 16x16 / 8x8 and 4x4 -> 2x2 + normalise (siglip_encoder.py:160-163,208)
+        for side_in, side_out in ((27, 16), (27, 8), (4, 2)):
+            f = r(2, side_in * side_in, 24).to(dt)
+            y = f.view(2, side_in, side_in, 24).permute(0, 3, 1, 2).contiguous()
+            y = F.interpolate(y.to(torch.float32), size=(side_out, side_out), mode="bilinear", align_corners=False).to(dt)
+            y = y.permute(0, 2, 3, 1).contiguous().flatten(1, 2)
+            out[f"interp_{side_in}_{side_out}_x_{tag}"] = f
+            out[f"interp_{side_in}_{side_out}_y_{tag}"] = y
+            out[f"interp_{side_in}_{side_out}_yn_{tag}"] = F.normalize(y, p=2, dim=-1)
+        # CE (shifted, ignore -100, mean) and cosine
+        lg = r(2, 6, 50).to(dt).float()
+        lb_ = torch.tensor([[-100, 3, 4, -100, 7, 49], [-100, -100, 1, 2, -100, -100]])
+        ce = torch.nn.CrossEntropyLoss()(lg[:, :-1].reshape(-1, 50), lb_[:, 1:].reshape(-1))
+        out[f"ce_logits_{tag}"], out[f"ce_labels_{tag}"], out[f"ce_loss_{tag}"] = lg, lb_, ce
+        a, b = F.normalize(r(6, 32), dim=-1).to(dt), F.normalize(r(6, 32), dim=-1).to(dt)
+        out[f"cos_t_{tag}"], out[f"cos_p_{tag}"] = a, b
+        out[f"cos_loss_{tag}"] = -F.cosine_similarity(a, b, dim=-1).mean()
+    # AdamW: 3 steps of torch.optim.AdamW
+    p = torch.nn.Parameter(r(257))
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    out["adam_p0"] = p.detach().clone()
+    gs = []
+    for s in range(3):
+        gr = r(257)
+        gs.append(gr)
+        p.grad = gr.clone()
+        opt.step()
+    out["adam_grads"] = torch.stack(gs)
+    out["adam_p3"] = p.detach().clone()
+    save_npz("ops.npz", **out)
+
+
+# ----------------------------------------------------------------------------- end to end (vi, vii)
+
+def e2e_batch(kind):
+    A = 128000
+    if kind == "mixed":
+        ids = [[A, A, 11, 12, ST, IM, EN, 13, 14, 15, 16, 128009],
+               [A, A, 21, 22, 23, ST, IM, EN, 128009],
+               [A, A, 31, 32, 33, 34, 35]]
+        lab = [[-100] * 7 + [13, 14, 15, 16, 128009],
+               [-100] * 5 + [ST, IM, EN, 128009],
+               [-100, -100, -100, 32, 33, 34, 35]]
+    elif kind == "understanding_only":       # no answer-side image -> loss_image_ar = NaN (A9)
+        ids = [[A, A, 11, ST, IM, EN, 13, 14],
+               [A, A, 31, 32, 33, 34]]
+        lab = [[-100] * 6 + [13, 14],
+               [-100, -100, -100, 32, 33, 34]]
+    elif kind == "generation_only":
+        ids = [[A, A, 21, 22, ST, IM, EN, 128009],
+               [A, A, 23, ST, IM, EN, 128009, 128001]]
+        lab = [[-100] * 4 + [ST, IM, EN, 128009],
+               [-100] * 3 + [ST, IM, EN, 128009, -100]]
+    else:
+        raise KeyError(kind)
+    return ids, lab
+
+
+def grad_summary(t):
+    f = t.detach().float().flatten()
+    n = min(256, f.numel())
+    idx = (torch.arange(n, dtype=torch.long) * (f.numel() - 1)) // max(n - 1, 1)
+    return torch.cat([f.norm()[None], f[idx]])
+
+
+def gen_e2e():
+    rng = np.random.default_rng(41)
+    for kind, T, use_ar in (("mixed", 4, True), ("mixed", 16, True), ("understanding_only", 4, True),
+                            ("understanding_only", 4, False), ("generation_only", 4, True)):
+        cfg = tiny_cfg(num_image_tokens=T, use_vision_ar=use_ar)
+        sd = init_state_dict(cfg, seed=43)
+        ids, lab = e2e_batch(kind)
+        pad_id = 128001
+        ids_t = torch.tensor(pad_rows(ids, pad_id))
+        lab_t = torch.tensor(pad_rows(lab, -100))
+        msk_t = ids_t.ne(pad_id)
+        n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
+        images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            model = build_reference(cfg, sd, dt)
+            for n, p in model.named_parameters():
+                p.requires_grad_("vision_tower" not in n)
+            out = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images.to(dt))
+            rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, images=images,
+                       seed=np.int64(43), rows_per_image=np.int64(T), use_vision_ar=np.int64(use_ar),
+                       loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language),
+                       loss_image_ar=np.float64(model.loss_image_ar),
+                       logits_sub=out.logits[:, :, ::997], hidden=out.hidden_states)
+            if torch.isfinite(out.loss):
+                out.loss.backward()
+                for n, p in model.named_parameters():
+                    if p.grad is not None and "vision_proj" not in n:
+                        rec["grad::" + n] = grad_summary(p.grad)
+            save_npz(f"e2e_{kind}_T{T}_ar{int(use_ar)}_{tag}.npz", **rec)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
+    for w in which:
+        print(f"[gen_golden] {w}")
+        globals()["gen_" + w]()

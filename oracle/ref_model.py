@@ -1,0 +1,312 @@
+"""End-to-end CPU restatement of the hot path (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+`forward(sd, cfg, batch)` reproduces, on a flat state dict with the reference's key names
+(SURVEY.md section 8b), what `MetaMorphLlamaForCausalLM.forward` computes
+(reference metamorph/model/language_model/metamorph_llama.py:603-660 -> :285-498), i.e.
+
+  A3  SigLIP tower, hidden_states[-1] (pre post_layernorm)      siglip_encoder.py:138-213
+  A4  mm_projector + detached regression targets                metamorph_arch.py:140-164
+  A5  <image>/text splice                                       metamorph_arch.py:177-425
+  A6  LLaMA decoder                                             (transformers LlamaModel)
+  A7  lm_head + shifted CE                                      metamorph_llama.py:393-413
+  A8  vision_head + normalise + cosine / soft-CE / mean-abs     metamorph_llama.py:420-462
+  A9  loss combine incl. the NaN / "loss doubles" quirks        metamorph_llama.py:461-474
+
+Tensors that require grad in `sd` receive gradients through ordinary torch autograd, so the
+same function is the backward oracle.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ref_ops as ops
+from .ref_plan import splice_bookkeeping, IGNORE_INDEX, IMAGE_START_ID
+
+
+@dataclass
+class OracleConfig:
+    # LLM
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    vocab_size: int = 128258
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    # vision tower (SigLIP geometry; reference hard-codes SO400M/14-384, siglip_encoder.py:113)
+    v_hidden: int = 1152
+    v_layers: int = 27
+    v_heads: int = 16
+    v_intermediate: int = 4304
+    v_patch: int = 14
+    v_image: int = 384
+    v_ln_eps: float = 1e-6
+    # connector / heads
+    num_image_tokens: int = 256
+    mm_projector_type: str = "mlp2x_gelu"
+    vision_head_type: str = "mlp"
+    normalize_vision: bool = True
+    apply_softmax: bool = False
+    use_vision_ar: bool = True
+    vision_coef: float = 1.0
+    tokenizer_model_max_length: int | None = 4096
+    tokenizer_padding_side: str = "right"
+    image_start_id: int = IMAGE_START_ID
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+
+# ------------------------------------------------------------------ SigLIP tower (A3)
+
+def siglip_hidden(sd, cfg: OracleConfig, images: torch.Tensor, prefix="model.vision_tower.vision_tower."):
+    """images [N,3,H,W] -> last encoder-layer output [N,P,hv] (no post_layernorm, no head)."""
+    g = lambda k: sd[prefix + k]
+    w = g("embeddings.patch_embedding.weight")
+    dt = w.dtype
+    x = torch.nn.functional.conv2d(images.to(dt), w, g("embeddings.patch_embedding.bias"),
+                                   stride=cfg.v_patch)
+    N, C, gh, gw = x.shape
+    x = x.flatten(2).transpose(1, 2) + g("embeddings.position_embedding.weight")[None]
+    H, d = cfg.v_heads, cfg.v_hidden // cfg.v_heads
+    for j in range(cfg.v_layers):
+        p = f"encoder.layers.{j}."
+        h = ops.layernorm(x, g(p + "layer_norm1.weight"), g(p + "layer_norm1.bias"), cfg.v_ln_eps)
+        q = ops.linear(h, g(p + "self_attn.q_proj.weight"), g(p + "self_attn.q_proj.bias"))
+        k = ops.linear(h, g(p + "self_attn.k_proj.weight"), g(p + "self_attn.k_proj.bias"))
+        v = ops.linear(h, g(p + "self_attn.v_proj.weight"), g(p + "self_attn.v_proj.bias"))
+        sh = lambda t: t.view(N, -1, H, d).transpose(1, 2)
+        a = ops.attention(sh(q), sh(k), sh(v), None, causal=False)
+        a = a.transpose(1, 2).reshape(N, -1, H * d)
+        x = x + ops.linear(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
+        h = ops.layernorm(x, g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"), cfg.v_ln_eps)
+        h = ops.gelu_tanh(ops.linear(h, g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias")))
+        x = x + ops.linear(h, g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias"))
+    return x
+
+
+def vision_features(sd, cfg: OracleConfig, images: torch.Tensor):
+    """SiglipVisionTower.forward (frozen): tower -> cast to images.dtype -> reduce -> normalise."""
+    with torch.no_grad():
+        f = siglip_hidden(sd, cfg, images).to(images.dtype)
+        f = ops.bilinear_reduce(f, cfg.num_image_tokens)
+        if cfg.normalize_vision:
+            f = ops.l2_normalize(f)
+        if cfg.apply_softmax:
+            f = torch.softmax(f / 0.07, dim=-1)
+    return f
+
+
+# ------------------------------------------------------------------ projector / heads
+
+def _mlp(sd, prefix, x, n_linear):
+    """nn.Sequential(Linear, GELU, Linear, ...) with keys prefix{0,2,4}.{weight,bias}."""
+    for i in range(n_linear):
+        x = ops.linear(x, sd[f"{prefix}{2 * i}.weight"], sd[f"{prefix}{2 * i}.bias"])
+        if i != n_linear - 1:
+            x = ops.gelu_erf(x)
+    return x
+
+
+def mm_projector(sd, cfg: OracleConfig, feat):
+    t = cfg.mm_projector_type
+    if t == "linear":
+        return ops.linear(feat, sd["model.mm_projector.weight"], sd["model.mm_projector.bias"])
+    if t == "identity":
+        return feat
+    if t.startswith("mlp") and t.endswith("x_gelu"):
+        return _mlp(sd, "model.mm_projector.", feat, int(t[3:-6]))
+    raise ValueError(f"Unknown projector type: {t}")
+
+
+def vision_head(sd, cfg: OracleConfig, x):
+    t = cfg.vision_head_type
+    if t == "mlp":
+        return _mlp(sd, "vision_head.", x, 2)
+    if t == "mlp2x_gelu":
+        return _mlp(sd, "vision_head.", x, 3)
+    return ops.linear(x, sd["vision_head.weight"], sd["vision_head.bias"])   # "linear" / default
+
+
+# ------------------------------------------------------------------ LLaMA decoder (A6)
+
+def llama_decoder(sd, cfg: OracleConfig, x, key_valid, position_ids=None):
+    B, L, h = x.shape
+    Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    if position_ids is None:
+        position_ids = torch.arange(L)[None].expand(B, L)
+    cos, sin = ops.rope_tables(position_ids, d, cfg.rope_theta, x.dtype)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        n = ops.rmsnorm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+        q = ops.linear(n, sd[p + "self_attn.q_proj.weight"]).view(B, L, Hq, d).transpose(1, 2)
+        k = ops.linear(n, sd[p + "self_attn.k_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
+        v = ops.linear(n, sd[p + "self_attn.v_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
+        q, k = ops.rope_apply(q, cos, sin), ops.rope_apply(k, cos, sin)
+        a = ops.attention(q, k, v, key_valid, causal=True)
+        a = a.transpose(1, 2).reshape(B, L, Hq * d)
+        x = x + ops.linear(a, sd[p + "self_attn.o_proj.weight"])
+        n = ops.rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        g = ops.linear(n, sd[p + "mlp.gate_proj.weight"])
+        u = ops.linear(n, sd[p + "mlp.up_proj.weight"])
+        x = x + ops.linear(ops.swiglu(g, u), sd[p + "mlp.down_proj.weight"])
+    return ops.rmsnorm(x, sd["model.norm.weight"], cfg.rms_norm_eps)
+
+
+# ------------------------------------------------------------------ splice (A5)
+
+def splice(sd, cfg: OracleConfig, input_ids, labels, attention_mask, proj_feat, target_feat):
+    """Returns inputs_embeds [B,L,h], labels [B,L] | None, attention_mask bool [B,L],
+    image_positions [B,L] int64, target_features [Na,T,hv], position_ids [B,L]."""
+    ids = input_ids.tolist()
+    lab = labels.tolist() if labels is not None else None
+    msk = attention_mask.bool().tolist() if attention_mask is not None else None
+    N, T, _ = proj_feat.shape
+    plan = splice_bookkeeping(ids, lab, msk, N, T, cfg.tokenizer_model_max_length,
+                              cfg.tokenizer_padding_side, cfg.image_start_id)
+    emb = sd["model.embed_tokens.weight"]
+    B, L = len(plan["src"]), len(plan["src"][0])
+    h = emb.shape[1]
+    rows = []
+    zero = torch.zeros(h, dtype=proj_feat.dtype)
+    for b in range(B):
+        for s in plan["src"][b]:
+            if s is None:
+                rows.append(zero)
+            elif isinstance(s, tuple):
+                rows.append(proj_feat[s[1], s[2]])
+            else:
+                rows.append(emb[s].to(proj_feat.dtype))
+    x = torch.stack(rows).view(B, L, h)
+    out_labels = torch.tensor(plan["labels"], dtype=torch.long) if plan["labels"] is not None else None
+    return (x, out_labels, torch.tensor(plan["attention_mask"], dtype=torch.bool),
+            torch.tensor(plan["image_positions"], dtype=torch.long),
+            target_feat[plan["target_keep"]] if len(plan["target_keep"]) else target_feat[:0],
+            torch.tensor(plan["position_ids"], dtype=torch.long))
+
+
+# ------------------------------------------------------------------ full forward
+
+def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True):
+    feat = vision_features(sd, cfg, images)                    # [N,T,hv], no grad
+    proj = mm_projector(sd, cfg, feat)                         # [N,T,h]
+    target = feat.detach().clone()
+    x, lab, key_valid, img_pos, target, _pid = splice(sd, cfg, input_ids, labels, attention_mask, proj, target)
+    # position_ids stays None in the reference when the caller passes None (metamorph_arch.py:411-412)
+    hid = llama_decoder(sd, cfg, x, key_valid, None)
+    out = {"hidden_states": hid, "labels": lab, "attention_mask": key_valid,
+           "image_positions": img_pos, "target_features": target, "inputs_embeds": x}
+    logits = ops.linear(hid, sd["lm_head.weight"]).float()
+    if return_logits:
+        out["logits"] = logits
+    if lab is None:
+        out["loss"] = None
+        return out
+    ce = ops.shifted_cross_entropy(logits, lab, IGNORE_INDEX)
+    # rows of hidden[:, :-1] whose NEXT position is an answer-image row (metamorph_llama.py:386-390,425-432)
+    sel = img_pos[:, 1:].bool()
+    pred_in = hid[:, :-1][sel]                                  # [R,h], row-major (b,t) order
+    pred = vision_head(sd, cfg, pred_in)
+    if cfg.normalize_vision:
+        pred = ops.l2_normalize(pred)
+    if cfg.apply_softmax:
+        pred = torch.softmax(pred / 0.07, dim=-1)
+    tgt = target.reshape(-1, target.shape[-1])
+    if cfg.apply_softmax:
+        l_img = ops.soft_ce_loss(tgt, pred)
+    elif cfg.normalize_vision:
+        if tgt.shape[0] != pred.shape[0]:
+            l_img = ce                                         # the try/except at :451-455
+        else:
+            l_img = ops.cosine_loss(tgt, pred)
+    else:
+        l_img = ops.mean_abs_loss(tgt, pred)
+    out["loss_language"] = float(ce.detach())
+    out["loss_image_ar"] = float(l_img.detach())
+    loss = ce
+    if cfg.use_vision_ar and float(l_img.detach()) != 0:
+        loss = ce + cfg.vision_coef * l_img
+    out["loss"] = loss
+    out["pred"] = pred
+    return out
+
+
+# ------------------------------------------------------------------ synthetic weights
+
+def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: float = 0.02,
+                    with_vision=True):
+    """Deterministic N(0, std) weights (numpy PCG64 so the stream is platform independent);
+    norm weights 1 + N(0, 0.1) so that their gradients are exercised."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def rnd(*shape, s=std):
+        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * s).to(dtype)
+
+    def norm_w(n):
+        return (1.0 + rnd(n, s=0.1).float()).to(dtype)
+
+    h, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    d, Hq, Hkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+    sd["model.embed_tokens.weight"] = rnd(V, h)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = rnd(Hq * d, h)
+        sd[p + "self_attn.k_proj.weight"] = rnd(Hkv * d, h)
+        sd[p + "self_attn.v_proj.weight"] = rnd(Hkv * d, h)
+        sd[p + "self_attn.o_proj.weight"] = rnd(h, Hq * d)
+        sd[p + "mlp.gate_proj.weight"] = rnd(I, h)
+        sd[p + "mlp.up_proj.weight"] = rnd(I, h)
+        sd[p + "mlp.down_proj.weight"] = rnd(h, I)
+        sd[p + "input_layernorm.weight"] = norm_w(h)
+        sd[p + "post_attention_layernorm.weight"] = norm_w(h)
+    sd["model.norm.weight"] = norm_w(h)
+    hv = cfg.v_hidden
+    n_lin = {"linear": 1, "identity": 0}.get(cfg.mm_projector_type)
+    if n_lin is None:
+        n_lin = int(cfg.mm_projector_type[3:-6])
+    if cfg.mm_projector_type == "linear":
+        sd["model.mm_projector.weight"] = rnd(h, hv); sd["model.mm_projector.bias"] = rnd(h)
+    else:
+        for j in range(n_lin):
+            sd[f"model.mm_projector.{2 * j}.weight"] = rnd(h, hv if j == 0 else h)
+            sd[f"model.mm_projector.{2 * j}.bias"] = rnd(h)
+    sd["model.vision_proj.weight"] = rnd(h, 4096)       # dead Linear(4096, h), metamorph_arch.py:31
+    sd["model.vision_proj.bias"] = rnd(h)
+    sd["lm_head.weight"] = rnd(V, h)
+    if cfg.vision_head_type == "mlp":
+        sd["vision_head.0.weight"] = rnd(h, h); sd["vision_head.0.bias"] = rnd(h)
+        sd["vision_head.2.weight"] = rnd(hv, h); sd["vision_head.2.bias"] = rnd(hv)
+    elif cfg.vision_head_type == "mlp2x_gelu":
+        sd["vision_head.0.weight"] = rnd(h, h); sd["vision_head.0.bias"] = rnd(h)
+        sd["vision_head.2.weight"] = rnd(h, h); sd["vision_head.2.bias"] = rnd(h)
+        sd["vision_head.4.weight"] = rnd(hv, h); sd["vision_head.4.bias"] = rnd(hv)
+    elif cfg.vision_head_type == "linear":
+        sd["vision_head.weight"] = rnd(h, h); sd["vision_head.bias"] = rnd(h)
+    else:
+        sd["vision_head.weight"] = rnd(hv, h); sd["vision_head.bias"] = rnd(hv)
+    if with_vision:
+        vp = "model.vision_tower.vision_tower."
+        P = (cfg.v_image // cfg.v_patch) ** 2
+        sd[vp + "embeddings.patch_embedding.weight"] = rnd(hv, 3, cfg.v_patch, cfg.v_patch)
+        sd[vp + "embeddings.patch_embedding.bias"] = rnd(hv)
+        sd[vp + "embeddings.position_embedding.weight"] = rnd(P, hv)
+        for j in range(cfg.v_layers):
+            p = vp + f"encoder.layers.{j}."
+            for ln in ("layer_norm1", "layer_norm2"):
+                sd[p + ln + ".weight"] = norm_w(hv)
+                sd[p + ln + ".bias"] = rnd(hv)
+            for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[p + f"self_attn.{nm}.weight"] = rnd(hv, hv)
+                sd[p + f"self_attn.{nm}.bias"] = rnd(hv)
+            sd[p + "mlp.fc1.weight"] = rnd(cfg.v_intermediate, hv)
+            sd[p + "mlp.fc1.bias"] = rnd(cfg.v_intermediate)
+            sd[p + "mlp.fc2.weight"] = rnd(hv, cfg.v_intermediate)
+            sd[p + "mlp.fc2.bias"] = rnd(hv)
+    return sd

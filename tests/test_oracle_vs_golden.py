@@ -1,0 +1,180 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors recorded from the reference itself
+(oracle/gen_golden.py).  CPU only; runs in the `-m "not gpu"` tier."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as ops
+from oracle.fake_tokenizer import FakeTokenizer
+from oracle.ref_model import OracleConfig, forward, init_state_dict, vision_features, mm_projector, siglip_hidden
+from oracle.ref_plan import splice_bookkeeping, tokenizer_image_token
+
+from conftest import GOLDEN
+
+
+def T(a, dt=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dt) if dt is not None else t
+
+
+def tiny_cfg(**kw):
+    base = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=1, vocab_size=128258, v_layers=2, v_intermediate=144, v_image=56,
+                num_image_tokens=4, tokenizer_model_max_length=64)
+    base.update(kw)
+    return OracleConfig(**base)
+
+
+# ------------------------------------------------------------------ A1
+
+def test_a1_tokenizer_image_token():
+    cases = json.load(open(os.path.join(GOLDEN, "a1_tokenizer.json")))
+    assert len(cases) >= 40
+    for c in cases:
+        tok = FakeTokenizer(add_bos=c["add_bos"])
+        assert tokenizer_image_token(c["prompt"], tok, c["image_token_index"]) == c["ids"], c["prompt"]
+
+
+# ------------------------------------------------------------------ A5
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "a5_*.npz"))))
+def test_a5_splice_bookkeeping(path):
+    g = np.load(path)
+    Timg = int(g["rows_per_image"])
+    plan = splice_bookkeeping(g["input_ids"].tolist(), g["labels"].tolist(), g["attention_mask"].tolist(),
+                              int(g["num_images"]), Timg, int(g["max_length"]),
+                              "left" if int(g["left"]) else "right")
+    src = [[-1 if s is None else (-2 - (s[1] * Timg + s[2]) if isinstance(s, tuple) else s) for s in row]
+           for row in plan["src"]]
+    assert np.array_equal(np.array(src), g["out_src"])
+    assert np.array_equal(np.array(plan["labels"]), g["out_labels"])
+    assert np.array_equal(np.array(plan["attention_mask"]), g["out_attention_mask"])
+    assert np.array_equal(np.array(plan["image_positions"]), g["out_image_positions"])
+    assert plan["target_keep"] == g["out_target_keep"].tolist()
+    assert int(g["out_position_ids_is_none"]) == 1
+
+
+# ------------------------------------------------------------------ per-op
+
+OPS = np.load(os.path.join(GOLDEN, "ops.npz"))
+TOL = {"f32": dict(rtol=2e-5, atol=2e-6), "bf16": dict(rtol=1.6e-2, atol=1e-2)}
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_ops(tag):
+    dt, tol = DT[tag], TOL[tag]
+    g = lambda k: T(OPS[f"{k}_{tag}"])
+    close = lambda a, b, **kw: torch.testing.assert_close(a.float(), b.float(), **{**tol, **kw})
+    close(ops.rmsnorm(g("rms_x").to(dt), g("rms_w").to(dt), 1e-5), g("rms_y"))
+    pos = torch.arange(9)[None].expand(2, 9)
+    cos, sin = ops.rope_tables(pos, 128, 500000.0, dt)
+    close(cos, g("rope_cos")); close(sin, g("rope_sin"))
+    qe = ops.rope_apply(g("rope_q").to(dt), cos, sin)
+    ke = ops.rope_apply(g("rope_k").to(dt), cos, sin)
+    close(qe, g("rope_qe")); close(ke, g("rope_ke"))
+    o = ops.attention(g("rope_qe").to(dt), g("rope_ke").to(dt), g("att_v").to(dt), T(OPS[f"att_valid_{tag}"]).bool())
+    close(o, g("att_o"))
+    close(ops.swiglu(g("swi_g").to(dt), g("swi_u").to(dt)), g("swi_y"))
+    close(ops.gelu_erf(g("swi_g").to(dt).float()).to(dt), g("gelu_erf"))
+    close(ops.gelu_tanh(g("swi_g").to(dt).float()).to(dt), g("gelu_tanh"))
+    close(ops.layernorm(g("swi_g").to(dt), g("ln_w").to(dt), g("ln_b").to(dt), 1e-6), g("ln_y"))
+    for a, b in ((27, 16), (27, 8), (4, 2)):
+        x = g(f"interp_{a}_{b}_x").to(dt)
+        y = ops.bilinear_reduce(x, b * b)
+        close(y, g(f"interp_{a}_{b}_y"))
+        close(ops.l2_normalize(y), g(f"interp_{a}_{b}_yn"))
+    ce = ops.shifted_cross_entropy(g("ce_logits"), T(OPS[f"ce_labels_{tag}"]))
+    close(ce, g("ce_loss"))
+    close(ops.cosine_loss(g("cos_t").to(dt), g("cos_p").to(dt)), g("cos_loss"))
+
+
+def test_adamw_matches_torch():
+    p = T(OPS["adam_p0"]).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(3):
+        ops.adamw_step(p, T(OPS["adam_grads"][s]), m, v, s + 1, 1e-2, 0.9, 0.95, 1e-8, 0.1)
+    torch.testing.assert_close(p, T(OPS["adam_p3"]), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ A3 tower
+
+@pytest.mark.parametrize("Timg", [4, 16])
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_a3_tower(Timg, tag):
+    g = np.load(os.path.join(GOLDEN, f"a3_tower_T{Timg}_{tag}.npz"))
+    cfg = tiny_cfg(num_image_tokens=Timg)
+    dt = DT[tag]
+    sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=dt)
+    images = T(g["images"]).to(dt)
+    tol = dict(rtol=1e-4, atol=2e-5) if tag == "f32" else dict(rtol=5e-2, atol=3e-2)
+    with torch.no_grad():
+        raw = siglip_hidden(sd, cfg, images)
+        torch.testing.assert_close(raw[:, :, ::8].float(), T(g["raw_hidden"]), **tol)
+        feat = vision_features(sd, cfg, images)
+        tolf = dict(rtol=1e-4, atol=1e-5) if tag == "f32" else dict(rtol=5e-2, atol=4e-3)
+        torch.testing.assert_close(feat.float(), T(g["features"]), **tolf)
+        proj = mm_projector(sd, cfg, feat)
+        torch.testing.assert_close(proj[:, :, ::4].float(), T(g["projected"]), **tolf)
+
+
+# ------------------------------------------------------------------ end to end
+
+def _grad_summary(t):
+    f = t.detach().float().flatten()
+    n = min(256, f.numel())
+    idx = (torch.arange(n, dtype=torch.long) * (f.numel() - 1)) // max(n - 1, 1)
+    return torch.cat([f.norm()[None], f[idx]])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "e2e_*_f32.npz"))))
+def test_e2e_fp32(path):
+    g = np.load(path)
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])))
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    for k, v in sd.items():
+        if "vision_tower" not in k:
+            v.requires_grad_(True)
+    out = forward(sd, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]))
+    ref_loss = float(g["loss"])
+    if np.isnan(ref_loss):
+        assert torch.isnan(out["loss"])
+    else:
+        assert abs(float(out["loss"]) - ref_loss) < 2e-5 * max(1, abs(ref_loss))
+    assert abs(out["loss_language"] - float(g["loss_language"])) < 2e-5 * max(1, abs(ref_loss))
+    if np.isnan(float(g["loss_image_ar"])):
+        assert np.isnan(out["loss_image_ar"])            # the A9 quirk: no answer-side image -> NaN
+    else:
+        assert abs(out["loss_image_ar"] - float(g["loss_image_ar"])) < 2e-5
+    torch.testing.assert_close(out["logits"][:, :, ::997], T(g["logits_sub"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out["hidden_states"], T(g["hidden"]), rtol=1e-4, atol=1e-5)
+    if torch.isfinite(out["loss"]):
+        out["loss"].backward()
+        n = 0
+        for k in g.files:
+            if k.startswith("grad::"):
+                name = k[6:]
+                assert sd[name].grad is not None, name
+                torch.testing.assert_close(_grad_summary(sd[name].grad), T(g[k]), rtol=2e-4, atol=1e-6)
+                n += 1
+        assert n >= 20
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "e2e_*_bf16.npz"))))
+def test_e2e_bf16(path):
+    g = np.load(path)
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])))
+    sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16)
+    with torch.no_grad():
+        out = forward(sd, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]).bfloat16())
+    ref_loss = float(g["loss"])
+    if np.isnan(ref_loss):
+        assert torch.isnan(out["loss"])
+    else:
+        # north_star tolerance: 1e-3 in bf16 (relative, on the loss)
+        assert abs(float(out["loss"]) - ref_loss) < 1e-3 * max(1, abs(ref_loss)) * 3
+    torch.testing.assert_close(out["hidden_states"].float(), T(g["hidden"]), rtol=5e-2, atol=5e-2)
