@@ -1,0 +1,220 @@
+/*
+ * mm355.h -- C ABI of libmm355.so: the MI355X (gfx950 / CDNA4) kernels behind the MetaMorph hot path.
+ *
+ * The reference (facebookresearch/metamorph) has NO FFI layer: its boundary is the Python class
+ * contract of metamorph.model and all device arithmetic is reached through torch /
+ * transformers.  This header is therefore the ABI a maintainer would bind FROM the reference's Python
+ * (ctypes); every entry point cites the reference call site whose arithmetic it
+ * replaces.  Paths are relative to the reference checkout; "HF" = transformers (pinned 4.45.0 in
+ * pyproject.toml:16, not vendored).
+ *
+ * Conventions
+ *   - raw DEVICE pointers, caller allocates everything (no hipMalloc / hipFree / sync inside);
+ *   - row-major, leading dimensions in ELEMENTS; bf16 is the storage type unless a name says f32;
+ *   - 16-byte aligned base pointers and leading dimensions that are multiples of 8 elements;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - returns 0 or a negative MM355_E* code; never throws, never exits;
+ *   - re-entrant, no global mutable state.
+ */
+#ifndef MM355_H
+#define MM355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM355_VERSION 100            /* 0.1.0 */
+
+#define MM355_OK            0
+#define MM355_EINVAL       -1        /* bad pointer / dimension / alignment                */
+#define MM355_EUNSUPPORTED -2        /* legal request this build has no kernel for         */
+#define MM355_ELAUNCH      -3        /* hipLaunch reported an error (hipGetLastError)      */
+
+typedef uint16_t mm355_bf16;         /* raw bfloat16 bits                                  */
+
+int mm355_version(void);
+const char* mm355_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family.   C[M,N] = epilogue( A[M,K] . B[N,K]^T )      (y = x W^T, the nn.Linear form)
+ * Replaces every nn.Linear reached on the path: HF LlamaAttention/LlamaMLP projections
+ * (metamorph_llama.py:349-359), lm_head (:398), mm_projector (multimodal_projector/builder.py:52-59),
+ * vision_head (metamorph_llama.py:252-256), SigLIP q/k/v/out/fc1/fc2 (siglip_encoder.py:141) and the
+ * patch-embedding Conv2d lowered to a GEMM.  Backward GEMMs (dX = dY W, dW = dY^T X) use the same
+ * entry point on transposed operands (mm355_transpose_bf16).
+ *   epilogue: v = acc; if BIAS v += bias[n]; if GELU_* v = gelu(v); if RESIDUAL v += R[m % res_mod][n];
+ *             if ACCUMULATE v += C_old[m][n];  store as bf16 (or f32 with OUT_F32).
+ * Requirements: K % 8 == 0, lda/ldb % 8 == 0 (ldc/ldr % 8 == 0 for bf16 vector stores, else scalar tail).
+ * variant: 0 = auto; 1..n select a specific tile configuration (bench / tests).
+ * ------------------------------------------------------------------------------------------------ */
+#define MM355_GEMM_BIAS        1u
+#define MM355_GEMM_GELU_ERF    2u    /* nn.GELU() default (projector, vision_head)         */
+#define MM355_GEMM_GELU_TANH   4u    /* SigLIP "gelu_pytorch_tanh"                          */
+#define MM355_GEMM_RESIDUAL    8u
+#define MM355_GEMM_ACCUMULATE 16u
+#define MM355_GEMM_OUT_F32    32u
+
+int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb,
+                    void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                    const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr, int64_t res_row_mod,
+                    uint32_t flags, int variant, void* stream);
+int mm355_gemm_num_variants(void);
+
+/* out[c][r] = in[r][c]   (rows x cols -> cols x rows), bf16.  Used for the backward GEMM operands. */
+int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols,
+                         mm355_bf16* out, int64_t ld_out, void* stream);
+
+/* column sums: db[n] (+)= sum_m dY[m][n]  (bias gradients of mm_projector / vision_head). */
+int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RMSNorm -- HF LlamaRMSNorm (fp32 normalise, cast to bf16, THEN multiply by weight); K7.
+ * bwd: dx[m] = (dres ? dres[m] : 0) + d/dx ; dw_f32[h] += sum_m dy*xhat (caller zeroes dw_f32).
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h,
+                      float eps, void* stream);
+int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w,
+                      const mm355_bf16* dres, mm355_bf16* dx, float* dw_f32,
+                      int64_t M, int64_t h, float eps, void* stream);
+
+/* LayerNorm forward (SigLIP encoder, eps 1e-6); the tower is frozen in every shipped recipe. */
+int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y,
+                        int64_t M, int64_t h, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoPE -- HF apply_rotary_pos_emb, rotate-half convention, theta from config; K9.
+ * Tables: cos/sin[L][d] bf16 (fp32 math, then cast -- LlamaRotaryEmbedding.forward).
+ * mm355_rope_qk rotates the q and k column blocks of a fused qkv activation [B*L, ld] IN PLACE
+ * (q heads at column 0, k heads at column Hq*d).  inverse != 0 applies the transposed rotation
+ * (backward).  Position of row (b,l) is l.
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, float theta, void* stream);
+int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                  const mm355_bf16* cos_t, const mm355_bf16* sin_t, int inverse, void* stream);
+
+/* out[b][h][dd][l] = in[(b*L + l)*ld + col0 + h*d + dd]   (per-head transposes for attention).
+ * Lp >= L is the padded row length of `out` (columns [L,Lp) are zero filled). */
+int mm355_head_transpose(const mm355_bf16* in, int64_t ld, int64_t col0, int64_t B, int64_t L, int64_t H,
+                         int64_t d, mm355_bf16* out, int64_t Lp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention -- torch SDPA as driven by HF LlamaModel (causal + key padding, GQA, fp32 softmax; K10)
+ * and by HF SiglipAttention (non causal, d = 72; K2).
+ * q/k/v are column blocks of row-major activations: element (b,l,head,dd) at
+ *   ptr[(b*L + l)*ld + head*d + dd].   vt = V transposed per kv head [B][Hkv][d][Lp].
+ * seqlens[b] = number of valid (non padding) keys of sample b (right padding); NULL = L.
+ * o: [B*L][Hq*d] bf16; lse: [B][Hq][L] f32 (natural-log sum-exp of the scaled scores).
+ * Rows l >= seqlens[b] produce o = 0, lse = 0.
+ * Supported d: 64, 128 (LLaMA), 72 (SigLIP SO400M), any d % 8 == 0 and d <= 128.
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* vt, int64_t ld_q, int64_t ld_k,
+                   mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
+                   int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d,
+                   float scale, int causal, void* stream);
+
+/* delta[b][h][l] = sum_dd dO*O ; also writes dOt = dO transposed per head [B][Hq][d][Lp]. */
+int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta,
+                        mm355_bf16* dot, int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t d, void* stream);
+
+/* Backward.  qt/kt/dot are per-head transposes [B][H][d][Lp]; dq_f32 [B*L][Hq*d] must be zeroed by the
+ * caller (accumulated with atomics); dk/dv written as column blocks with leading dimension ld_dkv. */
+int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
+                   const mm355_bf16* d_o, int64_t ld_o,
+                   const mm355_bf16* qt, const mm355_bf16* kt, const mm355_bf16* dot,
+                   const float* lse, const float* delta, const int32_t* seqlens,
+                   float* dq_f32, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
+                   int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d,
+                   float scale, int causal, void* stream);
+
+/* dq_f32 [M][Hq*d] -> bf16 into the q column block of dqkv (optionally through the inverse RoPE);
+ * used after mm355_attn_bwd.  cos_t/sin_t NULL = plain cast. */
+int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int64_t ld_out,
+                           int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise: SwiGLU (HF LlamaMLP; K12), GELU (projector / vision_head), scaling helpers.
+ * gu = [M][2I] with gate in columns [0,I) and up in [I,2I).
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_swiglu_fwd(const mm355_bf16* gu, mm355_bf16* act, int64_t M, int64_t I, void* stream);
+int mm355_swiglu_bwd(const mm355_bf16* gu, const mm355_bf16* dact, mm355_bf16* dgu, mm355_bf16* act,
+                     int64_t M, int64_t I, void* stream);
+#define MM355_GELU_ERF  0
+#define MM355_GELU_TANH 1
+int mm355_gelu_fwd(const mm355_bf16* x, mm355_bf16* y, int64_t n, int kind, void* stream);
+int mm355_gelu_bwd(const mm355_bf16* x, const mm355_bf16* dy, mm355_bf16* dx, int64_t n, int kind, void* stream);
+/* x[i] *= *s_dev (optionally times s_host) */
+int mm355_scale_bf16(mm355_bf16* x, int64_t n, const float* s_dev, float s_host, void* stream);
+/* y[i] (+)= s * x[i]; y bf16, x bf16/f32 */
+int mm355_axpy_bf16(mm355_bf16* y, const mm355_bf16* x, int64_t n, const float* s_dev, float s_host,
+                    int accumulate, void* stream);
+int mm355_axpy_f32_to_bf16(mm355_bf16* y, const float* x, int64_t n, float s_host, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cross entropy over a chunk of rows of bf16 logits (metamorph_llama.py:398-413; K13).
+ * logits [R][ld] bf16 (columns [V,ld) are padding).  targets[r] in [0,V) or < 0 = ignored row.
+ * loss_sum += sum_r (lse_r - logit_r[target]);  then, IN PLACE, logits <- grad_scale*(softmax - onehot)
+ * (zero on ignored rows and padding columns).  fp32 math on the bf16-rounded logits like the reference's
+ * `.float()`; rows are compacted by the host so ignored rows normally never reach this kernel.
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V,
+                  float grad_scale, float* loss_sum, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Splice (metamorph_arch.py:259-399; K6) driven by the host gather plan (bit-exact int bookkeeping):
+ *   src[r] >= 0        -> row src[r] of embed_tokens.weight
+ *   src[r] == -1       -> zero row (padding)
+ *   src[r] <= -2       -> row (-2 - src[r]) of the projected image features
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_splice_gather(const mm355_bf16* embed, const mm355_bf16* proj, const int32_t* src,
+                        mm355_bf16* out, int64_t rows, int64_t h, void* stream);
+/* backward into the projector output: dproj[n] = dout[row_of_feature[n]] or 0 when row_of_feature[n] < 0 */
+int mm355_rows_gather(const mm355_bf16* in, int64_t ld_in, const int32_t* idx, mm355_bf16* out, int64_t ld_out,
+                      int64_t R, int64_t h, void* stream);
+/* dst[idx[r]] += src[r]   (idx unique) */
+int mm355_rows_scatter_add(const mm355_bf16* src, int64_t ld_src, const int32_t* idx, mm355_bf16* dst,
+                           int64_t ld_dst, int64_t R, int64_t h, void* stream);
+/* embedding gradient: for segment s (token id tok[s]) sum rows pos[seg_start[s] .. seg_start[s+1]) of dout
+ * in fp32 and (accumulate ? add to : store as) dembed[tok[s]].  Deterministic, no atomics. */
+int mm355_embed_grad(const mm355_bf16* dout, const int32_t* tok, const int32_t* seg_start, const int32_t* pos,
+                     int64_t n_seg, mm355_bf16* dembed, int64_t h, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vision front/back ends.
+ * im2col: images [N][3][H][W] (f32 or bf16) -> patches [N*gh*gw][Kp] bf16, k = c*p*p + dy*p + dx,
+ *         columns [3*p*p, Kp) zero  (SigLIP patch embedding Conv2d 14x14/14, "valid"; K1).
+ * bilinear_l2norm: [N][side_in^2][C] -> [N][side_out^2][C]; fp32 bilinear (align_corners=False), round to
+ *         bf16, then F.normalize(p=2, eps 1e-12) in bf16 when normalize != 0 (siglip_encoder.py:151-163,206-208).
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_im2col_patch(const void* images, int images_are_f32, int64_t N, int64_t H, int64_t W, int64_t p,
+                       mm355_bf16* out, int64_t Kp, void* stream);
+int mm355_bilinear_l2norm(const mm355_bf16* in, mm355_bf16* out, int64_t N, int64_t side_in, int64_t side_out,
+                          int64_t C, int normalize, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cosine regression loss (metamorph_llama.py:433-435,449-455; K16).  pred_raw = vision_head output.
+ *   p = normalize ? F.normalize(pred_raw) (bf16 rounded) : pred_raw
+ *   loss_sum += sum_r cos(target_r, p_r)  (caller turns it into -mean);  dpred = d(-mean cos)/d pred_raw * 1
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
+                      float* cos_sum, mm355_bf16* dpred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ZeRO-2 shard update (replaces DeepSpeed zero2.json + HF adamw_torch, train.py:82): AdamW on the
+ * rank's fp32 master shard, writes the updated bf16 parameters.  grad_scale_dev (nullable) is a device
+ * scalar multiplied into the gradient (1/world, clip coefficient).
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_adamw_shard(float* p32, float* m, float* v, const mm355_bf16* g, mm355_bf16* p_out, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float bias_corr1, float bias_corr2, const float* grad_scale_dev, void* stream);
+/* out[0] += sum x^2 (grad-norm partial) */
+int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, void* stream);
+/* clip coefficient: coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) * pre_scale */
+int mm355_clip_coef(const float* sumsq, float max_norm, float pre_scale, float* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM355_H */

@@ -1,0 +1,393 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] . B[N,K]^T)  -- the nn.Linear form.
+//
+// Replaces the cuBLAS GEMMs the reference reaches through nn.Linear (see include/mm355.h).
+//
+// Structure (per workgroup): BM x BN output tile, BK = 64, WM x WN waves, each wave owns a
+// (BM/WM) x (BN/WN) sub-tile as 16x16 fragments of v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+//   * A and B tiles live in LDS as [rows][64 bf16] (128-B rows) with the 16-B chunk index XOR-ed with
+//     (row & 7): ds_read_b128 fragment reads are bank-conflict free (cdna guide T2).
+//   * staging: either register staged (global_load_dwordx4 -> ds_write_b128; handles ragged K) or
+//     LDS-DMA (global_load_lds_dwordx4; the swizzle is applied to the per-lane SOURCE address because the
+//     LDS destination of the DMA is lane-linear).  Two LDS stages, next tile in flight during the MFMAs.
+//   * epilogue: accumulators -> wave-private LDS slab -> row-contiguous 16-B stores with bias / GELU /
+//     residual / accumulate fused.
+//   * workgroup -> tile map: bijective XCD remap (block b runs on XCD b % 8) then grouped raster so the
+//     blocks sharing an XCD's L2 walk neighbouring tiles.
+#include "mm355_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const uint16_t* A;
+    const uint16_t* B;
+    void* C;
+    const uint16_t* bias;
+    const uint16_t* res;
+    int64_t lda, ldb, ldc, ldr, res_mod;
+    int M, N, K;
+    uint32_t flags;
+    int ntm, ntn;
+};
+
+// ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
+// so the unrolled fast path stays small.
+__device__ __attribute__((noinline)) void epi_scalar(const GemmArgs& a, int grow, int c, int64_t rr, float v0, float v1,
+                                                     float v2, float v3, float v4, float v5, float v6, float v7) {
+    const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+    const uint32_t fl = a.flags;
+    for (int e = 0; e < 8; ++e) {
+        const int ce = c + e;
+        if (ce >= a.N) break;
+        float x = v[e];
+        if (fl & MM355_GEMM_BIAS) x += bf2f(a.bias[ce]);
+        if (fl & MM355_GEMM_GELU_ERF) x = gelu_erf_f(x);
+        else if (fl & MM355_GEMM_GELU_TANH) x = gelu_tanh_f(x);
+        if (fl & MM355_GEMM_RESIDUAL) x += bf2f(a.res[rr * a.ldr + ce]);
+        if (fl & MM355_GEMM_OUT_F32) {
+            float* p = (float*)a.C + (int64_t)grow * a.ldc + ce;
+            if (fl & MM355_GEMM_ACCUMULATE) x += *p;
+            *p = x;
+        } else {
+            uint16_t* p = (uint16_t*)a.C + (int64_t)grow * a.ldc + ce;
+            if (fl & MM355_GEMM_ACCUMULATE) x += bf2f(*p);
+            *p = f2bf(x);
+        }
+    }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int NT = WM * WN * 64, NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;           // 16-B vectors per thread (reg staging)
+    constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;           // 1-KiB DMA pieces per wave (glds)
+    constexpr int GM = 8;
+    static_assert(FM >= 1 && FN >= 2 && (FN % 2) == 0, "tile shape");
+    static_assert(AV >= 1 && BV >= 1 && AI >= 1 && BI >= 1, "thread/tile ratio");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- workgroup -> tile --------------------------------------------------------------------
+    const int total = a.ntm * a.ntn;
+    const int bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int gsize = GM * a.ntn;
+    const int grp = logical / gsize;
+    const int first_m = grp * GM;
+    const int gm = min(a.ntm - first_m, GM);
+    const int in_g = logical - grp * gsize;
+    const int tm = first_m + in_g % gm;
+    const int tn = in_g / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, N = a.N, K = a.K;
+    const int nk = (K + 63) >> 6;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int sw0 = ((fq) ^ (fr & 7)) << 4;
+    const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const int a_off = (wm * TM + fr) * 128;
+    const int b_off = A_BYTES + (wn * TN + fr) * 128;
+
+    u32x4 ra[AV], rb[BV];
+
+    auto gload = [&](int kt) {
+        const int k0 = kt << 6;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + i * NT, row = v >> 3, c = v & 7;
+            const int gr = min(m0 + row, M - 1), k = k0 + c * 8;
+            ra[i] = (k < K) ? *(const u32x4*)(a.A + (int64_t)gr * a.lda + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int v = tid + i * NT, row = v >> 3, c = v & 7;
+            const int gr = min(n0 + row, N - 1), k = k0 + c * 8;
+            rb[i] = (k < K) ? *(const u32x4*)(a.B + (int64_t)gr * a.ldb + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + i * NT, row = v >> 3, c = v & 7;
+            *(u32x4*)(sb + row * 128 + ((c ^ (row & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int v = tid + i * NT, row = v >> 3, c = v & 7;
+            *(u32x4*)(sb + A_BYTES + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
+        }
+    };
+    auto gdma = [&](int kt, int buf) {
+        const int k0 = kt << 6;
+        const int rin = lane >> 3;                       // row inside the 8-row piece
+        const int c = (lane & 7) ^ rin;                  // source chunk that belongs in LDS slot (lane & 7)
+        unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int piece = i * NW + wave;
+            const int gr = min(m0 + piece * 8 + rin, M - 1);
+            const uint16_t* g = a.A + (int64_t)gr * a.lda + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sb + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int piece = i * NW + wave;
+            const int gr = min(n0 + piece * 8 + rin, N - 1);
+            const uint16_t* g = a.B + (int64_t)gr * a.ldb + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sb + A_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- main loop -----------------------------------------------------------------------------
+    if constexpr (GLDS) {
+        gdma(0, 0);
+    } else {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if constexpr (GLDS) gdma(kt + 1, cur ^ 1);
+            else gload(kt + 1);
+        }
+        const unsigned char* sb = smem + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = kk ? sw1 : sw0;
+            bf16x8 af[FM], bf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sb + a_off + i * 2048 + sw);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *(const bf16x8*)(sb + b_off + j * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (!GLDS) {
+            if (more) lstore(cur ^ 1);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    constexpr int CPL = TN / 4;                          // columns handled by one lane per row
+    float* stg = (float*)smem + wave * (16 * TN);
+    const uint32_t fl = a.flags;
+    const int row_l = lane >> 2, col_l = (lane & 3) * CPL;
+    uint16_t* Cb = (uint16_t*)a.C;
+    float* Cf = (float*)a.C;
+    const bool vec_ok = ((a.ldc & 7) == 0) && (!(fl & MM355_GEMM_RESIDUAL) || (a.ldr & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
+        __syncthreads();
+        const int grow = m0 + wm * TM + i * 16 + row_l;
+        if (grow < M) {
+            const int64_t rr = (fl & MM355_GEMM_RESIDUAL) ? (a.res_mod > 0 ? (int64_t)(grow % a.res_mod) : (int64_t)grow) : 0;
+#pragma unroll
+            for (int j = 0; j < CPL / 8; ++j) {
+                const int c = n0 + wn * TN + col_l + j * 8;
+                if (c >= N) continue;
+                float v[8];
+                const f32x4 s0 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8);
+                const f32x4 s1 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8 + 4);
+                v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w;
+                v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+                const bool full = (c + 8 <= N) && vec_ok;
+                if (full) {
+                    if (fl & MM355_GEMM_BIAS) {
+                        float b[8];
+                        unpack8(*(const u32x4*)(a.bias + c), b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += b[e];
+                    }
+                    if (fl & MM355_GEMM_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                    } else if (fl & MM355_GEMM_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    }
+                    if (fl & MM355_GEMM_RESIDUAL) {
+                        float b[8];
+                        unpack8(*(const u32x4*)(a.res + rr * a.ldr + c), b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += b[e];
+                    }
+                    if (fl & MM355_GEMM_OUT_F32) {
+                        float* p = Cf + (int64_t)grow * a.ldc + c;
+                        if (fl & MM355_GEMM_ACCUMULATE) {
+                            const f32x4 o0 = *(const f32x4*)p, o1 = *(const f32x4*)(p + 4);
+                            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
+                            v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                        }
+                        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        uint16_t* p = Cb + (int64_t)grow * a.ldc + c;
+                        if (fl & MM355_GEMM_ACCUMULATE) {
+                            float b[8];
+                            unpack8(*(const u32x4*)p, b);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += b[e];
+                        }
+                        *(u32x4*)p = pack8(v);
+                    }
+                } else {
+                    epi_scalar(a, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+int launch_gemm(GemmArgs a, hipStream_t s) {
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int LDS = 2 * STAGE;
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS>;
+    static bool attr_done = false;                       // idempotent one-time attribute (benign race)
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    a.ntm = (a.M + BM - 1) / BM;
+    a.ntn = (a.N + BN - 1) / BN;
+    const int64_t total = (int64_t)a.ntm * a.ntn;
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(WM * WN * 64), LDS, s, a);
+    return mm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose: out[c][r] = in[r][c], 64x64 tiles through LDS, 16-B global accesses on both sides.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ in, int64_t ld_in, int rows, int cols,
+                                                        uint16_t* __restrict__ out, int64_t ld_out) {
+    __shared__ uint16_t tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    // load: 64 rows x 8 vectors
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, r = v >> 3, c = (v & 7) * 8;
+        const int gr = r0 + r, gc = c0 + c;
+        uint16_t tmp[8];
+        if (gr < rows && gc + 8 <= cols) {
+            *(u32x4*)tmp = *(const u32x4*)(in + (int64_t)gr * ld_in + gc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tmp[e] = (gr < rows && gc + e < cols) ? in[(int64_t)gr * ld_in + gc + e] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][c + e] = tmp[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, c = v >> 3, r = (v & 7) * 8;   // output row = input col c
+        const int gc = c0 + c, gr = r0 + r;
+        if (gc >= cols) continue;
+        uint16_t tmp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmp[e] = tile[r + e][c];
+        if (gr + 8 <= rows && ((ld_out & 7) == 0)) {
+            *(u32x4*)(out + (int64_t)gc * ld_out + gr) = *(const u32x4*)tmp;
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (gr + e < rows) out[(int64_t)gc * ld_out + gr + e] = tmp[e];
+        }
+    }
+}
+
+// column sums of a [M][N] bf16 matrix into fp32 (atomic accumulate; caller zeroes)
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, int64_t ld, int M, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += bf2f(x[(int64_t)r * ld + c]);
+    atomicAdd(out + c, s);
+}
+
+}  // namespace
+
+extern "C" int mm355_gemm_num_variants(void) { return 6; }
+
+extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
+                               int64_t ldr, int64_t res_row_mod, uint32_t flags, int variant, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
+    if ((K & 7) || (lda & 7) || (ldb & 7) || !mm_aligned16(A) || !mm_aligned16(B) || !mm_aligned16(C)) return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    if ((flags & MM355_GEMM_BIAS) && (!bias || !mm_aligned16(bias))) return MM355_EINVAL;
+    if ((flags & MM355_GEMM_RESIDUAL) && (!residual || !mm_aligned16(residual))) return MM355_EINVAL;
+    if ((flags & MM355_GEMM_GELU_ERF) && (flags & MM355_GEMM_GELU_TANH)) return MM355_EINVAL;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.res = residual;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_row_mod;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool dma_ok = (K % 64) == 0;
+    if (variant == 0) {
+        // auto: LDS-DMA staging whenever K is a whole number of 64-wide tiles; the 256x256 tile once it
+        // still yields at least one full wave of workgroups over the 256 CUs.
+        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (dma_ok) variant = (t256 >= 200) ? 6 : 2;
+        else variant = 1;
+    }
+    if (!dma_ok && (variant == 2 || variant == 4 || variant == 6)) return MM355_EUNSUPPORTED;
+    switch (variant) {
+        case 1: return launch_gemm<128, 128, 2, 2, false>(a, s);
+        case 2: return launch_gemm<128, 128, 2, 2, true>(a, s);
+        case 3: return launch_gemm<256, 128, 4, 2, false>(a, s);
+        case 4: return launch_gemm<256, 128, 4, 2, true>(a, s);
+        case 5: return launch_gemm<256, 256, 2, 4, false>(a, s);
+        case 6: return launch_gemm<256, 256, 2, 4, true>(a, s);
+        default: return MM355_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols, mm355_bf16* out,
+                                    int64_t ld_out, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || (ld_in & 7) || !mm_aligned16(in) || !mm_aligned16(out)) return MM355_EINVAL;
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (int)rows, (int)cols, out, ld_out);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream) {
+    if (!dY || !db_f32 || M <= 0 || N <= 0) return MM355_EINVAL;
+    const int rpb = 256;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32, rpb);
+    return mm_launch_status();
+}

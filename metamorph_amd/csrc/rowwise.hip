@@ -1,0 +1,406 @@
+// Row-wise HBM-bound kernels of the MetaMorph hot path (gfx950): RMSNorm fwd/bwd, LayerNorm fwd,
+// cross-entropy over logits rows, cosine regression loss, bilinear token reduction + L2 normalise.
+// All loads/stores are 16-byte vectors (8 bf16); reductions are wave shuffles + one LDS hop.
+#include "mm355_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm forward: y = w * bf16(x * rsqrt(mean(x^2) + eps))      (HF LlamaRMSNorm order of roundings)
+// one workgroup per row, row cached in registers (VPT vectors of 8 per thread).
+// ------------------------------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                         uint16_t* __restrict__ y, int h, float eps) {
+    __shared__ float red[NT / 64];
+    const int64_t row = blockIdx.x;
+    const int nv = h >> 3;
+    const uint16_t* xr = x + row * h;
+    float xv[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+            unpack8(*(const u32x4*)(xr + v * 8), xv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+        }
+    }
+    ss = block_sum<NT>(ss, red);
+    const float rstd = rsqrtf(ss / (float)h + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+            float wv[8], o[8];
+            unpack8(*(const u32x4*)(w + v * 8), wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * round_bf(xv[i][e] * rstd);
+            *(u32x4*)(y + row * h + v * 8) = pack8(o);
+        }
+    }
+}
+
+// RMSNorm backward.  Each workgroup walks `rows_per_block` rows; a thread owns fixed columns so the
+// weight gradient is accumulated in registers and flushed with one atomicAdd per column per workgroup.
+template <int VPT>
+__global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                         const uint16_t* __restrict__ w, const uint16_t* __restrict__ dres,
+                                                         uint16_t* __restrict__ dx, float* __restrict__ dw, int M, int h,
+                                                         float eps, int rows_per_block) {
+    __shared__ float red[NT / 64];
+    const int nv = h >> 3;
+    float wv[VPT][8], dwacc[VPT][8];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[i][e] = 0.f; wv[i][e] = 0.f; }
+        if (v < nv) unpack8(*(const u32x4*)(w + v * 8), wv[i]);
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int row = r0; row < r1; ++row) {
+        const uint16_t* xr = x + (int64_t)row * h;
+        const uint16_t* gr = dy + (int64_t)row * h;
+        float xv[VPT][8], gv[VPT][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+                unpack8(*(const u32x4*)(xr + v * 8), xv[i]);
+                unpack8(*(const u32x4*)(gr + v * 8), gv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+            }
+        }
+        ss = block_sum<NT>(ss, red);
+        const float rstd = rsqrtf(ss / (float)h + eps);
+        float dot = 0.f;                                    // sum_c (dy*w) * xhat
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = xv[i][e] * rstd;
+                    dwacc[i][e] += gv[i][e] * round_bf(xh);
+                    gv[i][e] *= wv[i][e];
+                    dot += gv[i][e] * xh;
+                }
+            }
+        }
+        dot = block_sum<NT>(dot, red) / (float)h;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+                float o[8];
+                if (dres) unpack8(*(const u32x4*)(dres + (int64_t)row * h + v * 8), o);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += rstd * (gv[i][e] - xv[i][e] * rstd * dot);
+                *(u32x4*)(dx + (int64_t)row * h + v * 8) = pack8(o);
+            }
+        }
+    }
+    if (dw) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(dw + v * 8 + e, dwacc[i][e]);
+            }
+        }
+    }
+}
+
+// LayerNorm forward (fp32 math, one rounding at the end, like torch.layer_norm on bf16).
+template <int VPT>
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                           const uint16_t* __restrict__ b, uint16_t* __restrict__ y, int h, float eps) {
+    __shared__ float red[NT / 64];
+    const int64_t row = blockIdx.x;
+    const int nv = h >> 3;
+    float xv[VPT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+            unpack8(*(const u32x4*)(x + row * h + v * 8), xv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += xv[i][e];
+        }
+    }
+    const float mean = block_sum<NT>(s, red) / (float)h;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum<NT>(ss, red) / (float)h + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+            float wv[8], bv[8], o[8];
+            unpack8(*(const u32x4*)(w + v * 8), wv);
+            unpack8(*(const u32x4*)(b + v * 8), bv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (xv[i][e] - mean) * rstd * wv[e] + bv[e];
+            *(u32x4*)(y + row * h + v * 8) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross entropy over rows of bf16 logits, gradient written in place.   one workgroup (512 thr) per row.
+// pass 1: online max / sum-exp;  pass 2: g = scale * (softmax - onehot)
+// ------------------------------------------------------------------------------------------------
+constexpr int CE_NT = 512;
+__global__ __launch_bounds__(CE_NT) void ce_rows_kernel(uint16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ targets,
+                                                        int V, float grad_scale, float* __restrict__ loss_sum) {
+    __shared__ float red[CE_NT / 64];
+    const int64_t row = blockIdx.x;
+    uint16_t* lr = logits + row * ld;
+    const int tgt = targets[row];
+    const int nvec = (int)(ld >> 3);
+    if (tgt < 0) {                                           // ignored row: zero gradient
+        for (int v = threadIdx.x; v < nvec; v += CE_NT) *(u32x4*)(lr + v * 8) = u32x4{0u, 0u, 0u, 0u};
+        return;
+    }
+    float m = -INFINITY, s = 0.f;
+    for (int v = threadIdx.x; v < nvec; v += CE_NT) {
+        float f[8];
+        unpack8(*(const u32x4*)(lr + v * 8), f);
+        float lm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if (v * 8 + e >= V) f[e] = -INFINITY; lm = fmaxf(lm, f[e]); }
+        if (lm > m) { s *= __expf(m - lm); m = lm; }
+        if (m > -INFINITY) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
+        }
+    }
+    const float gmax = block_max<CE_NT>(m, red);
+    s = (m > -INFINITY) ? s * __expf(m - gmax) : 0.f;
+    const float gsum = block_sum<CE_NT>(s, red);
+    const float lse = gmax + __logf(gsum);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(lr[tgt]));
+    __syncthreads();                                         // target logit read before it is overwritten
+    for (int v = threadIdx.x; v < nvec; v += CE_NT) {
+        float f[8];
+        unpack8(*(const u32x4*)(lr + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = v * 8 + e;
+            float g = (c < V) ? __expf(f[e] - lse) : 0.f;
+            if (c == tgt) g -= 1.0f;
+            f[e] = g * grad_scale;
+        }
+        *(u32x4*)(lr + v * 8) = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cosine regression loss, one wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void cosine_loss_kernel(const uint16_t* __restrict__ pred, const uint16_t* __restrict__ tgt, int R, int C,
+                                                         int normalize, float* __restrict__ cos_sum, uint16_t* __restrict__ dpred) {
+    const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int nv = C >> 3;
+    const uint16_t* pr = pred + (int64_t)row * C;
+    const uint16_t* tr = tgt + (int64_t)row * C;
+    float pp = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        float p[8];
+        unpack8(*(const u32x4*)(pr + v * 8), p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pp += p[e] * p[e];
+    }
+    pp = wave_sum(pp);
+    // F.normalize on a bf16 tensor: norm rounded to bf16, clamp, divide, round
+    const float pn = normalize ? fmaxf(round_bf(sqrtf(pp)), 1e-12f) : 1.0f;
+    float tt = 0.f, uu = 0.f, tu = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        float p[8], t[8];
+        unpack8(*(const u32x4*)(pr + v * 8), p);
+        unpack8(*(const u32x4*)(tr + v * 8), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = normalize ? round_bf(p[e] / pn) : p[e];
+            tt += t[e] * t[e]; uu += u * u; tu += t[e] * u;
+        }
+    }
+    tt = wave_sum(tt); uu = wave_sum(uu); tu = wave_sum(tu);
+    const float nt = fmaxf(sqrtf(tt), 1e-8f), nu = fmaxf(sqrtf(uu), 1e-8f);
+    const float c = tu / (nt * nu);
+    if (lane == 0) atomicAdd(cos_sum, c);
+    if (!dpred) return;
+    // w = d cos / d u = (t/nt - c * u/nu) / nu ;  d u / d p = (I - phat phat^T) / pn
+    const float inv_r = -1.0f / (float)R;
+    float pw = 0.f;                                          // phat . w  (only when normalising)
+    const float pnorm = sqrtf(pp);
+    if (normalize) {
+        for (int v = lane; v < nv; v += 64) {
+            float p[8], t[8];
+            unpack8(*(const u32x4*)(pr + v * 8), p);
+            unpack8(*(const u32x4*)(tr + v * 8), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = round_bf(p[e] / pn);
+                const float w = (t[e] / nt - c * u / nu) / nu;
+                pw += p[e] * w;
+            }
+        }
+        pw = wave_sum(pw) / fmaxf(pnorm, 1e-20f);
+    }
+    for (int v = lane; v < nv; v += 64) {
+        float p[8], t[8], g[8];
+        unpack8(*(const u32x4*)(pr + v * 8), p);
+        unpack8(*(const u32x4*)(tr + v * 8), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = normalize ? round_bf(p[e] / pn) : p[e];
+            const float w = (t[e] / nt - c * u / nu) / nu;
+            g[e] = normalize ? inv_r * (w - (p[e] / fmaxf(pnorm, 1e-20f)) * pw) / pn : inv_r * w;
+        }
+        *(u32x4*)(dpred + (int64_t)row * C + v * 8) = pack8(g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear token reduction (fp32, align_corners=False) + L2 normalise; one wave per output token.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lerp_src(int o, int in_size, int out_size, int& i0, int& i1, float& w1) {
+    const float scale = (float)in_size / (float)out_size;
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(NT) void bilinear_l2norm_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int N, int si, int so,
+                                                             int C, int normalize) {
+    const int tok = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tok >= N * so * so) return;
+    const int n = tok / (so * so), oy = (tok / so) % so, ox = tok % so;
+    const int nv = C >> 3;
+    int y0, y1, x0, x1; float ly, lx;
+    if (si == so) { y0 = y1 = oy; x0 = x1 = ox; ly = lx = 0.f; }
+    else { lerp_src(oy, si, so, y0, y1, ly); lerp_src(ox, si, so, x0, x1, lx); }
+    const uint16_t* b = in + (int64_t)n * si * si * C;
+    const uint16_t* p00 = b + (int64_t)(y0 * si + x0) * C;
+    const uint16_t* p01 = b + (int64_t)(y0 * si + x1) * C;
+    const uint16_t* p10 = b + (int64_t)(y1 * si + x0) * C;
+    const uint16_t* p11 = b + (int64_t)(y1 * si + x1) * C;
+    uint16_t* o = out + (int64_t)tok * C;
+    float ss = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        float a[8], bq[8], c[8], d[8], r[8];
+        unpack8(*(const u32x4*)(p00 + v * 8), a);
+        unpack8(*(const u32x4*)(p01 + v * 8), bq);
+        unpack8(*(const u32x4*)(p10 + v * 8), c);
+        unpack8(*(const u32x4*)(p11 + v * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float top = a[e] * (1.0f - lx) + bq[e] * lx;
+            const float bot = c[e] * (1.0f - lx) + d[e] * lx;
+            r[e] = round_bf(si == so ? a[e] : top * (1.0f - ly) + bot * ly);
+            ss += r[e] * r[e];
+        }
+        *(u32x4*)(o + v * 8) = pack8(r);
+    }
+    if (!normalize) return;
+    ss = wave_sum(ss);
+    const float nrm = fmaxf(round_bf(sqrtf(ss)), 1e-12f);
+    for (int v = lane; v < nv; v += 64) {                    // same lane re-reads what it wrote
+        float r[8];
+        unpack8(*(const u32x4*)(o + v * 8), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = r[e] / nrm;
+        *(u32x4*)(o + v * 8) = pack8(r);
+    }
+}
+
+template <typename F>
+int dispatch_vpt(int h, F&& f) {
+    const int nv = h >> 3;
+    if (nv <= NT) return f(std::integral_constant<int, 1>{});
+    if (nv <= 2 * NT) return f(std::integral_constant<int, 2>{});
+    if (nv <= 4 * NT) return f(std::integral_constant<int, 4>{});
+    if (nv <= 8 * NT) return f(std::integral_constant<int, 8>{});
+    return MM355_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h, float eps, void* stream) {
+    if (!x || !w || !y || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
+    return dispatch_vpt((int)h, [&](auto vpt) {
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, y, (int)h, eps);
+        return mm_launch_status();
+    });
+}
+
+extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres,
+                                 mm355_bf16* dx, float* dw_f32, int64_t M, int64_t h, float eps, void* stream) {
+    if (!dy || !x || !w || !dx || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
+    const int rpb = M >= 8192 ? 16 : (M >= 1024 ? 4 : 1);
+    const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+    return dispatch_vpt((int)h, [&](auto vpt) {
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<decltype(vpt)::value>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, x, w, dres, dx,
+                           dw_f32, (int)M, (int)h, eps, rpb);
+        return mm_launch_status();
+    });
+}
+
+extern "C" int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y, int64_t M, int64_t h,
+                                   float eps, void* stream) {
+    if (!x || !w || !b || !y || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
+    return dispatch_vpt((int)h, [&](auto vpt) {
+        hipLaunchKernelGGL((layernorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, b, y, (int)h, eps);
+        return mm_launch_status();
+    });
+}
+
+extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V, float grad_scale,
+                             float* loss_sum, void* stream) {
+    if (!logits || !targets || !loss_sum || R <= 0 || V <= 0 || ld < V || (ld & 7) || R > 0x7fffffff || !mm_aligned16(logits)) return MM355_EINVAL;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(CE_NT), 0, (hipStream_t)stream, logits, ld, targets, (int)V, grad_scale, loss_sum);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
+                                 float* cos_sum, mm355_bf16* dpred, void* stream) {
+    if (!pred_raw || !target || !cos_sum || R <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
+    const unsigned grid = (unsigned)((R + NT / 64 - 1) / (NT / 64));
+    hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize, cos_sum, dpred);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_bilinear_l2norm(const mm355_bf16* in, mm355_bf16* out, int64_t N, int64_t side_in, int64_t side_out, int64_t C,
+                                     int normalize, void* stream) {
+    if (!in || !out || N <= 0 || side_in <= 0 || side_out <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
+    const int64_t toks = N * side_out * side_out;
+    const unsigned grid = (unsigned)((toks + NT / 64 - 1) / (NT / 64));
+    hipLaunchKernelGGL(bilinear_l2norm_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, out, (int)N, (int)side_in, (int)side_out, (int)C, normalize);
+    return mm_launch_status();
+}

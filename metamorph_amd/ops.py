@@ -1,0 +1,387 @@
+"""Tensor-level wrappers over the C ABI (include/mm355.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic op below is a
+hand-written gfx950 kernel in libmm355.so reached through ctypes with raw pointers.  Nothing in this
+module computes with torch ops, and nothing falls back to them.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as _lib
+
+BF16 = torch.bfloat16
+
+GEMM_BIAS, GEMM_GELU_ERF, GEMM_GELU_TANH, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32 = 1, 2, 4, 8, 16, 32
+GELU_ERF, GELU_TANH = 0, 1
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Mm355Unavailable("metamorph_amd ops run only on an MI355X HIP device; got a CPU tensor "
+                                        "(there is no CPU fallback)")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rows2d(t):
+    """(ptr, rows, cols, ld) of a 2-D view whose last dim is contiguous."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    return t.data_ptr(), t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+
+def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, accumulate=False,
+         out_f32=False, variant=0, n=None):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T).  a/b/out may be row-strided 2-D views (bf16)."""
+    _chk_dev(a, b, out, bias, residual)
+    assert a.dtype == BF16 and b.dtype == BF16
+    pa, M, K, lda = _rows2d(a)
+    pb, N, Kb, ldb = _rows2d(b)
+    assert K == Kb, (a.shape, b.shape)
+    if n is not None:
+        N = n
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    po, Mo, No, ldc = _rows2d(out)
+    assert Mo == M and No >= N, (out.shape, M, N)
+    flags = 0
+    if bias is not None:
+        flags |= GEMM_BIAS
+        assert bias.dtype == BF16 and bias.is_contiguous() and bias.numel() >= N
+    if gelu == "erf":
+        flags |= GEMM_GELU_ERF
+    elif gelu == "tanh":
+        flags |= GEMM_GELU_TANH
+    elif gelu is not None:
+        raise ValueError(gelu)
+    ldr = 0
+    if residual is not None:
+        flags |= GEMM_RESIDUAL
+        assert residual.dtype == BF16
+        _, _, _, ldr = _rows2d(residual)
+    if accumulate:
+        flags |= GEMM_ACCUMULATE
+    if out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    else:
+        assert out.dtype == BF16
+    rc = _L().mm355_gemm_bf16(pa, lda, pb, ldb, po, ldc, M, N, K, _p(bias), _p(residual), ldr, res_row_mod,
+                              flags, variant, _stream())
+    _lib.check(rc, f"mm355_gemm_bf16 M={M} N={N} K={K} lda={lda} ldb={ldb} ldc={ldc} flags={flags} variant={variant}")
+    return out
+
+
+def transpose(x, out=None, ld_out=None):
+    """out[c, r] = x[r, c]"""
+    _chk_dev(x, out)
+    px, R, C, ld = _rows2d(x)
+    if out is None:
+        ldo = ld_out or ((R + 7) // 8 * 8)
+        buf = torch.empty((C, ldo), device=x.device, dtype=BF16)
+        out = buf[:, :R]
+    po, Co, Ro, ldo = _rows2d(out)
+    assert Co == C and Ro == R
+    _lib.check(_L().mm355_transpose_bf16(px, ld, R, C, po, ldo, _stream()), "mm355_transpose_bf16")
+    return out
+
+
+def colsum_f32(dy, out_f32):
+    _chk_dev(dy, out_f32)
+    p, M, N, ld = _rows2d(dy)
+    assert out_f32.dtype == torch.float32 and out_f32.numel() >= N
+    _lib.check(_L().mm355_colsum_bf16(p, ld, M, N, out_f32.data_ptr(), _stream()), "mm355_colsum_bf16")
+    return out_f32
+
+
+# ------------------------------------------------------------------------------------------------ norms
+
+def rmsnorm_fwd(x, w, eps, out=None):
+    _chk_dev(x, w)
+    assert x.is_contiguous() and x.dtype == BF16 and w.dtype == BF16
+    h = x.shape[-1]
+    M = x.numel() // h
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_L().mm355_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, h, eps, _stream()), "mm355_rmsnorm_fwd")
+    return out
+
+
+def rmsnorm_bwd(dy, x, w, eps, dres=None, dw_f32=None, dx=None):
+    _chk_dev(dy, x, w)
+    assert dy.is_contiguous() and x.is_contiguous()
+    h = x.shape[-1]
+    M = x.numel() // h
+    dx = torch.empty_like(x) if dx is None else dx
+    _lib.check(_L().mm355_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), _p(dw_f32),
+                                      M, h, eps, _stream()), "mm355_rmsnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps, out=None):
+    _chk_dev(x, w, b)
+    assert x.is_contiguous()
+    h = x.shape[-1]
+    M = x.numel() // h
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_L().mm355_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, h, eps, _stream()),
+               "mm355_layernorm_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ rope / attention
+
+def rope_table(L, d, theta, device):
+    cos = torch.empty((L, d), device=device, dtype=BF16)
+    sin = torch.empty((L, d), device=device, dtype=BF16)
+    _chk_dev(cos)
+    _lib.check(_L().mm355_rope_table(cos.data_ptr(), sin.data_ptr(), L, d, theta, _stream()), "mm355_rope_table")
+    return cos, sin
+
+
+def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False):
+    """In place on the q (first Hq*d columns) and k (next Hkv*d columns) blocks of qkv [B*L, ld]."""
+    _chk_dev(qkv, cos, sin)
+    p, M, _, ld = _rows2d(qkv)
+    assert M == B * L and cos.shape[0] >= L
+    _lib.check(_L().mm355_rope_qk(p, ld, B, L, Hq, Hkv, d, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "mm355_rope_qk")
+    return qkv
+
+
+def pad64(L):
+    return (L + 63) // 64 * 64
+
+
+def head_transpose(x2d, col0, B, L, H, d):
+    """[B*L, ld] column block -> [B, H, d, Lp]"""
+    _chk_dev(x2d)
+    p, M, _, ld = _rows2d(x2d)
+    assert M == B * L
+    Lp = pad64(L)
+    out = torch.empty((B, H, d, Lp), device=x2d.device, dtype=BF16)
+    _lib.check(_L().mm355_head_transpose(p, ld, col0, B, L, H, d, out.data_ptr(), Lp, _stream()), "mm355_head_transpose")
+    return out
+
+
+def attn_fwd(q2d, k2d, vt, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None):
+    """q2d/k2d: [B*L, ld] views starting at the q / k column blocks; vt: [B,Hkv,d,Lp]."""
+    _chk_dev(q2d, k2d, vt)
+    pq, M, _, ldq = _rows2d(q2d)
+    pk, _, _, ldk = _rows2d(k2d)
+    Lp = vt.shape[-1]
+    if out is None:
+        out = torch.empty((M, Hq * d), device=q2d.device, dtype=BF16)
+    lse = torch.empty((B, Hq, L), device=q2d.device, dtype=torch.float32)
+    _lib.check(_L().mm355_attn_fwd(pq, pk, vt.data_ptr(), ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
+                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlens, dk2d, dv2d):
+    """Returns dq_f32 [B*L, Hq*d]; writes dk/dv into the given column-block views."""
+    _chk_dev(q2d, k2d, v2d, o, d_o)
+    pq, M, _, ldq = _rows2d(q2d)
+    pk, _, _, ldk = _rows2d(k2d)
+    pv, _, _, ldv = _rows2d(v2d)
+    assert ldv == ldk
+    Lp = pad64(L)
+    assert o.is_contiguous() and d_o.is_contiguous()
+    delta = torch.empty((B, Hq, L), device=o.device, dtype=torch.float32)
+    dot = torch.empty((B, Hq, d, Lp), device=o.device, dtype=BF16)
+    _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), dot.data_ptr(),
+                                        B, L, Lp, Hq, d, _stream()), "mm355_attn_bwd_prep")
+    qt = head_transpose(q2d, 0, B, L, Hq, d)
+    kt = head_transpose(k2d, 0, B, L, Hkv, d)
+    dq = torch.zeros((M, Hq * d), device=o.device, dtype=torch.float32)
+    pdk, _, _, lddk = _rows2d(dk2d)
+    pdv, _, _, lddv = _rows2d(dv2d)
+    assert lddk == lddv
+    _lib.check(_L().mm355_attn_bwd(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), qt.data_ptr(), kt.data_ptr(), dot.data_ptr(),
+                                   lse.data_ptr(), delta.data_ptr(), _p(seqlens), dq.data_ptr(), pdk, pdv, lddk,
+                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_bwd")
+    return dq
+
+
+def cast_f32_to_bf16_2d(src_f32, dst2d):
+    _chk_dev(src_f32, dst2d)
+    pd, R, C, ldd = _rows2d(dst2d)
+    assert src_f32.dim() == 2 and src_f32.shape == (R, C) and src_f32.stride(1) == 1
+    _lib.check(_L().mm355_cast_f32_bf16_2d(src_f32.data_ptr(), src_f32.stride(0), pd, ldd, R, C, _stream()), "mm355_cast_f32_bf16_2d")
+    return dst2d
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+
+def swiglu_fwd(gu, I):
+    _chk_dev(gu)
+    assert gu.is_contiguous() and gu.shape[-1] == 2 * I
+    M = gu.numel() // (2 * I)
+    act = torch.empty((M, I), device=gu.device, dtype=BF16)
+    _lib.check(_L().mm355_swiglu_fwd(gu.data_ptr(), act.data_ptr(), M, I, _stream()), "mm355_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(gu, dact, I, want_act=True):
+    _chk_dev(gu, dact)
+    assert gu.is_contiguous() and dact.is_contiguous()
+    M = gu.numel() // (2 * I)
+    dgu = torch.empty_like(gu)
+    act = torch.empty((M, I), device=gu.device, dtype=BF16) if want_act else None
+    _lib.check(_L().mm355_swiglu_bwd(gu.data_ptr(), dact.data_ptr(), dgu.data_ptr(), _p(act), M, I, _stream()), "mm355_swiglu_bwd")
+    return dgu, act
+
+
+def gelu_fwd(x, kind=GELU_ERF):
+    _chk_dev(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_L().mm355_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), kind, _stream()), "mm355_gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy, kind=GELU_ERF):
+    _chk_dev(x, dy)
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_L().mm355_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), kind, _stream()), "mm355_gelu_bwd")
+    return dx
+
+
+def scale_(x, s_dev=None, s_host=1.0):
+    _chk_dev(x)
+    assert x.is_contiguous() and x.dtype == BF16
+    if s_dev is not None:
+        assert s_dev.dtype == torch.float32
+    _lib.check(_L().mm355_scale_bf16(x.data_ptr(), x.numel(), _p(s_dev), s_host, _stream()), "mm355_scale_bf16")
+    return x
+
+
+def axpy_(y, x, s_dev=None, s_host=1.0, accumulate=True):
+    """y (+)= s * x ; y bf16, x bf16 or f32 (contiguous, same numel)."""
+    _chk_dev(y, x)
+    assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel() and y.dtype == BF16
+    if x.dtype == torch.float32:
+        assert s_dev is None
+        _lib.check(_L().mm355_axpy_f32_to_bf16(y.data_ptr(), x.data_ptr(), y.numel(), s_host, int(accumulate), _stream()), "mm355_axpy_f32_to_bf16")
+    else:
+        _lib.check(_L().mm355_axpy_bf16(y.data_ptr(), x.data_ptr(), y.numel(), _p(s_dev), s_host, int(accumulate), _stream()), "mm355_axpy_bf16")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ losses
+
+def ce_rows_(logits2d, targets_i32, V, grad_scale, loss_sum_f32):
+    _chk_dev(logits2d, targets_i32, loss_sum_f32)
+    p, R, _, ld = _rows2d(logits2d)
+    assert targets_i32.dtype == torch.int32 and targets_i32.numel() >= R
+    _lib.check(_L().mm355_ce_rows(p, ld, targets_i32.data_ptr(), R, V, grad_scale, loss_sum_f32.data_ptr(), _stream()), "mm355_ce_rows")
+
+
+def cosine_loss(pred_raw, target, normalize, want_grad=True):
+    _chk_dev(pred_raw, target)
+    assert pred_raw.is_contiguous() and target.is_contiguous() and pred_raw.shape == target.shape
+    R, C = pred_raw.shape
+    cos_sum = torch.zeros((1,), device=pred_raw.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred_raw) if want_grad else None
+    _lib.check(_L().mm355_cosine_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(normalize), cos_sum.data_ptr(), _p(dpred), _stream()),
+               "mm355_cosine_loss")
+    return cos_sum, dpred
+
+
+# ------------------------------------------------------------------------------------------------ splice / rows
+
+def splice_gather(embed, proj2d, src_i32, h):
+    _chk_dev(embed, proj2d, src_i32)
+    rows = src_i32.numel()
+    out = torch.empty((rows, h), device=embed.device, dtype=BF16)
+    assert embed.is_contiguous() and (proj2d is None or proj2d.is_contiguous())
+    _lib.check(_L().mm355_splice_gather(embed.data_ptr(), _p(proj2d), src_i32.data_ptr(), out.data_ptr(), rows, h, _stream()), "mm355_splice_gather")
+    return out
+
+
+def rows_gather(x2d, idx_i32, out=None):
+    _chk_dev(x2d, idx_i32)
+    p, _, h, ld = _rows2d(x2d)
+    R = idx_i32.numel()
+    if out is None:
+        out = torch.empty((R, h), device=x2d.device, dtype=BF16)
+    _lib.check(_L().mm355_rows_gather(p, ld, idx_i32.data_ptr(), out.data_ptr(), out.stride(0), R, h, _stream()), "mm355_rows_gather")
+    return out
+
+
+def rows_scatter_add_(dst2d, src2d, idx_i32):
+    _chk_dev(dst2d, src2d, idx_i32)
+    ps, R, h, lds = _rows2d(src2d)
+    pd, _, _, ldd = _rows2d(dst2d)
+    _lib.check(_L().mm355_rows_scatter_add(ps, lds, idx_i32.data_ptr(), pd, ldd, R, h, _stream()), "mm355_rows_scatter_add")
+    return dst2d
+
+
+def embed_grad_(dembed, dout2d, tok_i32, seg_i32, pos_i32, accumulate):
+    _chk_dev(dembed, dout2d)
+    assert dout2d.is_contiguous() and dembed.is_contiguous()
+    n_seg = tok_i32.numel()
+    if n_seg == 0:
+        return dembed
+    _lib.check(_L().mm355_embed_grad(dout2d.data_ptr(), tok_i32.data_ptr(), seg_i32.data_ptr(), pos_i32.data_ptr(), n_seg,
+                                     dembed.data_ptr(), dembed.shape[1], int(accumulate), _stream()), "mm355_embed_grad")
+    return dembed
+
+
+# ------------------------------------------------------------------------------------------------ vision
+
+def im2col_patch(images, p, Kp):
+    _chk_dev(images)
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    N, _, H, W = images.shape
+    is_f32 = images.dtype == torch.float32
+    assert is_f32 or images.dtype == BF16
+    out = torch.empty((N * (H // p) * (W // p), Kp), device=images.device, dtype=BF16)
+    _lib.check(_L().mm355_im2col_patch(images.data_ptr(), int(is_f32), N, H, W, p, out.data_ptr(), Kp, _stream()), "mm355_im2col_patch")
+    return out
+
+
+def bilinear_l2norm(feat, side_in, side_out, normalize):
+    _chk_dev(feat)
+    assert feat.is_contiguous()
+    N, P, C = feat.shape
+    assert P == side_in * side_in
+    out = torch.empty((N, side_out * side_out, C), device=feat.device, dtype=BF16)
+    _lib.check(_L().mm355_bilinear_l2norm(feat.data_ptr(), out.data_ptr(), N, side_in, side_out, C, int(normalize), _stream()), "mm355_bilinear_l2norm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+
+def adamw_shard_(p32, m, v, g, p_out, lr, beta1, beta2, eps, wd, step, grad_scale_dev=None):
+    _chk_dev(p32, m, v, g, p_out)
+    n = p32.numel()
+    assert m.numel() == n and v.numel() == n and g.numel() == n and p_out.numel() == n
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _lib.check(_L().mm355_adamw_shard(p32.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p_out.data_ptr(), n, lr, beta1, beta2,
+                                      eps, wd, bc1, bc2, _p(grad_scale_dev), _stream()), "mm355_adamw_shard")
+
+
+def sumsq_(x, out_f32):
+    _chk_dev(x, out_f32)
+    assert x.is_contiguous()
+    _lib.check(_L().mm355_sumsq_bf16(x.data_ptr(), x.numel(), out_f32.data_ptr(), _stream()), "mm355_sumsq_bf16")
+    return out_f32
+
+
+def clip_coef(sumsq_f32, max_norm, pre_scale, out_f32):
+    _chk_dev(sumsq_f32, out_f32)
+    _lib.check(_L().mm355_clip_coef(sumsq_f32.data_ptr(), max_norm, pre_scale, out_f32.data_ptr(), _stream()), "mm355_clip_coef")
+    return out_f32

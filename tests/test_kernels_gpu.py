@@ -1,0 +1,421 @@
+"""Kernel-level parity: every libmm355.so entry point (through the C ABI) against the CPU oracle
+(oracle/ref_ops.py) on seeded inputs.  Needs an MI355X:  pytest -m gpu
+
+Tolerances: the kernels compute in bf16 with fp32 accumulation; the oracle is evaluated in fp32 on the
+SAME bf16-rounded inputs, so the only differences are the final bf16 rounding (rel 2^-8 = 3.9e-3) and
+accumulation order.  Integer / index work (gathers, transposes, im2col) is compared bit-exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as R  # noqa: E402  (the checker)
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from metamorph_amd import ops as _ops
+    from metamorph_amd import lib
+    lib.load()
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        # a transposed result is the classic MFMA-layout bug: say so if that is what happened
+        hint = ""
+        if got.dim() == 2 and got.shape[0] == got.shape[1] and (got.t() - ref).abs().max() < atol + rtol * ref.abs().max():
+            hint = " [matches the TRANSPOSE of the reference]"
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max err {err.max():.4g} "
+                             f"(ref max {ref.abs().max():.4g}); first bad {idx} got {got[tuple(idx)]:.5g} ref {ref[tuple(idx)]:.5g}{hint}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+
+GEMM_SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (512, 384, 1152), (64, 130, 64), (1458, 1152, 4304),
+               (200, 1152, 592), (1024, 1024, 4096)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_plain(ops, variant, shape):
+    M, N, K = shape
+    if K % 64 and variant in (2, 4, 6):
+        pytest.skip("LDS-DMA variants need K % 64 == 0")
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = a.float() @ b.float().t()
+    out = ops.gemm(a.to(DEV), b.to(DEV), variant=variant)
+    close(out, ref, 1e-2, 0.02 * math.sqrt(K), f"gemm v{variant} {shape}")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 6])
+def test_gemm_epilogues(ops, variant):
+    M, N, K = 320, 256, 128
+    a, b = rnd(M, K, seed=3, scale=0.3), rnd(N, K, seed=4, scale=0.3)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    acc = a.float() @ b.float().t()
+    tol = dict(rtol=1e-2, atol=0.03)
+    close(ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), variant=variant), acc + bias.float(), what="bias", **tol)
+    close(ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), gelu="erf", variant=variant), R.gelu_erf(acc + bias.float()), what="gelu_erf", **tol)
+    close(ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), gelu="tanh", variant=variant), R.gelu_tanh(acc + bias.float()), what="gelu_tanh", **tol)
+    close(ops.gemm(a.to(DEV), b.to(DEV), residual=res.to(DEV), variant=variant), acc + res.float(), what="residual", **tol)
+    pos = rnd(64, N, seed=7)                                   # residual indexed by row % 64 (position embedding)
+    close(ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=pos.to(DEV), res_row_mod=64, variant=variant),
+          acc + bias.float() + pos.float().repeat(5, 1), what="bias+pos", **tol)
+    c0 = rnd(M, N, seed=8)
+    c = c0.to(DEV).clone()
+    ops.gemm(a.to(DEV), b.to(DEV), out=c, accumulate=True, variant=variant)
+    close(c, acc + c0.float(), what="accumulate", **tol)
+    cf = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm(a.to(DEV), b.to(DEV), out=cf, variant=variant)
+    close(cf, acc, rtol=1e-4, atol=1e-3, what="out_f32")
+    ops.gemm(a.to(DEV), b.to(DEV), out=cf, accumulate=True, variant=variant)
+    close(cf, 2 * acc, rtol=1e-4, atol=2e-3, what="out_f32 accumulate")
+
+
+def test_gemm_strided_views(ops):
+    M, N, K = 192, 136, 128
+    big_a, big_b = rnd(M, 3 * K, seed=9), rnd(N, 2 * K, seed=10)
+    a, b = big_a[:, K:2 * K], big_b[:, K:]
+    ref = a.float() @ b.float().t()
+    out_big = torch.zeros(M, 256, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(big_a.to(DEV)[:, K:2 * K], big_b.to(DEV)[:, K:], out=out_big[:, 64:64 + N])
+    close(out_big[:, 64:64 + N], ref, 1e-2, 0.25, "strided gemm")
+    assert float(out_big[:, :64].abs().max()) == 0 and float(out_big[:, 64 + N:].abs().max()) == 0
+
+
+def test_transpose_and_colsum(ops):
+    for (r, c) in [(64, 64), (200, 136), (729, 1152), (130, 72)]:
+        x = rnd(r, c, seed=r)
+        t = ops.transpose(x.to(DEV))
+        assert torch.equal(t.cpu(), x.t()), (r, c)
+    x = rnd(515, 264, seed=11)
+    s = torch.zeros(264, device=DEV)
+    ops.colsum_f32(x.to(DEV), s)
+    close(s, x.float().sum(0), 1e-4, 1e-3, "colsum")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+
+@pytest.mark.parametrize("h", [256, 1152, 4096])
+def test_rmsnorm_fwd_bwd(ops, h):
+    M = 37
+    x, w, dy, dres = rnd(M, h, seed=1), (1 + 0.1 * rnd(h, seed=2).float()).bfloat16(), rnd(M, h, seed=3), rnd(M, h, seed=4)
+    y = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-5)
+    yr = R.rmsnorm(x, w, 1e-5)
+    close(y, yr, 8e-3, 1e-2, "rmsnorm fwd")
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    R.rmsnorm(xf, wf, 1e-5).backward(dy.float())
+    dw = torch.zeros(h, device=DEV)
+    dx = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-5, dres=dres.to(DEV), dw_f32=dw)
+    close(dx, xf.grad + dres.float(), 1e-2, 2e-2, "rmsnorm dx")
+    close(dw, wf.grad, 1e-2, 5e-2, "rmsnorm dw")
+
+
+def test_layernorm_fwd(ops):
+    x, w, b = rnd(50, 1152, seed=1), (1 + 0.1 * rnd(1152, seed=2).float()).bfloat16(), rnd(1152, seed=3, scale=0.1)
+    y = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6)
+    close(y, R.layernorm(x.float(), w.float(), b.float(), 1e-6), 8e-3, 1e-2, "layernorm")
+
+
+# ------------------------------------------------------------------------------------------------ rope
+
+def test_rope(ops):
+    B, L, Hq, Hkv, d = 2, 70, 4, 2, 128
+    cos, sin = ops.rope_table(L, d, 500000.0, DEV)
+    pos = torch.arange(L)[None]
+    cr, sr = R.rope_tables(pos, d, 500000.0, torch.bfloat16)
+    close(cos, cr[0], 0, 8e-3, "rope cos")
+    close(sin, sr[0], 0, 8e-3, "rope sin")
+    ld = (Hq + 2 * Hkv) * d
+    qkv = rnd(B * L, ld, seed=5)
+    dev = qkv.to(DEV).clone()
+    ops.rope_qk_(dev, B, L, Hq, Hkv, d, cos, sin)
+    q = qkv[:, :Hq * d].view(B, L, Hq, d).transpose(1, 2)
+    k = qkv[:, Hq * d:(Hq + Hkv) * d].view(B, L, Hkv, d).transpose(1, 2)
+    cb, sb = cos.cpu()[None].expand(B, L, d), sin.cpu()[None].expand(B, L, d)
+    qe = R.rope_apply(q, cb, sb).transpose(1, 2).reshape(B * L, Hq * d)
+    ke = R.rope_apply(k, cb, sb).transpose(1, 2).reshape(B * L, Hkv * d)
+    close(dev[:, :Hq * d], qe, 8e-3, 8e-3, "rope q")
+    close(dev[:, Hq * d:(Hq + Hkv) * d], ke, 8e-3, 8e-3, "rope k")
+    assert torch.equal(dev[:, (Hq + Hkv) * d:].cpu(), qkv[:, (Hq + Hkv) * d:]), "v block must be untouched"
+    # inverse is the transpose of the rotation: <R x, y> == <x, R^T y>
+    y = rnd(B * L, ld, seed=6)
+    ydev = y.to(DEV).clone()
+    ops.rope_qk_(ydev, B, L, Hq, Hkv, d, cos, sin, inverse=True)
+    n = (Hq + Hkv) * d
+    lhs = (dev[:, :n].float().cpu() * y[:, :n].float()).sum()
+    rhs = (qkv[:, :n].float() * ydev[:, :n].float().cpu()).sum()
+    assert abs(float(lhs - rhs)) < 2e-2 * max(1.0, abs(float(lhs))), (float(lhs), float(rhs))
+
+
+def test_head_transpose(ops):
+    B, L, H, d = 2, 100, 3, 72
+    x = rnd(B * L, 8 + H * d + 16, seed=1)
+    t = ops.head_transpose(x.to(DEV), 8, B, L, H, d)
+    ref = x[:, 8:8 + H * d].view(B, L, H, d).permute(0, 2, 3, 1)
+    assert t.shape == (B, H, d, 128)
+    assert torch.equal(t[..., :L].cpu(), ref)
+    assert float(t[..., L:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+ATT_CASES = [  # B, L, Hq, Hkv, d, causal, seqlens
+    (2, 200, 4, 2, 128, True, [200, 137]),
+    (1, 64, 2, 1, 128, True, None),
+    (2, 130, 4, 4, 64, True, [130, 5]),
+    (2, 100, 3, 3, 72, False, None),
+    (1, 729, 2, 2, 72, False, None),
+    (2, 333, 8, 2, 128, True, [333, 256]),
+]
+
+
+def _attn_setup(case, seed=0):
+    B, L, Hq, Hkv, d, causal, seqlens = case
+    ld = (Hq + 2 * Hkv) * d
+    qkv = rnd(B * L, ld, seed=seed, scale=0.7)
+    q = qkv[:, :Hq * d].view(B, L, Hq, d).transpose(1, 2)
+    k = qkv[:, Hq * d:(Hq + Hkv) * d].view(B, L, Hkv, d).transpose(1, 2)
+    v = qkv[:, (Hq + Hkv) * d:].view(B, L, Hkv, d).transpose(1, 2)
+    valid = None
+    if seqlens is not None:
+        valid = torch.arange(L)[None] < torch.tensor(seqlens)[:, None]
+    return qkv, q, k, v, valid
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attn_fwd(ops, case):
+    B, L, Hq, Hkv, d, causal, seqlens = case
+    qkv, q, k, v, valid = _attn_setup(case)
+    ref = R.attention(q, k, v, valid, causal=causal).transpose(1, 2).reshape(B, L, Hq * d)
+    dev = qkv.to(DEV)
+    vt = ops.head_transpose(dev, (Hq + Hkv) * d, B, L, Hkv, d)
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
+    o, lse = ops.attn_fwd(dev[:, :Hq * d], dev[:, Hq * d:(Hq + Hkv) * d], vt, B, L, Hq, Hkv, d, d ** -0.5, causal, sl)
+    o = o.view(B, L, Hq * d)
+    for b in range(B):
+        n = seqlens[b] if seqlens else L
+        close(o[b, :n], ref[b, :n], 1e-2, 1e-2, f"attn fwd {case} sample {b}")
+        assert float(o[b, n:].abs().max()) == 0 if n < L else True
+    # lse against the oracle definition
+    s = torch.matmul(q.float(), k.float().repeat_interleave(Hq // Hkv, 1).transpose(-1, -2)) * d ** -0.5
+    if causal:
+        s = s.masked_fill(~torch.ones(L, L, dtype=torch.bool).tril(), float("-inf"))
+    if valid is not None:
+        s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    lse_ref = torch.logsumexp(s, -1)
+    for b in range(B):
+        n = seqlens[b] if seqlens else L
+        close(lse[b, :, :n], lse_ref[b, :, :n], 1e-3, 1e-2, "lse")
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attn_bwd(ops, case):
+    B, L, Hq, Hkv, d, causal, seqlens = case
+    qkv, q, k, v, valid = _attn_setup(case, seed=3)
+    do = rnd(B * L, Hq * d, seed=4, scale=0.5)
+    if valid is not None:                                       # padded query rows carry no gradient
+        do = (do.view(B, L, -1) * valid[:, :, None]).reshape(B * L, -1).contiguous()
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = R.attention(qf, kf, vf, valid, causal=causal)
+    # nan-safe: padded rows under causal masking are finite in the oracle as well
+    (ref * do.float().view(B, L, Hq, d).transpose(1, 2)).sum().backward()
+    dev = qkv.to(DEV)
+    vt = ops.head_transpose(dev, (Hq + Hkv) * d, B, L, Hkv, d)
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
+    qd, kd, vd = dev[:, :Hq * d], dev[:, Hq * d:(Hq + Hkv) * d], dev[:, (Hq + Hkv) * d:]
+    o, lse = ops.attn_fwd(qd, kd, vt, B, L, Hq, Hkv, d, d ** -0.5, causal, sl)
+    dqkv = torch.zeros_like(dev)
+    dq = ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, B, L, Hq, Hkv, d, d ** -0.5, causal, sl,
+                      dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:])
+    tol = dict(rtol=2e-2, atol=2e-2)
+    close(dq.view(B, L, Hq, d), qf.grad.transpose(1, 2), what=f"dq {case}", **tol)
+    close(dqkv[:, Hq * d:(Hq + Hkv) * d].view(B, L, Hkv, d), kf.grad.transpose(1, 2), what=f"dk {case}", **tol)
+    close(dqkv[:, (Hq + Hkv) * d:].view(B, L, Hkv, d), vf.grad.transpose(1, 2), what=f"dv {case}", **tol)
+    assert float(dqkv[:, :Hq * d].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+
+def test_swiglu_gelu(ops):
+    M, I = 33, 512
+    gu, da = rnd(M, 2 * I, seed=1), rnd(M, I, seed=2)
+    act = ops.swiglu_fwd(gu.to(DEV), I)
+    g, u = gu[:, :I].float().requires_grad_(True), gu[:, I:].float().requires_grad_(True)
+    ref = R.swiglu(g, u)
+    close(act, ref, 1e-2, 1e-2, "swiglu fwd")
+    ref.backward(da.float())
+    dgu, act2 = ops.swiglu_bwd(gu.to(DEV), da.to(DEV), I)
+    close(dgu[:, :I], g.grad, 1e-2, 1e-2, "swiglu dgate")
+    close(dgu[:, I:], u.grad, 1e-2, 1e-2, "swiglu dup")
+    assert torch.equal(act2.cpu(), act.cpu())
+    x, dy = rnd(40, 256, seed=3), rnd(40, 256, seed=4)
+    for kind, fn in ((0, R.gelu_erf), (1, R.gelu_tanh)):
+        xf = x.float().requires_grad_(True)
+        y = fn(xf)
+        close(ops.gelu_fwd(x.to(DEV), kind), y, 8e-3, 8e-3, f"gelu {kind}")
+        y.backward(dy.float())
+        close(ops.gelu_bwd(x.to(DEV), dy.to(DEV), kind), xf.grad, 1e-2, 1e-2, f"gelu bwd {kind}")
+
+
+def test_scale_axpy_cast(ops):
+    x = rnd(1003, seed=1)
+    s = torch.tensor([0.37], device=DEV)
+    y = ops.scale_(x.to(DEV).clone(), s, 2.0)
+    close(y, x.float() * 0.74, 8e-3, 1e-3, "scale")
+    a, b = rnd(777, seed=2), rnd(777, seed=3)
+    y = ops.axpy_(a.to(DEV).clone(), b.to(DEV), s, 1.0, True)
+    close(y, a.float() + 0.37 * b.float(), 8e-3, 1e-2, "axpy")
+    f = torch.randn(777, generator=torch.Generator().manual_seed(4))
+    y = ops.axpy_(a.to(DEV).clone(), f.to(DEV), None, 0.5, False)
+    close(y, 0.5 * f, 8e-3, 1e-3, "axpy f32")
+    src = torch.randn(20, 64, generator=torch.Generator().manual_seed(5))
+    dst = torch.zeros(20, 128, device=DEV, dtype=torch.bfloat16)
+    ops.cast_f32_to_bf16_2d(src.to(DEV), dst[:, 32:96])
+    assert torch.equal(dst[:, 32:96].cpu(), src.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------ losses
+
+def test_ce_rows(ops):
+    Rr, V, ld = 37, 1003, 1024
+    lg = torch.zeros(Rr, ld, dtype=torch.bfloat16)
+    lg[:, :V] = rnd(Rr, V, seed=1, scale=3.0)
+    lg[:, V:] = float("nan")                                    # padding must never be read arithmetically
+    tg = torch.randint(0, V, (Rr,), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    tg[5] = -100
+    tg[6] = V - 1
+    x = lg[:, :V].float().requires_grad_(True)
+    keep = tg >= 0
+    lse = torch.logsumexp(x, -1)
+    loss = (lse - x.gather(1, tg.clamp_min(0).long()[:, None])[:, 0])[keep].sum()
+    loss.backward()
+    dev = lg.to(DEV).clone()
+    ls = torch.zeros(1, device=DEV)
+    ops.ce_rows_(dev, tg.to(DEV), V, 0.25, ls)
+    close(ls[0], loss, 2e-3, 1e-2, "ce loss sum")
+    close(dev[:, :V], 0.25 * x.grad, 1e-2, 2e-4, "ce grad")
+    assert float(dev[:, V:].float().abs().max()) == 0
+    assert float(dev[5].float().abs().max()) == 0
+
+
+def test_cosine_loss(ops):
+    Rr, C = 21, 1152
+    p, t = rnd(Rr, C, seed=1), R.l2_normalize(rnd(Rr, C, seed=2).float()).bfloat16()
+    for normalize in (1, 0):
+        pf = p.float().requires_grad_(True)
+        u = R.l2_normalize(pf) if normalize else pf
+        loss = R.cosine_loss(t.float(), u)
+        loss.backward()
+        cs, dp = ops.cosine_loss(p.to(DEV), t.to(DEV), normalize)
+        close(-cs[0] / Rr, loss, 1e-2, 2e-3, f"cosine loss normalize={normalize}")
+        close(dp, pf.grad, 3e-2, 2e-2 * float(pf.grad.abs().max()), f"cosine grad normalize={normalize}")
+
+
+# ------------------------------------------------------------------------------------------------ splice
+
+def test_splice_and_rows(ops):
+    V, h = 500, 256
+    emb, proj = rnd(V, h, seed=1), rnd(12, h, seed=2)
+    src = torch.tensor([3, 499, -1, -2, -13, 0, 3, -1, -7], dtype=torch.int32)
+    out = ops.splice_gather(emb.to(DEV), proj.to(DEV), src.to(DEV), h)
+    for r, s in enumerate(src.tolist()):
+        exp = emb[s] if s >= 0 else (torch.zeros(h, dtype=torch.bfloat16) if s == -1 else proj[-2 - s])
+        assert torch.equal(out[r].cpu(), exp), r
+    x = rnd(40, h, seed=3)
+    idx = torch.tensor([5, -1, 39, 0], dtype=torch.int32)
+    g = ops.rows_gather(x.to(DEV), idx.to(DEV))
+    assert torch.equal(g[0].cpu(), x[5]) and torch.equal(g[2].cpu(), x[39]) and float(g[1].abs().max()) == 0
+    dst = x.to(DEV).clone()
+    add = rnd(4, h, seed=4)
+    ops.rows_scatter_add_(dst, add.to(DEV), idx.to(DEV))
+    ref = x.float().clone()
+    for r, i in enumerate(idx.tolist()):
+        if i >= 0:
+            ref[i] += add[r].float()
+    close(dst, ref, 8e-3, 1e-2, "rows_scatter_add")
+    # embedding gradient by sorted segments
+    dout = rnd(9, h, seed=5)
+    tok = torch.tensor([0, 3, 499], dtype=torch.int32)
+    seg = torch.tensor([0, 1, 3, 4], dtype=torch.int32)
+    pos = torch.tensor([5, 0, 6, 1], dtype=torch.int32)
+    de = torch.zeros(V, h, device=DEV, dtype=torch.bfloat16)
+    ops.embed_grad_(de, dout.to(DEV), tok.to(DEV), seg.to(DEV), pos.to(DEV), False)
+    close(de[3], dout[0].float() + dout[6].float(), 8e-3, 1e-2, "embed grad dup token")
+    assert torch.equal(de[0].cpu(), dout[5]) and torch.equal(de[499].cpu(), dout[1])
+    ops.embed_grad_(de, dout.to(DEV), tok.to(DEV), seg.to(DEV), pos.to(DEV), True)
+    close(de[3], 2 * (dout[0].float() + dout[6].float()), 1e-2, 2e-2, "embed grad accumulate")
+
+
+# ------------------------------------------------------------------------------------------------ vision
+
+def test_im2col_matches_conv(ops):
+    N, H, p, C = 2, 56, 14, 32
+    img = torch.randn(N, 3, H, H, generator=torch.Generator().manual_seed(1))
+    w = rnd(C, 3, p, p, seed=2, scale=0.05)
+    Kp = 608
+    for x in (img, img.bfloat16()):
+        cols = ops.im2col_patch(x.to(DEV), p, Kp)
+        ref = torch.nn.functional.unfold(x.bfloat16().float(), p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)
+        assert torch.equal(cols[:, :3 * p * p].cpu().float(), ref)
+        assert float(cols[:, 3 * p * p:].abs().max()) == 0
+    wp = torch.zeros(C, Kp, dtype=torch.bfloat16)
+    wp[:, :3 * p * p] = w.reshape(C, -1)
+    y = ops.gemm(cols, wp.to(DEV))
+    conv = torch.nn.functional.conv2d(img.bfloat16().float(), w.float(), stride=p).flatten(2).transpose(1, 2).reshape(-1, C)
+    close(y, conv, 1e-2, 2e-2, "patch embed")
+
+
+@pytest.mark.parametrize("sides", [(27, 16), (27, 8), (4, 2), (4, 4)])
+def test_bilinear_l2norm(ops, sides):
+    si, so = sides
+    f = rnd(2, si * si, 1152, seed=si)
+    y = R.bilinear_reduce(f, so * so)
+    close(ops.bilinear_l2norm(f.to(DEV), si, so, False), y, 8e-3, 8e-3, "bilinear")
+    close(ops.bilinear_l2norm(f.to(DEV), si, so, True), R.l2_normalize(y), 1e-2, 1e-3, "bilinear+l2")
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+
+def test_adamw_and_norm(ops):
+    n = 10007
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    pout = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    coef = torch.tensor([0.5], device=DEV)
+    for step in range(1, 4):
+        gr = rnd(n, seed=10 + step)
+        R.adamw_step(p, gr, m, v, step, 1e-2, 0.9, 0.95, 1e-8, 0.1, grad_scale=0.5)
+        ops.adamw_shard_(pd, md, vd, gr.to(DEV), pout, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, coef)
+    close(pd, p, 1e-5, 1e-6, "adamw master")
+    assert torch.equal(pout.cpu(), p.bfloat16()) or (pout.float().cpu() - p).abs().max() < 1e-2
+    x = rnd(4099, seed=2)
+    s = torch.zeros(1, device=DEV)
+    ops.sumsq_(x.to(DEV), s)
+    close(s[0], (x.float() ** 2).sum(), 1e-4, 1e-2, "sumsq")
+    c = torch.zeros(1, device=DEV)
+    ops.clip_coef(s, 1.0, 0.125, c)
+    close(c[0], torch.tensor(min(1.0, 1.0 / (float((x.float() ** 2).sum()) ** 0.5 + 1e-6)) * 0.125), 1e-4, 1e-7, "clip coef")
