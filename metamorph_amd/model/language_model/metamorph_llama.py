@@ -1,0 +1,398 @@
+"""MetaMorphLlamaForCausalLM on MI355X kernels -- drop-in for the reference class of the same name
+(reference metamorph/model/language_model/metamorph_llama.py:129-738).
+
+Same constructor, same `forward` signature and `CausalLMOutputWithPast` contract, same side-effect attributes
+(`loss_language`, `loss_image_ar`), same state-dict keys; the arithmetic is libmm355 (hand-written gfx950
+HIP) instead of transformers' LlamaModel + torch ops:
+
+  reference                                         here
+  ------------------------------------------------  --------------------------------------------------------
+  HF LlamaModel, 32 x LlamaDecoderLayer             functional.DecoderLayerFn (one autograd node per layer:
+    (RMSNorm, q/k/v/o Linear, RoPE, SDPA, SwiGLU)      fused qkv / gate-up GEMMs, flash attention, fused
+                                                       residual epilogues, hand-written backward)
+  lm_head -> fp32 logits [B,L,V] -> CrossEntropy    functional.LinearCrossEntropyFn (chunked, target rows only)
+  mask-multiply + boolean index (device sync)       row gather by the host plan (no sync)
+  vision_head -> F.normalize -> cosine_similarity   GEMMs + fused cosine loss kernel
+  three .item() syncs per step                      device-side combine; floats materialise only when read
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+from transformers import AutoConfig, AutoModelForCausalLM, LlamaConfig, PreTrainedModel
+from transformers.modeling_outputs import CausalLMOutputWithPast
+
+from ... import functional as F
+from ... import ops
+from ...constants import DEFAULT_IMAGE_END_ID, DEFAULT_IMAGE_START_ID, IGNORE_INDEX
+from ...splice_plan import SplicePlan
+from ..metamorph_arch import MetaMorphMetaForCausalLM, MetaMorphMetaModel, upload_plan
+from ..modules import HipEmbedding, HipGELU, HipLinear, HipRMSNorm
+
+BF16 = torch.bfloat16
+
+
+class MetaMorphConfig(LlamaConfig):
+    model_type = "metamorph_llama"
+
+
+def _rope_theta(config):
+    rp = getattr(config, "rope_parameters", None)
+    if isinstance(rp, dict) and "rope_theta" in rp:
+        if rp.get("rope_type", "default") != "default":
+            raise NotImplementedError(f"rope_type={rp.get('rope_type')!r}: only the default RoPE has a HIP kernel")
+        return float(rp["rope_theta"])
+    if getattr(config, "rope_scaling", None):
+        raise NotImplementedError("rope_scaling: only the default RoPE has a HIP kernel")
+    return float(getattr(config, "rope_theta", 10000.0))
+
+
+class _Attention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        h, d = config.hidden_size, config.hidden_size // config.num_attention_heads
+        self.q_proj = HipLinear(h, config.num_attention_heads * d, bias=False)
+        self.k_proj = HipLinear(h, config.num_key_value_heads * d, bias=False)
+        self.v_proj = HipLinear(h, config.num_key_value_heads * d, bias=False)
+        self.o_proj = HipLinear(config.num_attention_heads * d, h, bias=False)
+
+
+class _MLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.gate_proj = HipLinear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = HipLinear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = HipLinear(config.intermediate_size, config.hidden_size, bias=False)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self_attn = _Attention(config)
+        self.mlp = _MLP(config)
+        self.input_layernorm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+
+class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
+    """`model.*` sub-tree: embed_tokens, layers, norm, vision_tower, mm_projector, vision_proj."""
+    config_class = MetaMorphConfig
+
+    def __init__(self, config, vision_delay_load=True):
+        nn.Module.__init__(self)
+        self.config = config
+        if getattr(config, "attention_bias", False) or getattr(config, "mlp_bias", False):
+            raise NotImplementedError("attention_bias / mlp_bias are not used by LLaMA-3 and have no fused kernel")
+        self.embed_tokens = HipEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([_DecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self._init_vision(config, vision_delay_load=vision_delay_load)
+        self._rope = None
+
+    def rope_tables(self, L, device):
+        d = self.config.hidden_size // self.config.num_attention_heads
+        key = (L, str(device))
+        if self._rope is None or self._rope[0][0] < L or self._rope[0][1] != str(device):
+            Lc = max(L, 256)
+            cos, sin = ops.rope_table(Lc, d, _rope_theta(self.config), device)
+            self._rope = ((Lc, str(device)), cos, sin)
+        return self._rope[1], self._rope[2]
+
+
+class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
+    config_class = MetaMorphConfig
+    base_model_prefix = "model"
+    supports_gradient_checkpointing = False     # activations are already kept at kernel-fusion granularity
+    _no_split_modules = ["_DecoderLayer"]
+    _keys_to_ignore_on_load_unexpected = [r"model\.vision_tower\.vision_tower\.head\..*", r".*rotary_emb\.inv_freq"]
+
+    def __init__(self, config, use_vision_ar=True, vision_head="None", vision_coef=1.0, normalize_vision=False,
+                 apply_softmax=False, vision_delay_load=True, full_ar=False):
+        super().__init__(config)
+        self.model = MetaMorphLlamaModel(config, vision_delay_load=vision_delay_load)
+        self.pretraining_tp = getattr(config, "pretraining_tp", 1)
+        self.vocab_size = config.vocab_size
+        self.lm_head = HipLinear(config.hidden_size, config.vocab_size, bias=False)
+        self.normalize_vision = bool(normalize_vision) or bool(getattr(config, "normalize_vision", False))
+        self.apply_softmax = apply_softmax
+        vision_head = getattr(config, "vision_head_type", vision_head)
+        hv = getattr(config, "mm_hidden_size", 1152)          # the reference hard-codes 1152 (metamorph_llama.py:255)
+        h = config.hidden_size
+        if vision_head == "linear":
+            self.vision_head = HipLinear(h, h)
+        elif vision_head == "mlp":
+            self.vision_head = nn.Sequential(HipLinear(h, h), HipGELU(), HipLinear(h, hv))
+        elif vision_head == "mlp2x_gelu":
+            self.vision_head = nn.Sequential(HipLinear(h, h), HipGELU(), HipLinear(h, h), HipGELU(), HipLinear(h, hv))
+        else:
+            self.vision_head = HipLinear(h, hv)
+        self.use_vision_ar = use_vision_ar
+        self.vision_coef = vision_coef
+        self._loss_language_t = None
+        self._loss_image_ar_t = None
+        self._mm_plan = None
+        self.post_init()
+
+    # ------------------------------------------------------------------ HF plumbing
+    def _init_weights(self, module):
+        std = getattr(self.config, "initializer_range", 0.02)
+        if isinstance(module, HipLinear):
+            nn.init.normal_(module.weight, mean=0.0, std=std)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, HipEmbedding):
+            nn.init.normal_(module.weight, mean=0.0, std=std)
+
+    def get_model(self):
+        return self.model
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, value):
+        self.lm_head = value
+
+    def resize_token_embeddings(self, new_num_tokens=None, pad_to_multiple_of=None, mean_resizing=True):
+        if new_num_tokens is None or new_num_tokens == self.config.vocab_size:
+            return self.get_input_embeddings()
+        for mod in (self.model.embed_tokens, self.lm_head):
+            old = mod.weight.data
+            new = torch.empty((new_num_tokens, old.shape[1]), device=old.device, dtype=old.dtype)
+            nn.init.normal_(new, std=getattr(self.config, "initializer_range", 0.02))
+            n = min(old.shape[0], new_num_tokens)
+            new[:n] = old[:n]
+            mod.weight = nn.Parameter(new, requires_grad=mod.weight.requires_grad)
+        self.model.embed_tokens.num_embeddings = new_num_tokens
+        self.lm_head.out_features = new_num_tokens
+        self.config.vocab_size = self.vocab_size = new_num_tokens
+        return self.get_input_embeddings()
+
+    @property
+    def loss_language(self):
+        """float, like the reference's attribute (metamorph_llama.py:464); the device->host read happens here,
+        when a logger asks, not inside forward."""
+        return float("nan") if self._loss_language_t is None else float(self._loss_language_t)
+
+    @property
+    def loss_image_ar(self):
+        return float("nan") if self._loss_image_ar_t is None else float(self._loss_image_ar_t)
+
+    # ------------------------------------------------------------------ plan handling
+    def _plan_for(self, inputs_embeds, attention_mask, labels, image_positions):
+        cached = self._mm_plan
+        if cached is not None and cached[0] is inputs_embeds:
+            self._mm_plan = None
+            return cached[1]
+        # inputs_embeds supplied by the caller: derive the index arrays from the given tensors (one host copy)
+        B, L, _ = inputs_embeds.shape
+        msk = np.ones((B, L), dtype=bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
+        if getattr(self.config, "tokenizer_padding_side", "right") == "left" and not msk.all():
+            raise NotImplementedError("left padding: the attention kernel takes per-sample lengths (right padding) only")
+        seqlens = msk.sum(1).astype(np.int32)
+        if not all(msk[b, : seqlens[b]].all() for b in range(B)):
+            raise NotImplementedError("attention_mask must be a right-padding mask")
+        lab = None if labels is None else labels.detach().cpu().numpy()
+        pos = np.zeros((B, L), dtype=np.int64) if image_positions is None else image_positions.detach().cpu().numpy()
+        nxt = np.zeros((B, L), dtype=bool)
+        nxt[:, :-1] = pos[:, 1:] == 1
+        st = ce_rows = None
+        n_valid = 0
+        if lab is not None:
+            s = np.full((B, L), IGNORE_INDEX, dtype=np.int64)
+            s[:, :-1] = lab[:, 1:]
+            st = s.reshape(-1).astype(np.int32)
+            ce_rows = np.flatnonzero(st != IGNORE_INDEX).astype(np.int32)
+            n_valid = int(ce_rows.shape[0])
+        z = np.zeros(0, dtype=np.int32)
+        plan = SplicePlan(B=B, L=L, rows_per_image=0, src=z, labels=lab, attention_mask=msk, image_positions=pos,
+                          position_ids=np.zeros((B, L), dtype=np.int64), seqlens=seqlens, target_keep=np.zeros(0, dtype=np.int64),
+                          feat_row=z, pred_rows=np.flatnonzero(nxt.reshape(-1)).astype(np.int32), shift_targets=st,
+                          ce_rows=ce_rows, n_valid=n_valid, emb_tok=z, emb_seg=np.zeros(1, dtype=np.int32), emb_pos=z,
+                          images_consumed=0)
+        return upload_plan(plan, inputs_embeds.device)
+
+    # ------------------------------------------------------------------ the hot path
+    def llm_forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                    inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                    return_dict=None, cache_position=None, image_positions=None, decoding=False, image_features=None):
+        """Reference metamorph_llama.py:285-498."""
+        if past_key_values is not None or use_cache:
+            raise NotImplementedError("KV-cache decoding is a 'next' row (SURVEY.md section 8f N1); the reference itself "
+                                      "forces use_cache=False in greedy_decode")
+        if output_attentions:
+            raise NotImplementedError("output_attentions: attention probabilities are never materialised by the flash kernel")
+        return_dict = True if return_dict is None else return_dict
+        cfg = self.config
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        if inputs_embeds.dtype != BF16:
+            raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
+        B, L, h = inputs_embeds.shape
+        pd = self._plan_for(inputs_embeds, attention_mask, labels, image_positions)
+        plan = pd["host"]
+        if plan.padding_side == "left" and not plan.attention_mask.all():
+            raise NotImplementedError("left padding: the attention kernel takes per-sample lengths (right padding) only")
+        dev = inputs_embeds.device
+        Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        d = h // Hq
+        cos, sin = self.model.rope_tables(L, dev)
+        meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"])
+
+        x = inputs_embeds.reshape(B * L, h)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        for layer in self.model.layers:
+            x = F.decoder_layer(x, layer, meta)
+        hid = self.model.norm(x)                                       # [B*L, h]
+        hidden_states = hid.view(B, L, h)
+
+        pred_z = None
+        if decoding:                                                    # metamorph_llama.py:363-377
+            with torch.no_grad():
+                last = hidden_states[:, -1, :].contiguous()
+                pred_z = self.vision_head(last)
+                if self.normalize_vision:
+                    pred_z = ops.bilinear_l2norm(pred_z.view(B, 1, -1).contiguous(), 1, 1, True).view(B, -1)
+                if self.apply_softmax:
+                    raise NotImplementedError("apply_softmax decode path has no HIP kernel")
+                prediction = self.model.mm_projector(pred_z)
+                hidden_states = hidden_states.clone()
+                hidden_states[:, -1, :] = prediction
+                hid = hidden_states.view(B * L, h)
+
+        loss = None
+        logits = None
+        if labels is None or getattr(cfg, "mm355_return_logits", False) or not torch.is_grad_enabled():
+            # inference / evaluation: the full fp32 logits tensor of the reference (metamorph_llama.py:398-399)
+            logits = ops.gemm(hid.detach(), self.lm_head.weight.data, out_f32=True).view(B, L, -1)
+        if labels is not None:
+            nan = torch.full((), float("nan"), device=dev, dtype=torch.float32)
+            if plan.n_valid > 0:
+                ce = F.LinearCrossEntropyFn.apply(hid, self.lm_head.weight, self.lm_head, pd, plan.n_valid)
+            else:
+                ce = nan                                                # mean over no targets (torch CE semantics)
+            loss = ce
+            if image_positions is not None:
+                if image_features is not None:
+                    R = int(plan.pred_rows.shape[0])
+                    tgt = image_features.reshape(-1, image_features.shape[-1])
+                    if self.apply_softmax:
+                        raise NotImplementedError("apply_softmax=True (soft-CE image loss) has no HIP kernel")
+                    if not self.normalize_vision:
+                        raise NotImplementedError("normalize_vision=False (mean-abs image loss) has no HIP kernel; "
+                                                  "every shipped recipe sets normalize_vision=True")
+                    if R == 0:
+                        # no answer-side image rows: the reference's mean over an empty tensor (NaN) -- SURVEY A9
+                        l_img = ce if tgt.shape[0] != 0 else nan
+                    else:
+                        pred_in = F.RowsGatherFn.apply(hid, pd["pred_rows"])
+                        pred = self.vision_head(pred_in)
+                        if tgt.shape[0] != R:
+                            l_img = ce                                  # the reference's try/except (:451-455)
+                        else:
+                            l_img = F.CosineLossFn.apply(pred.contiguous(), tgt.to(BF16).contiguous(), True)
+                else:
+                    l_img = ce                                          # metamorph_llama.py:461-462
+                self._loss_language_t = ce.detach()
+                self._loss_image_ar_t = l_img.detach()
+                if self.use_vision_ar:
+                    # `if loss_image_ar.item() != 0` without the host sync (NaN != 0 is True, so NaN propagates)
+                    loss = torch.where(l_img.detach() != 0, ce + self.vision_coef * l_img, ce)
+
+        if not return_dict:
+            out = (logits,)
+            return (loss,) + out if loss is not None else out
+        return CausalLMOutputWithPast(loss=pred_z if decoding else loss, logits=logits, past_key_values=None,
+                                      hidden_states=hidden_states, attentions=None)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                image_sizes=None, return_dict=None, cache_position=None, image_embeds=None, **kwargs):
+        """Reference metamorph_llama.py:603-660."""
+        image_positions = None
+        target = None
+        if inputs_embeds is None:
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels, image_positions,
+             target) = self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                                 labels, images, image_sizes, image_embeds)
+        return self.llm_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                                past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,
+                                use_cache=use_cache, output_attentions=output_attentions,
+                                output_hidden_states=output_hidden_states, return_dict=return_dict,
+                                image_positions=image_positions, image_features=target)
+
+    # ------------------------------------------------------------------ decoding (reference :502-597, :665-717)
+    @torch.no_grad()
+    def greedy_decode(self, position_ids, attention_mask, inputs_embeds, start_image_token_id=DEFAULT_IMAGE_START_ID,
+                      end_image_token_id=DEFAULT_IMAGE_END_ID, eos_token_id=(128001, 128009), do_sample=None,
+                      temperature=None, top_p=None, num_beams=None, max_new_tokens=1024, use_cache=None, output_image=False):
+        """Token mode / continuous 'image mode' greedy loop, re-running the prefix every step exactly like the
+        reference (which forces use_cache=False); a KV-cache version is the next row N1."""
+        in_image_mode = False
+        generated, image_embeds = [], []
+        total_image_tokens = 0
+        total_out = 0
+        num_image_tokens = self.get_model().vision_tower.image_token_len
+        eos = set(eos_token_id)
+        while True:
+            out = self.llm_forward(inputs_embeds=inputs_embeds, attention_mask=None, return_dict=True, decoding=in_image_mode)
+            image_embed = out.loss
+            next_token = int(torch.argmax(out.logits[:, -1, :], dim=-1)[0])
+            next_embed = out.hidden_states[:, -1, :].unsqueeze(0)
+            tok_embed = self.model.embed_tokens(torch.tensor([[next_token]], device=inputs_embeds.device))
+            if (not in_image_mode) and next_token == start_image_token_id:
+                in_image_mode = True
+                generated.append(next_token)
+                inputs_embeds = torch.cat((inputs_embeds, tok_embed), dim=1)
+            elif in_image_mode and total_image_tokens < num_image_tokens:
+                total_image_tokens += 1
+                image_embeds.append(image_embed)
+                inputs_embeds = torch.cat((inputs_embeds, next_embed), dim=1)
+                if total_image_tokens == num_image_tokens:
+                    in_image_mode = False
+            elif next_token == end_image_token_id:
+                in_image_mode = False
+                total_image_tokens = 0
+                generated.append(next_token)
+                inputs_embeds = torch.cat((inputs_embeds, tok_embed), dim=1)
+            else:
+                inputs_embeds = torch.cat((inputs_embeds, tok_embed), dim=1)
+                generated.append(next_token)
+            total_out += 1
+            if next_token in eos or total_out > max_new_tokens:
+                break
+        emb = torch.cat(image_embeds, dim=0) if image_embeds else torch.tensor([], dtype=torch.float32, device=inputs_embeds.device)
+        output = [torch.tensor(generated, dtype=torch.int32, device=inputs_embeds.device)]
+        return (output, emb) if output_image else output
+
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, image_sizes=None, output_image=False, use_customize_greedy=True,
+                 image_embeds=None, **kwargs):
+        position_ids = kwargs.pop("position_ids", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        if images is not None or image_embeds is not None:
+            (_, position_ids, attention_mask, _, inputs_embeds, _, _, _) = self.prepare_inputs_labels_for_multimodal(
+                inputs, position_ids, attention_mask, None, None, images, image_sizes=image_sizes, image_embeds=image_embeds)
+        else:
+            inputs_embeds = self.get_model().embed_tokens(inputs)
+        if not use_customize_greedy:
+            raise NotImplementedError("HF generate() needs the KV-cache decode kernels (next row N1); use the custom greedy loop")
+        return self.greedy_decode(position_ids=position_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                                  output_image=output_image, **kwargs)
+
+
+for _reg, _args in ((AutoConfig.register, ("metamorph_llama", MetaMorphConfig)),
+                    (AutoModelForCausalLM.register, (MetaMorphConfig, MetaMorphLlamaForCausalLM))):
+    try:
+        _reg(*_args)
+    except ValueError:      # already registered (e.g. the reference package imported in the same process)
+        pass

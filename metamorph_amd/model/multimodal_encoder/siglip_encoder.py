@@ -1,0 +1,283 @@
+"""SigLIP vision tower on libmm355 kernels (forward only; the tower is frozen in every shipped recipe).
+
+Mirrors the reference's `SiglipVisionTower` (reference metamorph/model/multimodal_encoder/siglip_encoder.py:62-237):
+same constructor arguments, attributes and `forward(images) -> [N, num_image_tokens, 1152]` contract --
+hidden_states[select_layer = -1] of the HF SigLIP encoder (i.e. the last encoder layer's output BEFORE
+post_layernorm), 729 -> T tokens by fp32 bilinear interpolation, optional L2 normalisation.
+
+What differs is only the machinery: patch embedding is an im2col + MFMA GEMM with the bias and position
+embedding fused in the epilogue, q/k/v are one fused GEMM, attention is the non-causal flash kernel
+(d = 72 padded to 96 in LDS), fc1 carries bias + tanh-GELU in its epilogue, and the post_layernorm /
+attention-pool head that the reference computes and discards are simply not computed.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..modules import HipLayerNorm, HipLinear
+
+BF16 = torch.bfloat16
+
+SO400M_14_384 = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+                     image_size=384, patch_size=14, layer_norm_eps=1e-6)
+
+
+def extract_res_interp(model_name):
+    """Same name grammar as the reference (siglip_encoder.py:34-59)."""
+    valid = {
+        "siglip/CLIP-ViT-SO400M-14-384": "hf-hub:timm/ViT-SO400M-14-SigLIP-384",
+        "timm/ViT-SO400M-14-SigLIP-384": "hf-hub:timm/ViT-SO400M-14-SigLIP-384",
+        "siglip/CLIP-ViT-SO400M-14": "hf-hub:timm/ViT-SO400M-14-SigLIP",
+        "timm/ViT-SO400M-14-SigLIP": "hf-hub:timm/ViT-SO400M-14-SigLIP",
+    }
+    res = 384 if "384" in model_name else 224
+    interp = None
+    for prefix, base in valid.items():
+        if model_name.startswith(prefix):
+            base_model_name = base
+            break
+    else:
+        raise ValueError(f"Unknown vision tower: {model_name}")
+    for part in model_name.split("-"):
+        if part.startswith("res"):
+            res = int(part[3:])
+        elif part.startswith("interp"):
+            interp = int(part[6:])
+    return base_model_name, res, interp
+
+
+class _PatchEmbedding(nn.Module):
+    def __init__(self, hv, p):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(hv, 3, p, p))
+        self.bias = nn.Parameter(torch.zeros(hv))
+        nn.init.normal_(self.weight, std=0.02)
+
+
+class _PosEmbedding(nn.Module):
+    def __init__(self, n, hv):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, hv))
+        nn.init.normal_(self.weight, std=0.02)
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        self.patch_embedding = _PatchEmbedding(g["hidden_size"], g["patch_size"])
+        self.position_embedding = _PosEmbedding((g["image_size"] // g["patch_size"]) ** 2, g["hidden_size"])
+
+
+class _Attention(nn.Module):
+    def __init__(self, hv):
+        super().__init__()
+        self.k_proj = HipLinear(hv, hv)
+        self.v_proj = HipLinear(hv, hv)
+        self.q_proj = HipLinear(hv, hv)
+        self.out_proj = HipLinear(hv, hv)
+
+
+class _MLP(nn.Module):
+    def __init__(self, hv, iv):
+        super().__init__()
+        self.fc1 = HipLinear(hv, iv)
+        self.fc2 = HipLinear(iv, hv)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        hv = g["hidden_size"]
+        self.layer_norm1 = HipLayerNorm(hv, g["layer_norm_eps"])
+        self.self_attn = _Attention(hv)
+        self.layer_norm2 = HipLayerNorm(hv, g["layer_norm_eps"])
+        self.mlp = _MLP(hv, g["intermediate_size"])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(g) for _ in range(g["num_hidden_layers"])])
+
+
+class _Cfg:
+    def __init__(self, g):
+        self.__dict__.update(g)
+
+
+class HipSiglipVisionTransformer(nn.Module):
+    """State-dict layout of HF `SiglipVisionTransformer` (what the reference stores as `vision_tower.vision_tower`)."""
+
+    def __init__(self, geometry=None):
+        super().__init__()
+        g = dict(SO400M_14_384)
+        g.update(geometry or {})
+        self.geometry = g
+        self.config = _Cfg(g)
+        self.embeddings = _Embeddings(g)
+        self.encoder = _Encoder(g)
+        self.post_layernorm = HipLayerNorm(g["hidden_size"], g["layer_norm_eps"])   # kept for checkpoint round trips; unused
+        self._cache = {}
+
+    @property
+    def dtype(self):
+        return self.embeddings.patch_embedding.weight.dtype
+
+    @property
+    def device(self):
+        return self.embeddings.patch_embedding.weight.device
+
+    # -- derived, cached operands (the tower is frozen, so they are rebuilt only when storage moves) --------
+    def _cached(self, key, srcs, build):
+        sig = tuple((s.data_ptr(), s._version) for s in srcs)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, build())
+            self._cache[key] = hit
+        return hit[1]
+
+    def _patch_weight(self):
+        w = self.embeddings.patch_embedding.weight
+        k = w.shape[1] * w.shape[2] * w.shape[3]
+        kp = (k + 7) // 8 * 8
+
+        def build():
+            buf = torch.zeros((w.shape[0], kp), device=w.device, dtype=BF16)
+            buf[:, :k].copy_(w.data.reshape(w.shape[0], k))
+            return buf
+        return self._cached("patch", [w], build), kp
+
+    def _qkv(self, j):
+        a = self.encoder.layers[j].self_attn
+        ws = [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]
+        bs = [a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]
+        return self._cached(("qkv", j), ws + bs, lambda: (torch.cat([w.data for w in ws], 0).contiguous(),
+                                                         torch.cat([b.data for b in bs], 0).contiguous()))
+
+    @torch.no_grad()
+    def forward_features(self, images, select_layer=-1):
+        """[N,3,H,W] (fp32 or bf16) -> hidden_states[select_layer] of the HF encoder, [N, P, hv] bf16
+        (index -1 = output of the last encoder layer, before post_layernorm; 0 = the embeddings)."""
+        g = self.geometry
+        if self.dtype != BF16:
+            raise TypeError("SigLIP tower: the MI355X kernels compute in bf16; call .to(torch.bfloat16)")
+        if images.dtype not in (torch.float32, BF16):
+            images = images.float()
+        images = images.contiguous()
+        N, _, H, W = images.shape
+        p, hv, heads = g["patch_size"], g["hidden_size"], g["num_attention_heads"]
+        d = hv // heads
+        P = (H // p) * (W // p)
+        pos = self.embeddings.position_embedding.weight.data
+        if P != pos.shape[0]:
+            raise NotImplementedError("position-embedding interpolation for non-native resolutions is not implemented")
+        wpe, kp = self._patch_weight()
+        cols = ops.im2col_patch(images, p, kp)
+        x = ops.gemm(cols, wpe, bias=self.embeddings.patch_embedding.bias.data, residual=pos, res_row_mod=P)
+        del cols
+        n_layers = len(self.encoder.layers)
+        run = select_layer if select_layer >= 0 else n_layers + 1 + select_layer
+        if not 0 <= run <= n_layers:
+            raise IndexError(f"mm_vision_select_layer={select_layer} out of range for {n_layers} layers")
+        for j, layer in enumerate(self.encoder.layers[:run]):
+            h1 = layer.layer_norm1(x)
+            wqkv, bqkv = self._qkv(j)
+            qkv = ops.gemm(h1, wqkv, bias=bqkv)
+            vt = ops.head_transpose(qkv, 2 * hv, N, P, heads, d)
+            o, _ = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], vt, N, P, heads, heads, d, d ** -0.5, False, None)
+            a = layer.self_attn
+            x = ops.gemm(o, a.out_proj.weight.data, bias=a.out_proj.bias.data, residual=x)
+            h2 = layer.layer_norm2(x)
+            f = ops.gemm(h2, layer.mlp.fc1.weight.data, bias=layer.mlp.fc1.bias.data, gelu="tanh")
+            x = ops.gemm(f, layer.mlp.fc2.weight.data, bias=layer.mlp.fc2.bias.data, residual=x)
+        return x.view(N, P, hv)
+
+
+class SiglipVisionTower(nn.Module):
+    def __init__(self, vision_tower_name, args, delay_load=False):
+        super().__init__()
+        base_model_name, res, interp = extract_res_interp(vision_tower_name)
+        self.is_loaded = False
+        self.select_layer = getattr(args, "mm_vision_select_layer", -2)
+        self.select_feature = getattr(args, "mm_vision_select_feature", "patch")
+        self.image_token_reduction = getattr(args, "image_token_reduction", "none")
+        self.image_token_len = getattr(args, "num_image_tokens", 256)
+        self.freeze_vision = getattr(args, "freeze_vision", False)
+        self.vision_coef = getattr(args, "vision_coef", 1.0)
+        self.normalize_vision = getattr(args, "normalize_vision", False)
+        self.apply_softmax = getattr(args, "apply_softmax", False)
+        self.geometry = dict(SO400M_14_384)
+        self.geometry.update(getattr(args, "mm_vision_geometry", None) or {})
+        self.vision_tower_name = base_model_name
+        self._image_size = res if res is not None else 512
+        self._interp_size = interp
+        self.hidden_size = self.geometry["hidden_size"]
+        self.image_processor = None
+        if not delay_load:
+            self.load_model()
+        if self.image_token_reduction in ("mlpmixer", "concat_interpolation"):
+            raise NotImplementedError(f"image_token_reduction={self.image_token_reduction!r} has no HIP kernel "
+                                      "(every shipped recipe uses 'interpolation')")
+
+    def load_model(self, device_map=None, state_dict=None, random_init=False):
+        """Builds the tower.  Weights come from `state_dict` (HF SigLIP vision keys), from the HF hub checkpoint
+        the reference hard-codes (google/siglip-so400m-patch14-384, siglip_encoder.py:113) when reachable, or are
+        random (benchmarks / tests)."""
+        self.vision_model = "siglip"
+        self.vision_tower = HipSiglipVisionTransformer(self.geometry)
+        if state_dict is None and not random_init:
+            from transformers import AutoModel, AutoProcessor          # network / cache access, like the reference
+            model = AutoModel.from_pretrained("google/siglip-so400m-patch14-384")
+            self.image_processor = AutoProcessor.from_pretrained("google/siglip-so400m-patch14-384").image_processor
+            self.image_processor.crop_size = {"height": 384, "width": 384}
+            state_dict = {k[len("vision_model."):]: v for k, v in model.state_dict().items() if k.startswith("vision_model.")}
+        if state_dict is not None:
+            own = self.vision_tower.state_dict()
+            self.vision_tower.load_state_dict({k: v for k, v in state_dict.items() if k in own}, strict=False)
+        self.hidden_size = self.geometry["hidden_size"]
+        self.is_loaded = True
+
+    def feature_select(self, hidden_last):
+        if self.select_feature not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        return hidden_last
+
+    def forward(self, images):
+        if not self.freeze_vision and torch.is_grad_enabled() and any(p.requires_grad for p in self.vision_tower.parameters()):
+            raise NotImplementedError("trainable vision tower (freeze_vision=False) is out of scope: SURVEY.md section 8f row N4")
+        feats = self.feature_select(self.vision_tower.forward_features(images, self.select_layer))
+        b, num_tokens, dim = feats.shape
+        side_in = int(math.isqrt(num_tokens))
+        side_out = side_in
+        if num_tokens != self.image_token_len:
+            if self.image_token_len == -1:
+                return torch.zeros((b, num_tokens, dim), device=feats.device, dtype=feats.dtype)
+            if self.image_token_reduction != "interpolation":
+                raise NotImplementedError("Not Implemented!")
+            side_out = int(np.random.randint(1, 25)) if self.image_token_len == 0 else int(np.sqrt(self.image_token_len))
+        if self.apply_softmax:
+            raise NotImplementedError("apply_softmax=True (soft-CE variant) has no HIP kernel; recipes use normalize_vision")
+        if side_out == side_in and not self.normalize_vision:
+            return feats
+        return ops.bilinear_l2norm(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
+
+    @property
+    def dtype(self):
+        return self.vision_tower.dtype
+
+    @property
+    def device(self):
+        return self.vision_tower.device
+
+    @property
+    def config(self):
+        return self.vision_tower.config if self.is_loaded else _Cfg(self.geometry)
+
+    @property
+    def num_patches_per_side(self):
+        return self.geometry["image_size"] // self.geometry["patch_size"]

@@ -45,7 +45,7 @@ def _rows2d(t):
 
 def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, accumulate=False,
          out_f32=False, variant=0, n=None):
-    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T).  a/b/out may be row-strided 2-D views (bf16)."""
+    """out[M,N] = epilogue(a[M,K] . b[N,K]^T).  a/b/out may be row-strided 2-D views (bf16)."""
     _chk_dev(a, b, out, bias, residual)
     assert a.dtype == BF16 and b.dtype == BF16
     pa, M, K, lda = _rows2d(a)

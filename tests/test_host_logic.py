@@ -1,0 +1,240 @@
+"""CPU tier: the product's host-side logic against the golden vectors recorded from the reference, the C-ABI
+library's exports, and the rule that the product never touches oracle/ or a CPU fallback."""
+import ast
+import ctypes
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+
+
+# ------------------------------------------------------------------ A1
+
+def test_tokenizer_image_token_matches_reference():
+    from oracle.fake_tokenizer import FakeTokenizer
+    from metamorph_amd.mm_utils import tokenizer_image_token
+    cases = json.load(open(os.path.join(GOLDEN, "a1_tokenizer.json")))
+    for c in cases:
+        tok = FakeTokenizer(add_bos=c["add_bos"])
+        assert tokenizer_image_token(c["prompt"], tok, c["image_token_index"]) == c["ids"], c["prompt"]
+    t = tokenizer_image_token("a <image> b", FakeTokenizer(), return_tensors="pt")
+    assert t.dtype == torch.long
+    with pytest.raises(ValueError):
+        tokenizer_image_token("a", FakeTokenizer(), return_tensors="np")
+
+
+def test_llama3_template_gives_double_bos():
+    """literal <|begin_of_text|> in the prompt + the tokenizer's automatic BOS -> two BOS ids."""
+    from oracle.fake_tokenizer import FakeTokenizer
+    from metamorph_amd.mm_utils import tokenizer_image_token
+    ids = tokenizer_image_token("<|begin_of_text|> hi <image_start><image><image_end>", FakeTokenizer(add_bos=True))
+    assert ids[:2] == [128000, 128000] and ids.count(-200) == 1 and ids[ids.index(-200) - 1] == 128256
+
+
+# ------------------------------------------------------------------ A5
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "a5_*.npz"))))
+def test_splice_plan_matches_reference(path):
+    from metamorph_amd.splice_plan import build_splice_plan
+    g = np.load(path)
+    Timg = int(g["rows_per_image"])
+    plan = build_splice_plan(g["input_ids"], g["labels"], g["attention_mask"], int(g["num_images"]), Timg,
+                             int(g["max_length"]), "left" if int(g["left"]) else "right")
+    B, L = g["out_labels"].shape
+    assert (plan.B, plan.L) == (B, L)
+    assert np.array_equal(plan.src.reshape(B, L), g["out_src"])
+    assert np.array_equal(plan.labels, g["out_labels"])
+    assert np.array_equal(plan.attention_mask, g["out_attention_mask"])
+    assert np.array_equal(plan.image_positions, g["out_image_positions"])
+    assert plan.target_keep.tolist() == g["out_target_keep"].tolist()
+    # derived index arrays are consistent with the primary ones
+    flat = plan.src
+    for n, r in enumerate(plan.feat_row.tolist()):
+        if r >= 0:
+            assert flat[r] == -2 - n
+    assert (plan.feat_row >= 0).sum() == (flat <= -2).sum()
+    nxt = np.zeros((B, L), dtype=bool)
+    nxt[:, :-1] = g["out_image_positions"][:, 1:] == 1
+    assert plan.pred_rows.tolist() == np.flatnonzero(nxt.reshape(-1)).tolist()
+    st = np.full((B, L), -100)
+    st[:, :-1] = g["out_labels"][:, 1:]
+    assert np.array_equal(plan.shift_targets, st.reshape(-1))
+    assert plan.n_valid == int((st != -100).sum())
+    assert plan.seqlens.tolist() == g["out_attention_mask"].sum(1).tolist()
+    # embedding-gradient segments cover every token row exactly once, grouped by id
+    seen = []
+    for s in range(plan.emb_tok.shape[0]):
+        rows = plan.emb_pos[plan.emb_seg[s]: plan.emb_seg[s + 1]]
+        assert (flat[rows] == plan.emb_tok[s]).all()
+        seen.extend(rows.tolist())
+    assert sorted(seen) == np.flatnonzero(flat >= 0).tolist()
+
+
+def test_splice_plan_matches_oracle_on_random_batches():
+    from metamorph_amd.splice_plan import build_splice_plan
+    from oracle.ref_plan import splice_bookkeeping
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        B = int(rng.integers(1, 5))
+        Timg = int(rng.choice([1, 4, 16]))
+        max_len = int(rng.choice([12, 24, 40, 4096]))
+        rows, labs = [], []
+        for b in range(B):
+            n = int(rng.integers(2, 30))
+            ids = rng.integers(3, 1000, size=n).tolist()
+            lab = [int(x) if rng.random() < 0.5 else -100 for x in ids]
+            for _ in range(int(rng.integers(0, 4))):
+                p = int(rng.integers(1, len(ids)))
+                if ids[p - 1] == -200 or (p < len(ids) and ids[p] == -200):
+                    continue
+                ids.insert(p, -200)
+                lab.insert(p, -200)
+                if rng.random() < 0.5:
+                    lab[p - 1] = 128256
+            rows.append(ids)
+            labs.append(lab)
+        T_ = max(len(r) for r in rows)
+        pad = lambda r, v: r + [v] * (T_ - len(r))
+        ids_a = np.array([pad(r, 0) for r in rows])
+        lab_a = np.array([pad(r, -100) for r in labs])
+        msk_a = np.array([[True] * len(r) + [False] * (T_ - len(r)) for r in rows])
+        n_img = sum(max(1, r.count(-200)) for r in rows)
+        side = "left" if trial % 5 == 0 else "right"
+        ref = splice_bookkeeping(ids_a.tolist(), lab_a.tolist(), msk_a.tolist(), n_img, Timg, max_len, side)
+        plan = build_splice_plan(ids_a, lab_a, msk_a, n_img, Timg, max_len, side)
+        src = [[-1 if s is None else (-2 - (s[1] * Timg + s[2]) if isinstance(s, tuple) else s) for s in row] for row in ref["src"]]
+        assert np.array_equal(plan.src.reshape(plan.B, plan.L), np.array(src))
+        assert np.array_equal(plan.labels, np.array(ref["labels"]))
+        assert np.array_equal(plan.image_positions, np.array(ref["image_positions"]))
+        assert np.array_equal(plan.attention_mask, np.array(ref["attention_mask"]))
+        assert np.array_equal(plan.position_ids, np.array(ref["position_ids"]))
+        assert plan.target_keep.tolist() == ref["target_keep"]
+
+
+def test_splice_plan_error_behaviour():
+    from metamorph_amd.splice_plan import build_splice_plan
+    with pytest.raises(IndexError):                         # sentinel with no token before it (reference :317)
+        build_splice_plan(np.array([[-200, 5]]), np.array([[-100, 5]]), None, 1, 4, 64)
+    with pytest.raises(IndexError):                         # text-only sample but no dummy image supplied (reference :420)
+        build_splice_plan(np.array([[1, 2], [1, -200]]), np.array([[1, 2], [1, -200]]), None, 1, 4, 64)
+
+
+# ------------------------------------------------------------------ C ABI
+
+def test_library_exports_every_declared_symbol():
+    from metamorph_amd import lib
+    names = lib.exported_symbols()
+    assert len(names) >= 30
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), n
+    L = lib.load()
+    assert L.mm355_version() == 100
+    assert b"invalid" in L.mm355_strerror(-1)
+    # argument validation works without a GPU (no kernel is launched on the error path)
+    assert L.mm355_gemm_bf16(0, 8, 0, 8, 0, 8, 16, 16, 16, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert L.mm355_rmsnorm_fwd(0, 0, 0, 4, 8, 1e-5, 0) == -1
+
+
+def test_header_cites_reference_for_every_family():
+    text = open(os.path.join(REPO, "include", "mm355.h")).read()
+    for cite in ("metamorph_llama.py", "metamorph_arch.py", "siglip_encoder.py", "multimodal_projector/builder.py", "zero2.json"):
+        assert cite in text, cite
+
+
+# ------------------------------------------------------------------ isolation rules
+
+def _imports(path):
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom) and node.module:
+            yield ("." * node.level) + node.module
+
+
+def test_product_never_imports_oracle_or_reference():
+    bad = []
+    for path in glob.glob(os.path.join(REPO, "metamorph_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        for mod in _imports(path):
+            if mod.split(".")[0] in ("oracle", "metamorph") or "oracle" in mod:
+                bad.append((path, mod))
+        if "/root/reference" in src:
+            bad.append((path, "/root/reference"))
+    assert not bad, bad
+
+
+def test_no_torch_math_fallback_in_ops():
+    """ops.py may allocate / zero / view tensors but must not compute with torch."""
+    src = open(os.path.join(REPO, "metamorph_amd", "ops.py")).read()
+    for banned in ("torch.matmul", "torch.nn.functional", "F.linear", ".softmax(", "torch.einsum", "@ ", ".mm(", "scaled_dot_product"):
+        assert banned not in src, banned
+
+
+def test_cpu_tensor_is_refused_not_emulated():
+    from metamorph_amd import ops
+    from metamorph_amd.lib import Mm355Unavailable
+    a = torch.zeros(16, 16, dtype=torch.bfloat16)
+    with pytest.raises(Mm355Unavailable):
+        ops.gemm(a, a)
+    with pytest.raises(Mm355Unavailable):
+        ops.rmsnorm_fwd(a, a[0], 1e-5)
+
+
+# ------------------------------------------------------------------ model surface
+
+def test_state_dict_keys_and_config():
+    from metamorph_amd.factory import build_model
+    llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+               vocab_size=300, rms_norm_eps=1e-5, rope_theta=500000.0)
+    m = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
+    keys = set(m.state_dict().keys())
+    expect = {"model.embed_tokens.weight", "model.norm.weight", "lm_head.weight", "model.mm_projector.0.weight",
+              "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias",
+              "model.vision_proj.weight", "model.vision_proj.bias", "vision_head.0.weight", "vision_head.0.bias",
+              "vision_head.2.weight", "vision_head.2.bias",
+              "model.vision_tower.vision_tower.embeddings.patch_embedding.weight",
+              "model.vision_tower.vision_tower.embeddings.position_embedding.weight",
+              "model.vision_tower.vision_tower.encoder.layers.0.self_attn.out_proj.bias",
+              "model.vision_tower.vision_tower.encoder.layers.0.mlp.fc1.weight",
+              "model.vision_tower.vision_tower.post_layernorm.weight"}
+    for i in range(2):
+        for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+                  "mlp.down_proj", "input_layernorm", "post_attention_layernorm"):
+            expect.add(f"model.layers.{i}.{n}.weight")
+    assert expect <= keys, expect - keys
+    assert m.config.model_type == "metamorph_llama"
+    assert m.vision_head[2].weight.shape == (1152, 64)
+    assert np.isnan(m.loss_language) and np.isnan(m.loss_image_ar)
+    from metamorph_amd.model import build_vision_projector
+    with pytest.raises(ValueError):
+        build_vision_projector(type("C", (), dict(mm_projector_type="nope", mm_hidden_size=8, hidden_size=8))())
+
+
+def test_fused_weight_views_survive_dtype_cast():
+    from metamorph_amd import functional as F
+    ps = [torch.nn.Parameter(torch.randn(4, 8)), torch.nn.Parameter(torch.randn(2, 8)), torch.nn.Parameter(torch.randn(2, 8))]
+    before = [p.detach().clone() for p in ps]
+    w = F.fused_weight(ps)
+    assert w.shape == (8, 8) and all(torch.equal(p.data, b) for p, b in zip(ps, before))
+    assert F._adjacent([p.data for p in ps]) and F.fused_weight(ps).data_ptr() == w.data_ptr()
+    w[0, 0] = 42.0
+    assert float(ps[0][0, 0]) == 42.0
+    fb, acc, bufs = F.fused_grad_target(ps)
+    assert acc is False and fb.shape == (8, 8)
+    fb.fill_(1.0)
+    F.commit_fused_grad(ps, fb, acc, bufs)
+    assert all(p.grad is not None and float(p.grad.sum()) == p.numel() for p in ps)
+    fb2, acc2, _ = F.fused_grad_target(ps)
+    assert acc2 is True and fb2.data_ptr() == fb.data_ptr()
