@@ -500,6 +500,7 @@ int pick_dp(int64_t d) { return d <= 64 ? 64 : (d <= 96 ? 96 : 128); }
 extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* vt, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
                               int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv,
                               int64_t d, float scale, int causal, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !vt || !o || !lse || B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
     FwdArgs a{q, k, vt, ld_q, ld_k, ld_o, o, lse, seqlens, (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
@@ -515,6 +516,7 @@ extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm
 
 extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta, mm355_bf16* dot, int64_t B, int64_t L,
                                    int64_t Lp, int64_t Hq, int64_t d, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!o || !d_o || !delta || !dot || B <= 0 || L <= 0 || Hq <= 0 || d <= 0 || d > 128 || (d & 7) || (ld_o & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
     dim3 grid((unsigned)(Lp / 64), (unsigned)Hq, (unsigned)B);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, grid, dim3(NT), 0, (hipStream_t)stream, o, d_o, ld_o, delta, dot, (int)L, (int)Lp, (int)Hq, (int)d);
@@ -525,6 +527,7 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
                               int64_t ld_o, const mm355_bf16* qt, const mm355_bf16* kt, const mm355_bf16* dot, const float* lse,
                               const float* delta, const int32_t* seqlens, float* dq_f32, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
                               int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !d_o || !qt || !kt || !dot || !lse || !delta || !dq_f32 || !dk || !dv) return MM355_EINVAL;
     if (B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;

@@ -319,71 +319,86 @@ extern "C" const char* mm355_strerror(int code) {
 }
 
 extern "C" int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, float theta, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!cos_out || !sin_out || L <= 0 || d <= 0 || (d & 1)) return MM355_EINVAL;
     LAUNCH(rope_table_kernel, grid_for(L * d / 2), cos_out, sin_out, (int)L, (int)d, theta);
 }
 extern "C" int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, const mm355_bf16* cos_t,
                              const mm355_bf16* sin_t, int inverse, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!qkv || !cos_t || !sin_t || B <= 0 || L <= 0 || Hq <= 0 || Hkv < 0 || d <= 0 || (d & 15) || (ld & 7)) return MM355_EINVAL;
     const int64_t H = Hq + Hkv;                              // q heads then k heads are contiguous column blocks
     LAUNCH(rope_qk_kernel, grid_for(B * L * H * (d / 16)), qkv, ld, (int)B, (int)L, (int)H, (int)d, cos_t, sin_t, inverse);
 }
 extern "C" int mm355_head_transpose(const mm355_bf16* in, int64_t ld, int64_t col0, int64_t B, int64_t L, int64_t H, int64_t d, mm355_bf16* out,
                                     int64_t Lp, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || B <= 0 || L <= 0 || H <= 0 || d <= 0 || d > 128 || (d & 7) || (ld & 7) || (col0 & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
     hipLaunchKernelGGL(head_transpose_kernel, dim3((unsigned)(Lp / 64), (unsigned)H, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, in, ld, col0,
                        (int)L, (int)H, (int)d, out, (int)Lp);
     return mm_launch_status();
 }
 extern "C" int mm355_swiglu_fwd(const mm355_bf16* gu, mm355_bf16* act, int64_t M, int64_t I, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!gu || !act || M <= 0 || I <= 0 || (I & 7)) return MM355_EINVAL;
     LAUNCH(swiglu_fwd_kernel, grid_for(M * (I / 8)), gu, act, M, (int)I);
 }
 extern "C" int mm355_swiglu_bwd(const mm355_bf16* gu, const mm355_bf16* dact, mm355_bf16* dgu, mm355_bf16* act, int64_t M, int64_t I, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!gu || !dact || !dgu || M <= 0 || I <= 0 || (I & 7)) return MM355_EINVAL;
     LAUNCH(swiglu_bwd_kernel, grid_for(M * (I / 8)), gu, dact, dgu, act, M, (int)I);
 }
 extern "C" int mm355_gelu_fwd(const mm355_bf16* x, mm355_bf16* y, int64_t n, int kind, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !y || n <= 0 || (n & 7)) return MM355_EINVAL;
     LAUNCH(gelu_fwd_kernel, grid_for(n / 8), x, y, n, kind);
 }
 extern "C" int mm355_gelu_bwd(const mm355_bf16* x, const mm355_bf16* dy, mm355_bf16* dx, int64_t n, int kind, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !dy || !dx || n <= 0 || (n & 7)) return MM355_EINVAL;
     LAUNCH(gelu_bwd_kernel, grid_for(n / 8), x, dy, dx, n, kind);
 }
 extern "C" int mm355_scale_bf16(mm355_bf16* x, int64_t n, const float* s_dev, float s_host, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || n <= 0 || !mm_aligned16(x)) return MM355_EINVAL;
     LAUNCH(scale_kernel, grid_for(n / 8 + 1), x, n, s_dev, s_host);
 }
 extern "C" int mm355_axpy_bf16(mm355_bf16* y, const mm355_bf16* x, int64_t n, const float* s_dev, float s_host, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !y || n <= 0) return MM355_EINVAL;
     LAUNCH(axpy_kernel<uint16_t>, grid_for(n), y, x, n, s_dev, s_host, accumulate);
 }
 extern "C" int mm355_axpy_f32_to_bf16(mm355_bf16* y, const float* x, int64_t n, float s_host, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !y || n <= 0) return MM355_EINVAL;
     LAUNCH(axpy_kernel<float>, grid_for(n), y, x, n, (const float*)nullptr, s_host, accumulate);
 }
 extern "C" int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int64_t ld_out, int64_t rows, int64_t cols, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || rows <= 0 || cols <= 0 || (cols & 7) || (ld_in & 3) || (ld_out & 7)) return MM355_EINVAL;
     LAUNCH(cast2d_kernel, grid_for(rows * (cols / 8)), in, ld_in, out, ld_out, rows, (int)cols);
 }
 extern "C" int mm355_adamw_shard(float* p32, float* m, float* v, const mm355_bf16* g, mm355_bf16* p_out, int64_t n, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* grad_scale_dev,
                                  void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!p32 || !m || !v || !g || !p_out || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return MM355_EINVAL;
     LAUNCH(adamw_kernel, grid_for(n), p32, m, v, g, p_out, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
 }
 extern "C" int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !out || n <= 0 || !mm_aligned16(x)) return MM355_EINVAL;
     LAUNCH(sumsq_kernel, grid_for(n / 8 + 1), x, n, out);
 }
 extern "C" int mm355_clip_coef(const float* sumsq, float max_norm, float pre_scale, float* coef, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!sumsq || !coef) return MM355_EINVAL;
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, pre_scale, coef);
     return mm_launch_status();
 }
 extern "C" int mm355_im2col_patch(const void* images, int images_are_f32, int64_t N, int64_t H, int64_t W, int64_t p, mm355_bf16* out, int64_t Kp,
                                   void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!images || !out || N <= 0 || H < p || W < p || p <= 0 || Kp < 3 * p * p) return MM355_EINVAL;
     const int64_t total = N * (H / p) * (W / p) * Kp;
     if (images_are_f32) LAUNCH(im2col_kernel<float>, grid_for(total), (const float*)images, (int)N, (int)H, (int)W, (int)p, out, (int)Kp);
@@ -391,21 +406,25 @@ extern "C" int mm355_im2col_patch(const void* images, int images_are_f32, int64_
 }
 extern "C" int mm355_splice_gather(const mm355_bf16* embed, const mm355_bf16* proj, const int32_t* src, mm355_bf16* out, int64_t rows, int64_t h,
                                    void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!embed || !src || !out || rows <= 0 || h <= 0 || (h & 7)) return MM355_EINVAL;
     LAUNCH(splice_gather_kernel, (unsigned)((rows + 3) / 4), embed, proj, src, out, rows, (int)h);
 }
 extern "C" int mm355_rows_gather(const mm355_bf16* in, int64_t ld_in, const int32_t* idx, mm355_bf16* out, int64_t ld_out, int64_t R, int64_t h,
                                  void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !idx || !out || R <= 0 || h <= 0 || (h & 7) || (ld_in & 7) || (ld_out & 7)) return MM355_EINVAL;
     LAUNCH(rows_gather_kernel, (unsigned)((R + 3) / 4), in, ld_in, idx, out, ld_out, R, (int)h);
 }
 extern "C" int mm355_rows_scatter_add(const mm355_bf16* src, int64_t ld_src, const int32_t* idx, mm355_bf16* dst, int64_t ld_dst, int64_t R,
                                       int64_t h, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!src || !idx || !dst || R <= 0 || h <= 0 || (h & 7) || (ld_src & 7) || (ld_dst & 7)) return MM355_EINVAL;
     LAUNCH(rows_scatter_add_kernel, (unsigned)((R + 3) / 4), src, ld_src, idx, dst, ld_dst, R, (int)h);
 }
 extern "C" int mm355_embed_grad(const mm355_bf16* dout, const int32_t* tok, const int32_t* seg_start, const int32_t* pos, int64_t n_seg,
                                 mm355_bf16* dembed, int64_t h, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dout || !tok || !seg_start || !pos || !dembed || n_seg <= 0 || h <= 0 || (h & 7)) return MM355_EINVAL;
     LAUNCH(embed_grad_kernel, (unsigned)((n_seg + 3) / 4), dout, tok, seg_start, pos, n_seg, dembed, (int)h, accumulate);
 }

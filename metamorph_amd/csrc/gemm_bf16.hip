@@ -345,6 +345,7 @@ extern "C" int mm355_gemm_num_variants(void) { return 6; }
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
                                int64_t ldr, int64_t res_row_mod, uint32_t flags, int variant, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
     if ((K & 7) || (lda & 7) || (ldb & 7) || !mm_aligned16(A) || !mm_aligned16(B) || !mm_aligned16(C)) return MM355_EINVAL;
     if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
@@ -378,6 +379,7 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
 
 extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols, mm355_bf16* out,
                                     int64_t ld_out, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || rows <= 0 || cols <= 0 || (ld_in & 7) || !mm_aligned16(in) || !mm_aligned16(out)) return MM355_EINVAL;
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (int)rows, (int)cols, out, ld_out);
@@ -385,6 +387,7 @@ extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t
 }
 
 extern "C" int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dY || !db_f32 || M <= 0 || N <= 0) return MM355_EINVAL;
     const int rpb = 256;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb));

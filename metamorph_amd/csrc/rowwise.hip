@@ -353,6 +353,7 @@ int dispatch_vpt(int h, F&& f) {
 }  // namespace
 
 extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h, float eps, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !w || !y || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
     return dispatch_vpt((int)h, [&](auto vpt) {
         hipLaunchKernelGGL((rmsnorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, y, (int)h, eps);
@@ -362,6 +363,7 @@ extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355
 
 extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres,
                                  mm355_bf16* dx, float* dw_f32, int64_t M, int64_t h, float eps, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dy || !x || !w || !dx || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
     const int rpb = M >= 8192 ? 16 : (M >= 1024 ? 4 : 1);
     const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
@@ -374,6 +376,7 @@ extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, cons
 
 extern "C" int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y, int64_t M, int64_t h,
                                    float eps, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !w || !b || !y || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
     return dispatch_vpt((int)h, [&](auto vpt) {
         hipLaunchKernelGGL((layernorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, b, y, (int)h, eps);
@@ -383,6 +386,7 @@ extern "C" int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, con
 
 extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V, float grad_scale,
                              float* loss_sum, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!logits || !targets || !loss_sum || R <= 0 || V <= 0 || ld < V || (ld & 7) || R > 0x7fffffff || !mm_aligned16(logits)) return MM355_EINVAL;
     hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(CE_NT), 0, (hipStream_t)stream, logits, ld, targets, (int)V, grad_scale, loss_sum);
     return mm_launch_status();
@@ -390,6 +394,7 @@ extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targ
 
 extern "C" int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
                                  float* cos_sum, mm355_bf16* dpred, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!pred_raw || !target || !cos_sum || R <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
     const unsigned grid = (unsigned)((R + NT / 64 - 1) / (NT / 64));
     hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize, cos_sum, dpred);
@@ -398,6 +403,7 @@ extern "C" int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* t
 
 extern "C" int mm355_bilinear_l2norm(const mm355_bf16* in, mm355_bf16* out, int64_t N, int64_t side_in, int64_t side_out, int64_t C,
                                      int normalize, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || N <= 0 || side_in <= 0 || side_out <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
     const int64_t toks = N * side_out * side_out;
     const unsigned grid = (unsigned)((toks + NT / 64 - 1) / (NT / 64));

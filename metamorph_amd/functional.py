@@ -21,11 +21,18 @@ BF16 = torch.bfloat16
 # ------------------------------------------------------------------------------------------------
 
 def _adjacent(ts):
-    """True if the 2-D contiguous tensors `ts` are back-to-back rows of one storage."""
+    """True if the 2-D contiguous tensors `ts` are back-to-back rows of ONE storage object (tensors that merely
+    happen to sit next to each other in the caching allocator do not count: a view over them would outgrow the
+    first tensor's storage)."""
     t0 = ts[0]
     ptr = t0.data_ptr()
+    st = t0.untyped_storage()
+    total = sum(t.numel() * t.element_size() for t in ts)
+    if ptr - st.data_ptr() + total > st.nbytes():
+        return False
     for t in ts:
-        if not t.is_contiguous() or t.data_ptr() != ptr or t.shape[1:] != t0.shape[1:] or t.dtype != t0.dtype:
+        if (not t.is_contiguous() or t.data_ptr() != ptr or t.shape[1:] != t0.shape[1:] or t.dtype != t0.dtype
+                or t.untyped_storage().data_ptr() != st.data_ptr()):
             return False
         ptr += t.numel() * t.element_size()
     return True

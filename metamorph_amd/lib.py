@@ -65,6 +65,10 @@ def load():
         _load_error = (f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950).  metamorph_amd has no non-HIP fallback.")
         raise Mm355Unavailable(_load_error)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; it must be the HIP runtime this library binds to (one
+    # runtime per process: streams and device pointers are not interchangeable between two copies).  Importing
+    # torch first makes the dynamic linker resolve our DT_NEEDED libamdhip64.so.N to the already-loaded copy.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

