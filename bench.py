@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MetaMorph instruction-tuning step throughput on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): LLaMA-3-8B geometry + SigLIP-SO400M/14-384 tower (the tower the reference
+hard-codes), 2048-token spliced sequences with one 256-token image each, bf16, full fine-tune of everything
+but the tower (reference stage 2), fused AdamW with ZeRO-2 sharding over RCCL.  One step = zero_grad + forward +
+backward + gradient reduce-scatter + AdamW shard update + parameter all-gather on one batch of synthetic samples;
+weights are random (no checkpoints can be downloaded), data is synthetic and resident in HBM.
+
+Prints ONE JSON line (rank 0).  `value` = total valid spliced tokens per second over all GPUs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (256 CU x 2.4 GHz x 4096 FLOP/clk/CU)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step (each 2048 spliced tokens)")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--image-tokens", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
+    ap.add_argument("--vit-layers", type=int, default=27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(B, L, T, device, seed):
+    """[BOS,BOS, 20 text, <image_start>, <image>, <image_end>, text ...] padded so the SPLICED length is exactly L.
+    Samples 1..B-1 are image-QA (prompt-side image, labels -100 on the first 300 spliced positions); sample 0 is a
+    generation sample (answer-side image: the label at <image_start> is live) so the vision-head / cosine path runs and
+    the combined loss is finite (with no answer image the reference's loss is NaN)."""
+    g = torch.Generator().manual_seed(seed)
+    n_ids = L - T + 1
+    ids = torch.randint(0, 127999, (B, n_ids), generator=g)
+    ids[:, 0] = 128000
+    ids[:, 1] = 128000
+    ids[:, 22], ids[:, 23], ids[:, 24] = 128256, -200, 128257
+    labels = ids.clone()
+    spliced_pos = torch.arange(n_ids)
+    spliced_pos = torch.where(spliced_pos > 23, spliced_pos + T - 1, spliced_pos)
+    labels[:, spliced_pos < 300] = -100
+    labels[:, 23] = -100
+    labels[0, 20:] = ids[0, 20:]            # generation sample: supervise from just before <image_start>
+    labels[0, 23] = -200
+    mask = torch.ones(B, n_ids, dtype=torch.bool)
+    images = torch.randn(B, 3, 384, 384, generator=g)
+    return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
+
+
+class GemmTimer:
+    """HIP-event timing of every GEMM launch (torch.cuda.Event == hipEvent on the stream the kernels are launched on)."""
+
+    def __init__(self):
+        from metamorph_amd import ops
+        self.ops = ops
+        self.orig = ops.gemm
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        def timed(a, b, out=None, **kw):
+            if not self.enabled:
+                return self.orig(a, b, out, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(a, b, out, **kw)
+            e.record()
+            M, K = a.shape
+            N = kw.get("n") or b.shape[0]
+            self.records.append((s, e, 2.0 * M * N * K))
+            return r
+        self.ops.gemm = timed
+        import metamorph_amd.functional as F
+        F.ops.gemm = timed
+
+    def summary(self):
+        torch.cuda.synchronize()
+        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), t, fl
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: LLaMA-3-8B / SO400M
+    layer geometry, 2 of 32 decoder layers, 2 of 27 tower layers, full 128258-entry lm_head, one 512-token sample
+    (256 image + 256 text rows), fp32, forward+backward with the stage-2 freeze policy; per-stage times are scaled to
+    the full depth to quote tokens/s."""
+    import numpy as np
+    from oracle.ref_model import OracleConfig, init_state_dict
+    from oracle import ref_model as RM, ref_ops as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = OracleConfig(num_hidden_layers=2, v_layers=2, num_image_tokens=256, tokenizer_model_max_length=4096)
+    sd = init_state_dict(cfg, seed=1)
+    for k, v in sd.items():
+        if "vision_tower" not in k and "vision_proj" not in k:
+            v.requires_grad_(True)
+    L = 512
+    n_ids = L - 256 + 1
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 127999, (1, n_ids), generator=g)
+    ids[0, :2] = 128000
+    ids[0, 22], ids[0, 23], ids[0, 24] = 128256, -200, 128257
+    labels = ids.clone()
+    labels[0, :20] = -100
+    images = torch.randn(1, 3, 384, 384, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        feat = RM.vision_features(sd, cfg, images)
+    t_vit = time.time() - t0
+    t0 = time.time()
+    proj = RM.mm_projector(sd, cfg, feat)
+    x, lab, valid, pos, tgt, _ = RM.splice(sd, cfg, ids, labels, torch.ones_like(ids, dtype=torch.bool), proj, feat)
+    hid = RM.llama_decoder(sd, cfg, x, valid)
+    t_dec_f = time.time() - t0
+    t0 = time.time()
+    logits = R.linear(hid, sd["lm_head.weight"]).float()
+    ce = R.shifted_cross_entropy(logits, lab)
+    pred = R.l2_normalize(RM.vision_head(sd, cfg, hid[:, :-1][pos[:, 1:].bool()]))
+    loss = ce + R.cosine_loss(tgt.reshape(-1, tgt.shape[-1]), pred)
+    t_head_f = time.time() - t0
+    t0 = time.time()
+    loss.backward()
+    t_bwd = time.time() - t0
+    # backward splits ~ like forward between decoder and head
+    frac_dec = t_dec_f / (t_dec_f + t_head_f)
+    t_dec = t_dec_f + t_bwd * frac_dec
+    t_head = t_head_f + t_bwd * (1 - frac_dec)
+    full = t_dec * (32 / 2) + t_head + t_vit * (27 / 2)
+    return {"value": round(L / full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens (256 image + 256 text), LLaMA-3-8B + SO400M layer "
+                       f"geometry with 2/32 decoder and 2/27 tower layers + full lm_head; measured {t_dec:.2f}s (2 dec layers) "
+                       f"{t_head:.2f}s (heads) {t_vit:.2f}s (2 tower layers), scaled to full depth = {full:.1f}s per {L} tokens"),
+            "measured_seconds": round(t_dec + t_head + t_vit, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+
+    from metamorph_amd.factory import LLAMA3_8B, build_model
+    from metamorph_amd.zero2 import Zero2AdamW
+
+    llm = dict(LLAMA3_8B, num_hidden_layers=args.layers)
+    geo = dict(num_hidden_layers=args.vit_layers)
+    torch.manual_seed(1234 + rank)
+    t_build = time.time()
+    model = build_model(llm, geo, num_image_tokens=args.image_tokens, max_length=4096, device=dev, init_on_device=True)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    n_params = sum(p.numel() for p in params)
+    if world > 1:                                                # identical initial weights on every rank
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    t_build = time.time() - t_build
+
+    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank)
+    timer = GemmTimer()
+    if not args.no_kernel_timing:
+        timer.install()
+
+    def step():
+        opt.zero_grad()
+        out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images)
+        out.loss.backward()
+        opt.step()
+        return out.loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(loss.detach())
+    tokens_per_rank = args.batch * args.seq
+    value = world * tokens_per_rank * args.steps / dt
+
+    n_gemm, t_gemm, fl_gemm = timer.summary() if not args.no_kernel_timing else (0, 0.0, 0.0)
+    roofline = None
+    if n_gemm:
+        ach = fl_gemm / t_gemm / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
+                    "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": n_gemm, "gemm_seconds_per_step": round(t_gemm / args.steps, 4),
+                    "algorithmic_flops_per_step": fl_gemm / args.steps}
+    # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
+    h, V, L = 4096, 128258, args.seq
+    per_tok = 3.0 * (args.layers * (436.2076e6 + 2.0 * L * h) + 2.0 * h * V)
+    step_flops = per_tok * tokens_per_rank + args.batch * 666.5e9 * (args.vit_layers / 27.0)
+    mfu = step_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
+
+    if rank == 0:
+        rec = {
+            "metric": "train tokens/sec (LLaMA-3-8B + SigLIP-SO400M, seq2048, 256 img toks), whole job",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/pixels)",
+            "tokens_per_sec_per_gpu": round(value / world, 1),
+            "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
+                                   "bf16 full fine-tune (tower frozen), AdamW + ZeRO-2",
+                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens,
+                       "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
+                       "parallelism": f"dp{world} zero2", "samples": f"{args.batch - 1} image-QA + 1 image-generation per GPU"},
+            "loss": round(loss_val, 4), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
+            "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+        }
+        if roofline:
+            rec["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""ZeRO-2 partition / collective logic on CPU: world_size 2 over gloo must reproduce a single-rank AdamW step on
+the mean gradient (the reference's DeepSpeed semantics: gradients averaged over data-parallel ranks, global-norm
+clipping, one AdamW update; scripts/zero2.json + HF Trainer).  The shard-update arithmetic is injected from the
+oracle here because the HIP kernel cannot run on CPU; on the GPU box the same class runs with the kernel
+(tests/test_zero2_gpu.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_ops as R
+
+
+def _oracle_update(p32, m, v, g, p_out, lr, b1, b2, eps, wd, step, scale_dev):
+    R.adamw_step(p32, g, m, v, step, lr, b1, b2, eps, wd, grad_scale=float(scale_dev))
+    p_out.copy_(p32.to(p_out.dtype))
+
+
+def _oracle_sumsq(x, out):
+    out += (x.float() ** 2).sum()
+
+
+def _oracle_clip(sumsq, max_norm, pre, out):
+    c = 1.0 if max_norm <= 0 else min(1.0, max_norm / (float(sumsq) ** 0.5 + 1e-6))
+    out[0] = c * pre
+
+
+def _make_params(dtype):
+    g = torch.Generator().manual_seed(0)
+    shapes = [(8, 16), (4, 16), (4, 16), (16, 16), (37,), (5, 3)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).to(dtype)) for s in shapes]
+
+
+def _grads_for(rank, step, params):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return [torch.randn(p.shape, generator=g).to(p.dtype) * 3.0 for p in params]
+
+
+def _worker(rank, world, port, dtype, steps, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metamorph_amd.zero2 import Zero2AdamW
+        params = _make_params(dtype)
+        opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
+                         shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+        assert opt.world == world and opt.shard * world == opt.padded
+        # fused blocks stay contiguous in the flat buffer (q/k/v -> one GEMM operand)
+        assert params[1].data_ptr() == params[0].data_ptr() + params[0].numel() * params[0].element_size()
+        for s in range(1, steps + 1):
+            for p, g in zip(params, _grads_for(rank, s, params)):
+                p._mm_grad_buf.copy_(g)              # what the backward kernels do
+                p.grad = p._mm_grad_buf
+            if s == 2:
+                params[-1].grad = None               # a parameter without gradient this step contributes zeros
+            opt.step()
+            opt.zero_grad()
+            assert all(p.grad is None for p in params)
+        flat = torch.cat([p.data.reshape(-1) for p in params])
+        torch.save(flat, os.path.join(tmp, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_ranks_equal_one_rank(tmp_path, dtype):
+    world, steps = 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert torch.equal(r0, r1), "ranks must hold identical parameters after the all-gather"
+
+    # single-rank reference with the same per-step gradients (step 2: last parameter has no gradient)
+    params = _make_params(dtype)
+    flat = torch.cat([p.data.reshape(-1) for p in params]).float()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    n_last = params[-1].numel()
+    for s in range(1, steps + 1):
+        per_rank = []
+        for r in range(world):
+            g = torch.cat([x.reshape(-1) for x in _grads_for(r, s, params)]).to(dtype).float()
+            if s == 2:
+                g[-n_last:] = 0
+            per_rank.append(g)
+        summed = per_rank[0] + per_rank[1]
+        if dtype == torch.bfloat16:
+            summed = summed.to(dtype).float()
+        coef = min(1.0, 1.0 / (float(summed.norm()) / world + 1e-6)) / world
+        R.adamw_step(flat, summed, m, v, s, 1e-2, 0.9, 0.95, 1e-8, 0.1, grad_scale=coef)
+    want = flat.to(dtype)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1e-2)
+    torch.testing.assert_close(r0.float(), want.float(), **tol)
+
+
+def test_single_process_world1(tmp_path):
+    from metamorph_amd.zero2 import Zero2AdamW
+    params = _make_params(torch.float32)
+    before = [p.detach().clone() for p in params]
+    opt = Zero2AdamW(params, lr=1e-2, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+    assert all(torch.equal(p.data, b) for p, b in zip(params, before)), "flattening must not change values"
+    for p, g in zip(params, _grads_for(0, 1, params)):
+        p._mm_grad_buf.copy_(g)
+        p.grad = p._mm_grad_buf
+    opt.step()
+    assert not any(torch.equal(p.data, b) for p, b in zip(params, before))
+    sd = opt.state_dict()
+    opt2 = Zero2AdamW(_make_params(torch.float32), lr=1e-2, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.master, opt.master) and opt2._step == 1
