@@ -103,15 +103,20 @@ class GemmTimer:
 
 def cpu_baseline(args):
     """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: LLaMA-3-8B / SO400M
-    layer geometry, 2 of 32 decoder layers, 2 of 27 tower layers, full 128258-entry lm_head, one 512-token sample
+    layer geometry, 1 of 32 decoder layers, 1 of 27 tower layers, full 128258-entry lm_head, one 512-token sample
     (256 image + 256 text rows), fp32, forward+backward with the stage-2 freeze policy; per-stage times are scaled to
     the full depth to quote tokens/s."""
     import numpy as np
     from oracle.ref_model import OracleConfig, init_state_dict
     from oracle import ref_model as RM, ref_ops as R
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))                 # more threads than that only adds contention for this size
     torch.set_num_threads(threads)
-    cfg = OracleConfig(num_hidden_layers=2, v_layers=2, num_image_tokens=256, tokenizer_model_max_length=4096)
+    NL = 1                                           # decoder / tower layers actually run (scaled to 32 / 27 below)
+    cfg = OracleConfig(num_hidden_layers=NL, v_layers=NL, num_image_tokens=256, tokenizer_model_max_length=4096)
     sd = init_state_dict(cfg, seed=1)
     for k, v in sd.items():
         if "vision_tower" not in k and "vision_proj" not in k:
@@ -147,11 +152,11 @@ def cpu_baseline(args):
     frac_dec = t_dec_f / (t_dec_f + t_head_f)
     t_dec = t_dec_f + t_bwd * frac_dec
     t_head = t_head_f + t_bwd * (1 - frac_dec)
-    full = t_dec * (32 / 2) + t_head + t_vit * (27 / 2)
+    full = t_dec * (32 / NL) + t_head + t_vit * (27 / NL)
     return {"value": round(L / full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens (256 image + 256 text), LLaMA-3-8B + SO400M layer "
-                       f"geometry with 2/32 decoder and 2/27 tower layers + full lm_head; measured {t_dec:.2f}s (2 dec layers) "
-                       f"{t_head:.2f}s (heads) {t_vit:.2f}s (2 tower layers), scaled to full depth = {full:.1f}s per {L} tokens"),
+                       f"geometry with {NL}/32 decoder and {NL}/27 tower layers + full lm_head; measured {t_dec:.2f}s ({NL} dec layer) "
+                       f"{t_head:.2f}s (heads) {t_vit:.2f}s ({NL} tower layer), scaled to full depth = {full:.1f}s per {L} tokens"),
             "measured_seconds": round(t_dec + t_head + t_vit, 2)}
 
 
