@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip"]
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result"]
 
@@ -24,7 +24,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + ["mm355_common.h"]:
+    for f in SOURCES + ["mm355_common.h", "attn2.h"]:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(os.path.dirname(PKG), "include", "mm355.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())

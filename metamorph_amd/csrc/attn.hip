@@ -15,6 +15,8 @@
 // Workgroup = 4 waves.  fwd: 64 query rows (16 per wave) x KV tiles of 64.  bwd: one KV tile of 64 keys
 // (16 per wave) of one KV head, looping over the GQA group's query heads and 32-row query tiles.
 #include "mm355_common.h"
+#include "attn2.h"
+#include <cstdlib>
 
 namespace {
 
@@ -269,7 +271,7 @@ struct BwdArgs {
     float scale; int causal;
 };
 
-template <int DP>
+template <int DP, bool WITH_DQ>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     constexpr int DS = DP == 64 ? 64 : 128;
     constexpr int KS = DP / 32;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
         }
     }
     // Kt tile [DP][64 keys] (B operand of dQ = dS K), loaded once
-    {
+    if constexpr (WITH_DQ) {
         const uint16_t* ktb = a.kt + (((int64_t)b * a.Hkv + hk) * d) * a.Lp + kv0;
         for (int v = tid; v < DP * 8; v += NT) {
             const int r = v >> 3, c = v & 7;
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
                 dvacc[j] = mfma16(pa, dob8, dvacc[j]);
                 dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
             }
+            if constexpr (WITH_DQ) {
             // dS -> LDS as [32 q][64 keys] for dQ = dS K (contraction over the workgroup's 64 keys)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
                     }
                 }
             }
+            }  // WITH_DQ
         }
     }
 
@@ -495,6 +499,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
 
 int pick_dp(int64_t d) { return d <= 64 ? 64 : (d <= 96 ? 96 : 128); }
 
+// MM355_ATTN_V1=1 selects the first-generation kernels of this file (kept for A/B runs)
+bool use_v1() {
+    const char* e = std::getenv("MM355_ATTN_V1");
+    return e && e[0] == '1';
+}
+
 }  // namespace
 
 extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* vt, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
@@ -503,9 +513,14 @@ extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !vt || !o || !lse || B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_v1()) {
+        attn2::Args a2{q, k, nullptr, vt, nullptr, nullptr, ld_q, ld_k, ld_o, o, lse, nullptr, nullptr, nullptr, seqlens,
+                       (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
+        return mm355_attn2_fwd_launch(a2, pick_dp(d), s);
+    }
     FwdArgs a{q, k, vt, ld_q, ld_k, ld_o, o, lse, seqlens, (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)Hq, (unsigned)B);
-    hipStream_t s = (hipStream_t)stream;
     switch (pick_dp(d)) {
         case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(NT), 0, s, a); break;
         case 96: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(NT), 0, s, a); break;
@@ -535,10 +550,23 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
               (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)Hkv, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
+    if (!use_v1()) {
+        // dK/dV: KV-tile-owning kernel without the dQ part; dQ: query-tile-owning kernel (no atomics)
+        switch (pick_dp(d)) {
+            case 64: hipLaunchKernelGGL((attn_bwd_kernel<64, false>), grid, dim3(NT), 0, s, a); break;
+            case 96: hipLaunchKernelGGL((attn_bwd_kernel<96, false>), grid, dim3(NT), 0, s, a); break;
+            default: hipLaunchKernelGGL((attn_bwd_kernel<128, false>), grid, dim3(NT), 0, s, a); break;
+        }
+        int rc = mm_launch_status();
+        if (rc != MM355_OK) return rc;
+        attn2::Args a2{q, k, v, nullptr, kt, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq_f32, seqlens,
+                       (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
+        return mm355_attn2_dq_launch(a2, pick_dp(d), s);
+    }
     switch (pick_dp(d)) {
-        case 64: hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(NT), 0, s, a); break;
-        case 96: hipLaunchKernelGGL(attn_bwd_kernel<96>, grid, dim3(NT), 0, s, a); break;
-        default: hipLaunchKernelGGL(attn_bwd_kernel<128>, grid, dim3(NT), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((attn_bwd_kernel<64, true>), grid, dim3(NT), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((attn_bwd_kernel<96, true>), grid, dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL((attn_bwd_kernel<128, true>), grid, dim3(NT), 0, s, a); break;
     }
     return mm_launch_status();
 }

@@ -1,0 +1,435 @@
+// Attention, second generation (gfx950): "swapped" formulation, P never leaves registers.
+//
+//   forward   S^T = K Q^T   (A = K tile from LDS, B = Q fragments in registers)
+//             lane holds S^T[key = j*16 + fq*4 + r][q = fr]  -> a query row lives in 4 lanes x 16 registers:
+//             row max / sum = 15 in-register ops + 2 shuffles; the exponentiated P^T accumulators ARE the
+//             B operand of O^T += Vt P^T (k-slot e of lane group fq <-> key fq*4+e / 16+fq*4+e-4, and the
+//             A operand Vt[d][key] is read from LDS with the same permutation as two 8-byte reads).
+//             No P round trip through LDS, no block barrier inside a KV tile.
+//   dQ        same structure with three MFMA groups per KV tile:  S^T = K Q^T,  dP^T = V dO^T,
+//             dQ^T += Kt dS^T.  One workgroup owns its query rows => plain stores, no atomics.
+//   K/V tiles are double buffered in LDS with register-staged prefetch (global loads for tile t+1 are issued
+//   before the MFMAs of tile t, written to the other buffer after them; one barrier per tile).
+//
+// Workgroup = 4 waves, each wave owns RQ*16 query rows.  Replaces torch SDPA as driven by HF LlamaModel /
+// SiglipAttention (reference call sites metamorph_llama.py:349-359, siglip_encoder.py:141).
+#include "attn2.h"
+
+namespace attn2 {
+
+constexpr int NT = 256;
+
+MM_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// [rows][128 el] tile (256-B rows): 16-B chunk ^ (row & 15);  [rows][64 el] tile (128-B rows): chunk ^ swz64(row)
+MM_DEV int off128(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+MM_DEV int swz64(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+MM_DEV int off64(int row, int chunk) { return row * 128 + ((chunk ^ swz64(row)) << 4); }
+
+
+template <int DP> struct Geo {
+    static constexpr int DS = DP == 64 ? 64 : 128;          // LDS row length of [key][d] tiles
+    static constexpr int KS = DP / 32;                      // k-steps over d
+    static constexpr int NF = DP / 16;                      // 16-wide fragments over d
+    static constexpr int KD_BYTES = 64 * DS * 2;            // [64 keys][DS]
+    static constexpr int T_BYTES = DP * 128;                // [DP][64 keys]
+    static constexpr int KD_VEC = 64 * (DP / 8);            // 16-B vectors of a [64][DP] tile
+    static constexpr int T_VEC = DP * 8;
+};
+
+template <int DP> MM_DEV int off_kd(int row, int chunk) { return Geo<DP>::DS == 64 ? off64(row, chunk) : off128(row, chunk); }
+
+// register-staged tile movers --------------------------------------------------------------------
+template <int DP, int NV>
+MM_DEV void load_kd(u32x4 (&r)[NV], const uint16_t* base, int64_t ld, int kv0, int L, int d, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        const int row = v / (DP / 8), c = v % (DP / 8);
+        r[i] = u32x4{0u, 0u, 0u, 0u};
+        if (v < Geo<DP>::KD_VEC && c * 8 < d) r[i] = *(const u32x4*)(base + (int64_t)min(kv0 + row, L - 1) * ld + c * 8);
+    }
+}
+template <int DP, int NV>
+MM_DEV void store_kd(const u32x4 (&r)[NV], unsigned char* s, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        if (v < Geo<DP>::KD_VEC) *(u32x4*)(s + off_kd<DP>(v / (DP / 8), v % (DP / 8))) = r[i];
+    }
+}
+template <int DP, int NV>
+MM_DEV void load_t(u32x4 (&r)[NV], const uint16_t* base, int64_t Lp, int kv0, int d, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        const int row = v >> 3, c = v & 7;
+        r[i] = u32x4{0u, 0u, 0u, 0u};
+        if (v < Geo<DP>::T_VEC && row < d) r[i] = *(const u32x4*)(base + (int64_t)row * Lp + kv0 + c * 8);
+    }
+}
+template <int DP, int NV>
+MM_DEV void store_t(const u32x4 (&r)[NV], unsigned char* s, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        if (v < Geo<DP>::T_VEC) *(u32x4*)(s + off64(v >> 3, v & 7)) = r[i];
+    }
+}
+
+// A operand from a [DP][64 keys] transposed tile with the accumulator-order key permutation:
+// lane (row = f*16 + fr, fq) takes keys kk*32 + fq*4 .. +4 and kk*32 + 16 + fq*4 .. +4
+MM_DEV bf16x8 read_t_perm(const unsigned char* s, int row, int kk, int fq) {
+    const int sub = (fq & 1) * 8;
+    const bf16x4 lo = *(const bf16x4*)(s + off64(row, kk * 4 + (fq >> 1)) + sub);
+    const bf16x4 hi = *(const bf16x4*)(s + off64(row, kk * 4 + 2 + (fq >> 1)) + sub);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+MM_DEV bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
+    u32x4 w;
+    w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]); w.z = pack2bf(b[0], b[1]); w.w = pack2bf(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <int DP, int RQ>
+__global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
+    using G = Geo<DP>;
+    constexpr int KS = G::KS, NF = G::NF;
+    constexpr int NVK = (G::KD_VEC + NT - 1) / NT, NVT = (G::T_VEC + NT - 1) / NT;
+    constexpr int STAGE = G::KD_BYTES + G::T_BYTES;
+    constexpr int ROWS = RQ * 16;                           // query rows per wave
+    constexpr int BQ = 4 * ROWS;
+    constexpr int EPI = 4 * ROWS * DP * 2;                  // bf16 output staging
+    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q0 = blockIdx.x * BQ, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int d = a.d, L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    uint16_t* o_base = a.o + row_base * a.ld_o + (int64_t)hq * d;
+    float* lse_base = a.lse + ((int64_t)b * a.Hq + hq) * L;
+
+    if (q0 >= seqlen) {                                      // whole tile is padding: o = 0, lse = 0
+        for (int v = tid; v < BQ * (d >> 3); v += NT) {
+            const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
+            if (q0 + r < L) *(u32x4*)(o_base + (int64_t)(q0 + r) * a.ld_o + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int r = tid; r < BQ; r += NT)
+            if (q0 + r < L) lse_base[q0 + r] = 0.f;
+        return;
+    }
+
+    const int qw0 = q0 + wave * ROWS;                        // first query row of this wave
+    bf16x8 qf[RQ][KS];                                       // B operand: Q[q = fr][d chunk]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const uint16_t* qp = a.q + (row_base + min(qw0 + rq * 16 + fr, L - 1)) * a.ld_q + (int64_t)hq * d;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk * 32 + fq * 8;
+            qf[rq][kk] = (c < d) ? *(const bf16x8*)(qp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    f32x4 ot[RQ][NF];                                        // O^T[d = j*16 + fq*4 + r][q = fr]
+    float m_run[RQ], l_run[RQ];
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        m_run[rq] = -INFINITY; l_run[rq] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) ot[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * d;
+    const uint16_t* vtbase = a.vt + (((int64_t)b * a.Hkv + hk) * d) * a.Lp;
+    const float sl2 = a.scale * 1.4426950408889634f;         // scores in log2 domain: exp2(s*sl2 - m)
+
+    u32x4 rk[NVK], rv[NVT];
+    load_kd<DP, NVK>(rk, kbase, a.ld_k, 0, L, d, tid);
+    load_t<DP, NVT>(rv, vtbase, a.Lp, 0, d, tid);
+    store_kd<DP, NVK>(rk, smem, tid);
+    store_t<DP, NVT>(rv, smem + G::KD_BYTES, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            load_kd<DP, NVK>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid);
+            load_t<DP, NVT>(rv, vtbase, a.Lp, kv0 + 64, d, tid);
+        }
+        const unsigned char* sK = smem + cur * STAGE;
+        const unsigned char* sV = sK + G::KD_BYTES;
+        // a wave whose rows all precede this tile (causal) has nothing to do here
+        const bool active = !a.causal || kv0 <= qw0 + ROWS - 1;
+        if (active) {
+            f32x4 st[RQ][4];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                }
+            const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+                const int qg = qw0 + rq * 16 + fr;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float val = st[rq][j][r] * sl2;
+                        if (need_mask) {
+                            const int kg = kv0 + j * 16 + fq * 4 + r;
+                            if (!((kg < seqlen) && (!a.causal || kg <= qg))) val = -INFINITY;
+                        }
+                        st[rq][j][r] = val;
+                        mx = fmaxf(mx, val);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m_run[rq], mx);
+                const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m_run[rq] - mn);
+                float rs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (mn == -INFINITY) ? 0.f : exp2f(st[rq][j][r] - mn);
+                        st[rq][j][r] = p;
+                        rs += p;
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[rq] = l_run[rq] * alpha + rs;
+                m_run[rq] = mn;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 pb[RQ];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const bf16x8 va = read_t_perm(sV, j * 16 + fr, kk, fq);
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+                }
+            }
+        }
+        if (more) {
+            unsigned char* nb = smem + (cur ^ 1) * STAGE;
+            store_kd<DP, NVK>(rk, nb, tid);
+            store_t<DP, NVT>(rv, nb + G::KD_BYTES, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: O = O^T / l  -> bf16 [q][d] in LDS -> row-contiguous 16-B stores
+    unsigned char* so = smem + wave * (ROWS * DP * 2);
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qg = qw0 + rq * 16 + fr;
+        const bool valid = qg < seqlen;
+        const float inv = (valid && l_run[rq] > 0.f) ? 1.0f / l_run[rq] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            u32x2 w;
+            w.x = pack2bf(ot[rq][j][0] * inv, ot[rq][j][1] * inv);
+            w.y = pack2bf(ot[rq][j][2] * inv, ot[rq][j][3] * inv);
+            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+        }
+        if (fq == 0 && qg < L) lse_base[qg] = valid ? (m_run[rq] + log2f(l_run[rq])) * 0.6931471805599453f : 0.f;
+    }
+    __syncthreads();
+    for (int v = lane; v < ROWS * (d >> 3); v += 64) {
+        const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
+        const int qg = qw0 + r;
+        if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+// ================================================================================================
+// dQ (block owns its query rows; three MFMA groups per KV tile; no atomics)
+// ================================================================================================
+template <int DP, int RQ>
+__global__ __launch_bounds__(NT) void dq_kernel(Args a) {
+    using G = Geo<DP>;
+    constexpr int KS = G::KS, NF = G::NF;
+    constexpr int NVK = (G::KD_VEC + NT - 1) / NT, NVT = (G::T_VEC + NT - 1) / NT;
+    constexpr int STAGE = 2 * G::KD_BYTES + G::T_BYTES;     // K tile, V tile, Kt tile
+    constexpr int ROWS = RQ * 16;
+    constexpr int BQ = 4 * ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE];   // single stage (48 KiB at d=128): 3 workgroups per CU
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q0 = blockIdx.x * BQ, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int d = a.d, L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    const int64_t ld_dq = (int64_t)a.Hq * d;
+    float* dq_base = a.dq + row_base * ld_dq + (int64_t)hq * d;
+    if (q0 >= seqlen) return;                                // dq is pre-zeroed by the caller
+
+    const int qw0 = q0 + wave * ROWS;
+    bf16x8 qf[RQ][KS], dof[RQ][KS];
+    float lse_r[RQ], del_r[RQ];
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qg = min(qw0 + rq * 16 + fr, L - 1);
+        const uint16_t* qp = a.q + (row_base + qg) * a.ld_q + (int64_t)hq * d;
+        const uint16_t* dp = a.d_o + (row_base + qg) * a.ld_o + (int64_t)hq * d;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk * 32 + fq * 8;
+            qf[rq][kk] = (c < d) ? *(const bf16x8*)(qp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            dof[rq][kk] = (c < d) ? *(const bf16x8*)(dp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        lse_r[rq] = a.lse_in[((int64_t)b * a.Hq + hq) * L + qg] * 1.4426950408889634f;   // log2 domain
+        del_r[rq] = a.delta[((int64_t)b * a.Hq + hq) * L + qg];
+    }
+    f32x4 dqt[RQ][NF];                                       // dQ^T[d = j*16 + fq*4 + r][q = fr]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) dqt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * d;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * d;
+    const uint16_t* ktbase = a.kt + (((int64_t)b * a.Hkv + hk) * d) * a.Lp;
+    const float sl2 = a.scale * 1.4426950408889634f;
+
+    u32x4 rk[NVK], rv[NVK], rt[NVT];
+    load_kd<DP, NVK>(rk, kbase, a.ld_k, 0, L, d, tid);
+    load_kd<DP, NVK>(rv, vbase, a.ld_k, 0, L, d, tid);
+    load_t<DP, NVT>(rt, ktbase, a.Lp, 0, d, tid);
+    store_kd<DP, NVK>(rk, smem, tid);
+    store_kd<DP, NVK>(rv, smem + G::KD_BYTES, tid);
+    store_t<DP, NVT>(rt, smem + 2 * G::KD_BYTES, tid);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            load_kd<DP, NVK>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid);
+            load_kd<DP, NVK>(rv, vbase, a.ld_k, kv0 + 64, L, d, tid);
+            load_t<DP, NVT>(rt, ktbase, a.Lp, kv0 + 64, d, tid);
+        }
+        const unsigned char* sK = smem;
+        const unsigned char* sV = sK + G::KD_BYTES;
+        const unsigned char* sKt = sK + 2 * G::KD_BYTES;
+        const bool active = !a.causal || kv0 <= qw0 + ROWS - 1;
+        if (active) {
+            f32x4 st[RQ][4], dpt[RQ][4];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
+                    const bf16x8 vf = *(const bf16x8*)(sV + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) {
+                        st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                        dpt[rq][j] = mfma16(vf, dof[rq][kk], dpt[rq][j]);
+                    }
+                }
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+                const int qg = qw0 + rq * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kg = kv0 + j * 16 + fq * 4 + r;
+                        const bool ok = (qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg);
+                        const float p = ok ? exp2f(st[rq][j][r] * sl2 - lse_r[rq]) : 0.f;
+                        st[rq][j][r] = p * (dpt[rq][j][r] - del_r[rq]) * a.scale;      // dS^T
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 sb[RQ];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) sb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const bf16x8 ka = read_t_perm(sKt, j * 16 + fr, kk, fq);
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) dqt[rq][j] = mfma16(ka, sb[rq], dqt[rq][j]);
+                }
+            }
+        }
+        __syncthreads();                                     // every wave is done reading this tile
+        if (more) {
+            store_kd<DP, NVK>(rk, smem, tid);
+            store_kd<DP, NVK>(rv, smem + G::KD_BYTES, tid);
+            store_t<DP, NVT>(rt, smem + 2 * G::KD_BYTES, tid);
+            __syncthreads();
+        }
+    }
+    // dq[q][d] fp32: lane holds 4 consecutive d of one row -> 16-B stores
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qg = qw0 + rq * 16 + fr;
+        if (qg < seqlen) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int c = j * 16 + fq * 4;
+                if (c < d) *(f32x4*)(dq_base + (int64_t)qg * ld_dq + c) = dqt[rq][j];
+            }
+        }
+    }
+}
+
+}  // namespace attn2
+
+int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
+    using namespace attn2;
+    constexpr int RQ = 2;
+    dim3 grid((unsigned)((a.L + 4 * RQ * 16 - 1) / (4 * RQ * 16)), (unsigned)a.Hq, (unsigned)a.B);
+    switch (dp) {
+        case 64: hipLaunchKernelGGL((fwd_kernel<64, RQ>), grid, dim3(NT), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((fwd_kernel<96, RQ>), grid, dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL((fwd_kernel<128, RQ>), grid, dim3(NT), 0, s, a); break;
+    }
+    return mm_launch_status();
+}
+
+int mm355_attn2_dq_launch(const attn2::Args& a, int dp, hipStream_t s) {
+    using namespace attn2;
+    constexpr int RQ = 1;
+    dim3 grid((unsigned)((a.L + 4 * RQ * 16 - 1) / (4 * RQ * 16)), (unsigned)a.Hq, (unsigned)a.B);
+    switch (dp) {
+        case 64: hipLaunchKernelGGL((dq_kernel<64, RQ>), grid, dim3(NT), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((dq_kernel<96, RQ>), grid, dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL((dq_kernel<128, RQ>), grid, dim3(NT), 0, s, a); break;
+    }
+    return mm_launch_status();
+}

@@ -31,24 +31,25 @@ struct GemmArgs {
 
 // ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
 // so the unrolled fast path stays small.
-__device__ __attribute__((noinline)) void epi_scalar(const GemmArgs& a, int grow, int c, int64_t rr, float v0, float v1,
+// (arguments by value: taking the address of the kernel-argument struct would push it into scratch memory)
+__device__ __attribute__((noinline)) void epi_scalar(void* C, int64_t ldc, const uint16_t* bias, const uint16_t* res, int64_t ldr,
+                                                     uint32_t fl, int N, int grow, int c, int64_t rr, float v0, float v1,
                                                      float v2, float v3, float v4, float v5, float v6, float v7) {
     const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-    const uint32_t fl = a.flags;
     for (int e = 0; e < 8; ++e) {
         const int ce = c + e;
-        if (ce >= a.N) break;
+        if (ce >= N) break;
         float x = v[e];
-        if (fl & MM355_GEMM_BIAS) x += bf2f(a.bias[ce]);
+        if (fl & MM355_GEMM_BIAS) x += bf2f(bias[ce]);
         if (fl & MM355_GEMM_GELU_ERF) x = gelu_erf_f(x);
         else if (fl & MM355_GEMM_GELU_TANH) x = gelu_tanh_f(x);
-        if (fl & MM355_GEMM_RESIDUAL) x += bf2f(a.res[rr * a.ldr + ce]);
+        if (fl & MM355_GEMM_RESIDUAL) x += bf2f(res[rr * ldr + ce]);
         if (fl & MM355_GEMM_OUT_F32) {
-            float* p = (float*)a.C + (int64_t)grow * a.ldc + ce;
+            float* p = (float*)C + (int64_t)grow * ldc + ce;
             if (fl & MM355_GEMM_ACCUMULATE) x += *p;
             *p = x;
         } else {
-            uint16_t* p = (uint16_t*)a.C + (int64_t)grow * a.ldc + ce;
+            uint16_t* p = (uint16_t*)C + (int64_t)grow * ldc + ce;
             if (fl & MM355_GEMM_ACCUMULATE) x += bf2f(*p);
             *p = f2bf(x);
         }
@@ -58,7 +59,7 @@ __device__ __attribute__((noinline)) void epi_scalar(const GemmArgs& a, int grow
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
+template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     constexpr int NT = WM * WN * 64, NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -133,28 +134,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
             *(u32x4*)(sb + A_BYTES + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
         }
     };
+    // LDS-DMA sources: one row pointer per 1-KiB piece (8 rows x 128 B), computed once; the wave index is made
+    // provably uniform so that the LDS destination (M0) is scalar arithmetic, not a per-DMA v_readfirstlane.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const uint16_t* srcA[AI];
+    const uint16_t* srcB[BI];
+    {
+        const int rin = lane >> 3;                           // row inside the 8-row piece
+        const int c = (lane & 7) ^ rin;                      // source chunk that belongs in LDS slot (lane & 7)
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            srcA[i] = a.A + (int64_t)min(m0 + (i * NW + wave_s) * 8 + rin, M - 1) * a.lda + c * 8;
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            srcB[i] = a.B + (int64_t)min(n0 + (i * NW + wave_s) * 8 + rin, N - 1) * a.ldb + c * 8;
+    }
     auto gdma = [&](int kt, int buf) {
         const int k0 = kt << 6;
-        const int rin = lane >> 3;                       // row inside the 8-row piece
-        const int c = (lane & 7) ^ rin;                  // source chunk that belongs in LDS slot (lane & 7)
-        unsigned char* sb = smem + buf * STAGE;
+        unsigned char* sb = smem + buf * STAGE + wave_s * 1024;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int piece = i * NW + wave;
-            const int gr = min(m0 + piece * 8 + rin, M - 1);
-            const uint16_t* g = a.A + (int64_t)gr * a.lda + k0 + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sb + piece * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < AI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sb + i * NW * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int piece = i * NW + wave;
-            const int gr = min(n0 + piece * 8 + rin, N - 1);
-            const uint16_t* g = a.B + (int64_t)gr * a.ldb + k0 + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sb + A_BYTES + piece * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < BI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sb + A_BYTES + i * NW * 1024), 16, 0, 0);
     };
 
     // ---- main loop -----------------------------------------------------------------------------
+    if constexpr (PIPE == 0) {
     if constexpr (GLDS) {
         gdma(0, 0);
     } else {
@@ -189,6 +196,75 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         }
         __syncthreads();
         cur ^= 1;
+    }
+
+    } else {
+        // Software-pipelined schedule (LDS-DMA staging only): ONE barrier per K tile, placed in the MIDDLE of the
+        // tile's MFMAs.  Fragments are double buffered in registers (f0 = k-step 0, f1 = k-step 1), so every
+        // ds_read batch is issued in front of a 32-MFMA cluster, and the DMA of tile t+2 is in flight for a whole
+        // iteration before anybody waits for it:
+        //     read f1(t) | MFMA f0(t) | vmcnt(0)+barrier | DMA tile t+2 -> buffer of t | read f0(t+1) | MFMA f1(t)
+        static_assert(GLDS, "pipelined schedule uses LDS-DMA staging");
+        static_assert(FM % 2 == 0, "pipelined schedule splits the A fragments in two halves");
+        constexpr int HM = FM / 2;
+        // four 16-MFMA units per K tile: (k-step, A half) = (0,lo) (0,hi) (1,lo) (1,hi); two rotating A register
+        // sets X/Y and two B sets P/Q, each refilled from LDS one unit before it is consumed.
+        bf16x8 X[HM], Y[HM], P[FN], Q[FN];
+        bool kt_live = false;                            // ablation builds only: skip LDS reads once the loop runs
+        auto rdA = [&](bf16x8 (&af)[HM], int buf, int half, int sw) {
+            if constexpr (PIPE >= 3) { if (kt_live) return; }
+            const unsigned char* sb = smem + buf * STAGE + a_off + half * HM * 2048 + sw;
+#pragma unroll
+            for (int i = 0; i < HM; ++i) af[i] = *(const bf16x8*)(sb + i * 2048);
+        };
+        auto rdB = [&](bf16x8 (&bf)[FN], int buf, int sw) {
+            if constexpr (PIPE >= 3) { if (kt_live) return; }
+            const unsigned char* sb = smem + buf * STAGE + b_off + sw;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *(const bf16x8*)(sb + j * 2048);
+        };
+        auto mm = [&](const bf16x8 (&af)[HM], const bf16x8 (&bf)[FN], int half) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[half * HM + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        gdma(0, 0);
+        __syncthreads();
+        if (nk > 1) gdma(1, 1);
+        rdA(X, 0, 0, sw0);
+        rdB(P, 0, sw0);
+        if constexpr (PIPE >= 3) { rdA(Y, 0, 1, sw0); rdB(Q, 0, sw1); kt_live = true; }
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            rdA(Y, cur, 1, sw0);                              // unit 0: (k0, lo)
+            __builtin_amdgcn_sched_barrier(0);
+            mm(X, P, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(X, cur, 0, sw1);                              // unit 1: (k0, hi)
+            rdB(Q, cur, sw1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Y, P, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(Y, cur, 1, sw1);                              // unit 2: (k1, lo)
+            __builtin_amdgcn_sched_barrier(0);
+            mm(X, Q, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // tile kt+1 landed everywhere; buffer `cur` fully read
+            if constexpr (PIPE == 1 || PIPE == 3) { if (kt + 2 < nk) gdma(kt + 2, cur); }
+            if (kt + 1 < nk) {                                // unit 3: (k1, hi)
+                rdA(X, cur ^ 1, 0, sw0);
+                rdB(P, cur ^ 1, sw0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Y, Q, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur ^= 1;
+        }
+        __syncthreads();
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -260,18 +336,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
                         *(u32x4*)p = pack8(v);
                     }
                 } else {
-                    epi_scalar(a, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                    epi_scalar(a.C, a.ldc, a.bias, a.res, a.ldr, fl, N, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
+template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0>
 int launch_gemm(GemmArgs a, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = 2 * STAGE;
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS>;
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS, PIPE>;
     static bool attr_done = false;                       // idempotent one-time attribute (benign race)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -340,7 +416,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 6; }
+extern "C" int mm355_gemm_num_variants(void) { return 8; }
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -362,10 +438,10 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         // auto: LDS-DMA staging whenever K is a whole number of 64-wide tiles; the 256x256 tile once it
         // still yields at least one full wave of workgroups over the 256 CUs.
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (dma_ok) variant = (t256 >= 200) ? 6 : 2;
+        if (dma_ok) variant = (t256 >= 200) ? 7 : 2;
         else variant = 1;
     }
-    if (!dma_ok && (variant == 2 || variant == 4 || variant == 6)) return MM355_EUNSUPPORTED;
+    if (!dma_ok && (variant == 2 || variant == 4 || variant >= 6)) return MM355_EUNSUPPORTED;
     switch (variant) {
         case 1: return launch_gemm<128, 128, 2, 2, false>(a, s);
         case 2: return launch_gemm<128, 128, 2, 2, true>(a, s);
@@ -373,6 +449,11 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 4: return launch_gemm<256, 128, 4, 2, true>(a, s);
         case 5: return launch_gemm<256, 256, 2, 4, false>(a, s);
         case 6: return launch_gemm<256, 256, 2, 4, true>(a, s);
+        case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
+        case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
+        case 92: return launch_gemm<256, 256, 2, 4, true, 2>(a, s);   // ablations (wrong results, timing only)
+        case 93: return launch_gemm<256, 256, 2, 4, true, 3>(a, s);
+        case 94: return launch_gemm<256, 256, 2, 4, true, 4>(a, s);
         default: return MM355_EUNSUPPORTED;
     }
 }
