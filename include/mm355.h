@@ -63,6 +63,14 @@ int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64
                     uint32_t flags, int variant, void* stream);
 int mm355_gemm_num_variants(void);
 
+/* Weight-gradient form on the operands AS THEY LIE IN MEMORY (no transposed copies):
+ *   C[M,N] (+)= At[K,M]^T . Bt[K,N]      e.g. dW[out,in] = dY[tokens,out]^T . X[tokens,in]
+ * MFMA fragments are gathered from contraction-major LDS tiles with ds_read_b64_tr_b16.
+ * Requirements: K % 64 == 0 (else MM355_EUNSUPPORTED: use mm355_transpose_bf16 + mm355_gemm_bf16), M, N, lda, ldb % 8 == 0.
+ * flags: MM355_GEMM_ACCUMULATE, MM355_GEMM_OUT_F32. */
+int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, uint32_t flags, void* stream);
+
 /* out[c][r] = in[r][c]   (rows x cols -> cols x rows), bf16.  Used for the backward GEMM operands. */
 int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols,
                          mm355_bf16* out, int64_t ld_out, void* stream);
@@ -120,14 +128,16 @@ int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o
                         mm355_bf16* dot, int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t d, void* stream);
 
 /* Backward.  qt/kt/dot are per-head transposes [B][H][d][Lp]; dq_f32 [B*L][Hq*d] must be zeroed by the
- * caller (accumulated with atomics); dk/dv written as column blocks with leading dimension ld_dkv. */
+ * caller; dk/dv written as column blocks with leading dimension ld_dkv.
+ * workspace: NULL, or 2*B*L*Hq*d floats of scratch; with GQA (Hq > Hkv) it lets the dK/dV kernel run one
+ * workgroup per (KV tile, query head) and sum the group afterwards (better balance under causal masking). */
 int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
                    const mm355_bf16* d_o, int64_t ld_o,
                    const mm355_bf16* qt, const mm355_bf16* kt, const mm355_bf16* dot,
                    const float* lse, const float* delta, const int32_t* seqlens,
                    float* dq_f32, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
                    int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d,
-                   float scale, int causal, void* stream);
+                   float scale, int causal, float* workspace, void* stream);
 
 /* dq_f32 [M][Hq*d] -> bf16 into the q column block of dqkv (optionally through the inverse RoPE);
  * used after mm355_attn_bwd.  cos_t/sin_t NULL = plain cast. */

@@ -17,6 +17,7 @@
 #include "mm355_common.h"
 #include "attn2.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace {
 
@@ -266,6 +267,7 @@ struct BwdArgs {
     const uint16_t* qt; const uint16_t* kt; const uint16_t* dot;
     const float* lse; const float* delta; const int32_t* seqlens;
     float* dq; uint16_t* dk; uint16_t* dv;
+    float* dkp; float* dvp;          // optional fp32 per-QUERY-head partials [B*L][Hq*d]: grid.y = Hq, summed afterwards
     int64_t ld_q, ld_k, ld_o, ld_dkv;
     int B, L, Lp, Hq, Hkv, d;
     float scale; int causal;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     constexpr int KT_BYTES = DP * 128;                      // Kt tile [DP][64 keys]
     constexpr int DS_BYTES = 32 * 128;                      // dS tile [32 q][64 keys] bf16
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QD_BYTES + 2 * T_BYTES + KT_BYTES + DS_BYTES];
+    __shared__ __attribute__((aligned(16))) float sStat[64];   // lse[32] | delta[32] of the current query tile
     unsigned char* sQ = smem;
     unsigned char* sDO = sQ + QD_BYTES;
     unsigned char* sQt = sDO + QD_BYTES;
@@ -290,10 +293,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int kv0 = blockIdx.x * 64, hk = blockIdx.y, b = blockIdx.z;
+    const int group = a.Hq / a.Hkv;
+    const bool per_qhead = a.dkp != nullptr;
+    const int kv0 = blockIdx.x * 64, hk = per_qhead ? (int)blockIdx.y / group : (int)blockIdx.y, b = blockIdx.z;
     const int d = a.d, L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
-    const int group = a.Hq / a.Hkv;
     const int64_t row_base = (int64_t)b * L;
     const int mykey0 = kv0 + wave * 16;                      // this wave's 16 keys
 
@@ -304,8 +308,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
         for (int v = tid; v < 64 * (d >> 3); v += NT) {
             const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
             if (kv0 + r < L) {
-                *(u32x4*)(dk_base + (int64_t)(kv0 + r) * a.ld_dkv + c) = u32x4{0u, 0u, 0u, 0u};
-                *(u32x4*)(dv_base + (int64_t)(kv0 + r) * a.ld_dkv + c) = u32x4{0u, 0u, 0u, 0u};
+                if (per_qhead) {
+                    const int64_t o = (row_base + kv0 + r) * ((int64_t)a.Hq * d) + (int64_t)blockIdx.y * d + c;
+                    *(f32x4*)(a.dkp + o) = f32x4{0.f, 0.f, 0.f, 0.f}; *(f32x4*)(a.dkp + o + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *(f32x4*)(a.dvp + o) = f32x4{0.f, 0.f, 0.f, 0.f}; *(f32x4*)(a.dvp + o + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    *(u32x4*)(dk_base + (int64_t)(kv0 + r) * a.ld_dkv + c) = u32x4{0u, 0u, 0u, 0u};
+                    *(u32x4*)(dv_base + (int64_t)(kv0 + r) * a.ld_dkv + c) = u32x4{0u, 0u, 0u, 0u};
+                }
             }
         }
         return;
@@ -342,43 +352,76 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
     const int q_start = a.causal ? (kv0 & ~31) : 0;          // first 32-row query tile that can see this KV tile
     const int q_stop = seqlen;                               // padded query rows carry zero gradient
 
-    for (int g = 0; g < group; ++g) {
-        const int hq = hk * group + g;
+    const int g_lo = per_qhead ? (int)blockIdx.y % group : 0, g_hi = per_qhead ? g_lo + 1 : group;
+    // flattened (query head, 32-row query tile) iteration space with register-staged prefetch: the global loads of
+    // iteration it+1 are in flight while iteration it computes (T14: issue early, write LDS late)
+    const int ntq = q_stop > q_start ? (q_stop - q_start + 31) / 32 : 0;
+    const int n_it = (g_hi - g_lo) * ntq;
+    constexpr int NVQ = (32 * (DP / 8) + NT - 1) / NT, NVT2 = (DP * 4 + NT - 1) / NT;
+    u32x4 pq[NVQ], pdo[NVQ], pqt[NVT2], pdot[NVT2];
+    float pstat = 0.f;
+    auto fetch = [&](int it) {
+        const int hq = hk * group + g_lo + it / ntq;
+        const int qt0 = q_start + (it % ntq) * 32;
         const uint16_t* qb = a.q + row_base * a.ld_q + (int64_t)hq * d;
         const uint16_t* dob = a.d_o + row_base * a.ld_o + (int64_t)hq * d;
         const uint16_t* qtb = a.qt + (((int64_t)b * a.Hq + hq) * d) * a.Lp;
         const uint16_t* dotb = a.dot + (((int64_t)b * a.Hq + hq) * d) * a.Lp;
-        const float* lse_b = a.lse + ((int64_t)b * a.Hq + hq) * L;
-        const float* del_b = a.delta + ((int64_t)b * a.Hq + hq) * L;
-        float* dq_b = a.dq + row_base * ((int64_t)a.Hq * d) + (int64_t)hq * d;
-
-        for (int qt0 = q_start; qt0 < q_stop; qt0 += 32) {
-            __syncthreads();                                 // previous iteration's LDS reads done
-            // Q and dO tiles [32][DP]
-            for (int v = tid; v < 32 * (DP / 8); v += NT) {
-                const int r = v / (DP / 8), c = v % (DP / 8);
+#pragma unroll
+        for (int i = 0; i < NVQ; ++i) {
+            const int v = tid + i * NT, r = v / (DP / 8), c = v % (DP / 8);
+            pq[i] = u32x4{0u, 0u, 0u, 0u}; pdo[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < 32 * (DP / 8) && c * 8 < d) {
                 const int qrow = min(qt0 + r, L - 1);
-                u32x4 x = u32x4{0u, 0u, 0u, 0u}, y = u32x4{0u, 0u, 0u, 0u};
-                if (c * 8 < d) {
-                    x = *(const u32x4*)(qb + (int64_t)qrow * a.ld_q + c * 8);
-                    y = *(const u32x4*)(dob + (int64_t)qrow * a.ld_o + c * 8);
-                }
-                *(u32x4*)(sQ + lds_off<DS>(r, c)) = x;
-                *(u32x4*)(sDO + lds_off<DS>(r, c)) = y;
+                pq[i] = *(const u32x4*)(qb + (int64_t)qrow * a.ld_q + c * 8);
+                pdo[i] = *(const u32x4*)(dob + (int64_t)qrow * a.ld_o + c * 8);
             }
-            // Qt and dOt tiles [DP][32 q] : 64-B rows = 4 chunks, chunk XOR (row & 3)
-            for (int v = tid; v < DP * 4; v += NT) {
-                const int r = v >> 2, c = v & 3;
-                u32x4 x = u32x4{0u, 0u, 0u, 0u}, y = u32x4{0u, 0u, 0u, 0u};
-                if (r < d) {
-                    x = *(const u32x4*)(qtb + (int64_t)r * a.Lp + qt0 + c * 8);
-                    y = *(const u32x4*)(dotb + (int64_t)r * a.Lp + qt0 + c * 8);
-                }
-                const int off = r * 64 + ((c ^ (r & 3)) << 4);
-                *(u32x4*)(sQt + off) = x;
-                *(u32x4*)(sDOt + off) = y;
+        }
+#pragma unroll
+        for (int i = 0; i < NVT2; ++i) {
+            const int v = tid + i * NT, r = v >> 2, c = v & 3;
+            pqt[i] = u32x4{0u, 0u, 0u, 0u}; pdot[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < DP * 4 && r < d) {
+                pqt[i] = *(const u32x4*)(qtb + (int64_t)r * a.Lp + qt0 + c * 8);
+                pdot[i] = *(const u32x4*)(dotb + (int64_t)r * a.Lp + qt0 + c * 8);
             }
+        }
+        if (tid < 64) {
+            const int qrow = min(qt0 + (tid & 31), L - 1);
+            pstat = (tid < 32) ? a.lse[((int64_t)b * a.Hq + hq) * L + qrow] : a.delta[((int64_t)b * a.Hq + hq) * L + qrow];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVQ; ++i) {
+            const int v = tid + i * NT, r = v / (DP / 8), c = v % (DP / 8);
+            if (v < 32 * (DP / 8)) {
+                *(u32x4*)(sQ + lds_off<DS>(r, c)) = pq[i];
+                *(u32x4*)(sDO + lds_off<DS>(r, c)) = pdo[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVT2; ++i) {
+            const int v = tid + i * NT, r = v >> 2, c = v & 3;
+            if (v < DP * 4) {
+                const int off = r * 64 + ((c ^ ((r >> 2) & 3)) << 4);   // rows r, r+4, r+8, r+12 share a bank window
+                *(u32x4*)(sQt + off) = pqt[i];
+                *(u32x4*)(sDOt + off) = pdot[i];
+            }
+        }
+        if (tid < 64) sStat[tid] = pstat;
+    };
+    if (n_it > 0) fetch(0);
+    for (int it = 0; it < n_it; ++it) {
+        {
+            const int hq = hk * group + g_lo + it / ntq;
+            const int qt0 = q_start + (it % ntq) * 32;
+            float* dq_b = a.dq + row_base * ((int64_t)a.Hq * d) + (int64_t)hq * d;
+            (void)dq_b;
+            __syncthreads();                                 // previous iteration's LDS reads done
+            commit();
             __syncthreads();
+            if (it + 1 < n_it) fetch(it + 1);
 
             // S[i] / dP[i] for the two 16-row halves i: lane holds X[q = i*16 + fq*4 + r][key = fr]
             f32x4 s[2], dp[2];
@@ -396,6 +439,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             }
             // P = exp(S*scale - lse), dS = P * (dP - delta) * scale ; masked entries -> 0
             const int kg = mykey0 + fr;
+            f32x4 lse4[2], del4[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                lse4[i] = *(const f32x4*)(sStat + i * 16 + fq * 4);
+                del4[i] = *(const f32x4*)(sStat + 32 + i * 16 + fq * 4);
+            }
             uint16_t pbits[2][4], dsbits[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -405,8 +454,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
                     const bool ok = (qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg);
                     float p = 0.f, dsv = 0.f;
                     if (ok) {
-                        p = __expf(s[i][r] * a.scale - lse_b[qg]);
-                        dsv = p * (dp[i][r] - del_b[qg]) * a.scale;
+                        p = __expf(s[i][r] * a.scale - lse4[i][r]);
+                        dsv = p * (dp[i][r] - del4[i][r]) * a.scale;
                     }
                     pbits[i][r] = f2bf(p);
                     dsbits[i][r] = f2bf(dsv);
@@ -424,8 +473,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
                 const int row = j * 16 + fr;
                 const int c0 = (fq >> 1), c1 = 2 + (fq >> 1);   // 16-B chunk holding q = fq*4 (resp. 16 + fq*4)
                 const int sub = (fq & 1) * 8;                    // byte offset of the 4-element half inside the chunk
-                const int o0 = row * 64 + ((c0 ^ (row & 3)) << 4) + sub;
-                const int o1 = row * 64 + ((c1 ^ (row & 3)) << 4) + sub;
+                const int o0 = row * 64 + ((c0 ^ ((row >> 2) & 3)) << 4) + sub;
+                const int o1 = row * 64 + ((c1 ^ ((row >> 2) & 3)) << 4) + sub;
                 const bf16x4 d0 = *(const bf16x4*)(sDOt + o0), d1 = *(const bf16x4*)(sDOt + o1);
                 const bf16x4 q0v = *(const bf16x4*)(sQt + o0), q1v = *(const bf16x4*)(sQt + o1);
                 const bf16x8 dob8 = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
@@ -490,10 +539,34 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(BwdArgs a) {
             const int key = mykey0 + r;
             if (key < L) {
                 const f32x4 x0 = *(const f32x4*)(so + r * DP + c), x1 = *(const f32x4*)(so + r * DP + c + 4);
-                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                *(u32x4*)(ob + (int64_t)key * a.ld_dkv + c) = pack8(f);
+                if (per_qhead) {
+                    float* pp = (pass ? a.dvp : a.dkp) + (row_base + key) * ((int64_t)a.Hq * d) + (int64_t)blockIdx.y * d + c;
+                    *(f32x4*)pp = x0; *(f32x4*)(pp + 4) = x1;
+                } else {
+                    const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    *(u32x4*)(ob + (int64_t)key * a.ld_dkv + c) = pack8(f);
+                }
             }
         }
+    }
+}
+
+// dk[m][hk*d + c] = sum over the GQA group of the per-query-head fp32 partials
+__global__ __launch_bounds__(NT) void group_reduce_kernel(const float* __restrict__ part, uint16_t* __restrict__ out, int64_t ld_out, int64_t rows,
+                                                          int Hq, int Hkv, int d) {
+    const int group = Hq / Hkv, cv = (Hkv * d) >> 3;
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int64_t r = i / cv; const int c = (int)(i % cv) * 8;
+        const int hk = c / d, cc = c % d;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < group; ++g) {
+            const float* p = part + r * ((int64_t)Hq * d) + (int64_t)(hk * group + g) * d + cc;
+            const f32x4 x0 = *(const f32x4*)p, x1 = *(const f32x4*)(p + 4);
+            acc[0] += x0.x; acc[1] += x0.y; acc[2] += x0.z; acc[3] += x0.w;
+            acc[4] += x1.x; acc[5] += x1.y; acc[6] += x1.z; acc[7] += x1.w;
+        }
+        *(u32x4*)(out + r * ld_out + c) = pack8(acc);
     }
 }
 
@@ -541,24 +614,41 @@ extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, i
 extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
                               int64_t ld_o, const mm355_bf16* qt, const mm355_bf16* kt, const mm355_bf16* dot, const float* lse,
                               const float* delta, const int32_t* seqlens, float* dq_f32, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
-                              int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, void* stream) {
+                              int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
+                              float* workspace, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !d_o || !qt || !kt || !dot || !lse || !delta || !dq_f32 || !dk || !dv) return MM355_EINVAL;
     if (B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
-    BwdArgs a{q, k, v, d_o, qt, kt, dot, lse, delta, seqlens, dq_f32, dk, dv, ld_q, ld_k, ld_o, ld_dkv,
+    BwdArgs a{q, k, v, d_o, qt, kt, dot, lse, delta, seqlens, dq_f32, dk, dv, nullptr, nullptr, ld_q, ld_k, ld_o, ld_dkv,
               (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)Hkv, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     if (!use_v1()) {
-        // dK/dV: KV-tile-owning kernel without the dQ part; dQ: query-tile-owning kernel (no atomics)
+        // dK/dV: KV-tile-owning kernel without the dQ part; dQ: query-tile-owning kernel (no atomics).
+        // With GQA and a workspace the dK/dV kernel runs one workgroup per (KV tile, QUERY head) -- group x more,
+        // better balanced workgroups -- writing fp32 partials that a small kernel sums over the group.
+        dim3 g2 = grid;
+        if (workspace && Hq != Hkv) {
+            a.dkp = workspace;
+            a.dvp = workspace + (int64_t)B * L * Hq * d;
+            g2 = dim3((unsigned)((L + 63) / 64), (unsigned)Hq, (unsigned)B);
+        }
         switch (pick_dp(d)) {
-            case 64: hipLaunchKernelGGL((attn_bwd_kernel<64, false>), grid, dim3(NT), 0, s, a); break;
-            case 96: hipLaunchKernelGGL((attn_bwd_kernel<96, false>), grid, dim3(NT), 0, s, a); break;
-            default: hipLaunchKernelGGL((attn_bwd_kernel<128, false>), grid, dim3(NT), 0, s, a); break;
+            case 64: hipLaunchKernelGGL((attn_bwd_kernel<64, false>), g2, dim3(NT), 0, s, a); break;
+            case 96: hipLaunchKernelGGL((attn_bwd_kernel<96, false>), g2, dim3(NT), 0, s, a); break;
+            default: hipLaunchKernelGGL((attn_bwd_kernel<128, false>), g2, dim3(NT), 0, s, a); break;
         }
         int rc = mm_launch_status();
         if (rc != MM355_OK) return rc;
+        if (a.dkp) {
+            const int64_t rows = B * L;
+            const unsigned rg = (unsigned)std::min<int64_t>((rows * (Hkv * d / 8) + NT - 1) / NT, 4096);
+            hipLaunchKernelGGL(group_reduce_kernel, dim3(rg), dim3(NT), 0, s, a.dkp, dk, ld_dkv, rows, (int)Hq, (int)Hkv, (int)d);
+            hipLaunchKernelGGL(group_reduce_kernel, dim3(rg), dim3(NT), 0, s, a.dvp, dv, ld_dkv, rows, (int)Hq, (int)Hkv, (int)d);
+            rc = mm_launch_status();
+            if (rc != MM355_OK) return rc;
+        }
         attn2::Args a2{q, k, v, nullptr, kt, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq_f32, seqlens,
                        (int)B, (int)L, (int)Lp, (int)Hq, (int)Hkv, (int)d, scale, causal};
         return mm355_attn2_dq_launch(a2, pick_dp(d), s);

@@ -14,6 +14,7 @@
 // Workgroup = 4 waves, each wave owns RQ*16 query rows.  Replaces torch SDPA as driven by HF LlamaModel /
 // SiglipAttention (reference call sites metamorph_llama.py:349-359, siglip_encoder.py:141).
 #include "attn2.h"
+#include <cstdlib>
 
 namespace attn2 {
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
     constexpr int ROWS = RQ * 16;                           // query rows per wave
     constexpr int BQ = 4 * ROWS;
     constexpr int EPI = 4 * ROWS * DP * 2;                  // bf16 output staging
-    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr int SMEM = STAGE > EPI ? STAGE : EPI;          // single stage: tile t+1 waits in registers while tile t is consumed
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
     store_kd<DP, NVK>(rk, smem, tid);
     store_t<DP, NVT>(rv, smem + G::KD_BYTES, tid);
     __syncthreads();
-    int cur = 0;
+    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         const bool more = t + 1 < ntiles;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
             load_kd<DP, NVK>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid);
             load_t<DP, NVT>(rv, vtbase, a.Lp, kv0 + 64, d, tid);
         }
-        const unsigned char* sK = smem + cur * STAGE;
+        const unsigned char* sK = smem;
         const unsigned char* sV = sK + G::KD_BYTES;
         // a wave whose rows all precede this tile (causal) has nothing to do here
         const bool active = !a.causal || kv0 <= qw0 + ROWS - 1;
@@ -189,38 +190,47 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) {
                 const int qg = qw0 + rq * 16 + fr;
-                float mx = -INFINITY;
+                if (need_mask) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kg = kv0 + j * 16 + fq * 4 + r;
+                            if (!((kg < seqlen) && (!a.causal || kg <= qg))) st[rq][j][r] = -INFINITY;
+                        }
+                }
+                float mx = -INFINITY;                         // max of the RAW scores (scale > 0 commutes with max)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float val = st[rq][j][r] * sl2;
-                        if (need_mask) {
-                            const int kg = kv0 + j * 16 + fq * 4 + r;
-                            if (!((kg < seqlen) && (!a.causal || kg <= qg))) val = -INFINITY;
-                        }
-                        st[rq][j][r] = val;
-                        mx = fmaxf(mx, val);
-                    }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rq][j][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mn = fmaxf(m_run[rq], mx);
-                const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m_run[rq] - mn);
+                mx *= sl2;
+                // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew
+                // by more than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR, exact in fp32/bf16 range)
+                const bool grow = mx > m_run[rq] + RESCALE_THR || m_run[rq] == -INFINITY;
+                if (__any(grow && mx > -INFINITY)) {
+                    const float mn = fmaxf(m_run[rq], mx);
+                    const float alpha = (m_run[rq] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[rq] - mn);
+                    l_run[rq] *= alpha;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+                    m_run[rq] = mn;
+                }
+                const float mref = m_run[rq];
                 float rs = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = (mn == -INFINITY) ? 0.f : exp2f(st[rq][j][r] - mn);
+                        const float p = (mref == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
                         st[rq][j][r] = p;
                         rs += p;
                     }
                 rs += __shfl_xor(rs, 16, 64);
                 rs += __shfl_xor(rs, 32, 64);
-                l_run[rq] = l_run[rq] * alpha + rs;
-                m_run[rq] = mn;
-#pragma unroll
-                for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+                l_run[rq] += rs;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -235,13 +245,12 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
                 }
             }
         }
+        __syncthreads();                                     // every wave is done reading this tile
         if (more) {
-            unsigned char* nb = smem + (cur ^ 1) * STAGE;
-            store_kd<DP, NVK>(rk, nb, tid);
-            store_t<DP, NVT>(rv, nb + G::KD_BYTES, tid);
+            store_kd<DP, NVK>(rk, smem, tid);
+            store_t<DP, NVT>(rv, smem + G::KD_BYTES, tid);
+            __syncthreads();
         }
-        __syncthreads();
-        cur ^= 1;
     }
 
     // epilogue: O = O^T / l  -> bf16 [q][d] in LDS -> row-contiguous 16-B stores
@@ -410,9 +419,9 @@ __global__ __launch_bounds__(NT) void dq_kernel(Args a) {
 
 }  // namespace attn2
 
-int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
+template <int RQ>
+static int fwd_launch_rq(const attn2::Args& a, int dp, hipStream_t s) {
     using namespace attn2;
-    constexpr int RQ = 2;
     dim3 grid((unsigned)((a.L + 4 * RQ * 16 - 1) / (4 * RQ * 16)), (unsigned)a.Hq, (unsigned)a.B);
     switch (dp) {
         case 64: hipLaunchKernelGGL((fwd_kernel<64, RQ>), grid, dim3(NT), 0, s, a); break;
@@ -420,6 +429,12 @@ int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
         default: hipLaunchKernelGGL((fwd_kernel<128, RQ>), grid, dim3(NT), 0, s, a); break;
     }
     return mm_launch_status();
+}
+
+int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
+    const char* e = std::getenv("MM355_ATTN_RQ");           // A/B knob: query row-fragments per wave
+    if (e && e[0] == '2') return fwd_launch_rq<2>(a, dp, s);
+    return fwd_launch_rq<1>(a, dp, s);
 }
 
 int mm355_attn2_dq_launch(const attn2::Args& a, int dp, hipStream_t s) {

@@ -59,7 +59,10 @@ __device__ __attribute__((noinline)) void epi_scalar(void* C, int64_t ldc, const
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0>
+// TNL = true: both operands are stored contraction-major ("TN": A = At[K][M], B = Bt[K][N], C = At^T Bt), which is the
+// weight-gradient form dW = dY^T X on the activations as they lie in memory -- no transposed copies.  LDS tiles are then
+// [64 k][256] with the MFMA fragments gathered by ds_read_b64_tr_b16 (hardware 4x16 transpose read).
+template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0, bool TNL = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     constexpr int NT = WM * WN * 64, NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const uint16_t* srcA[AI];
     const uint16_t* srcB[BI];
-    {
+    if constexpr (!TNL) {
         const int rin = lane >> 3;                           // row inside the 8-row piece
         const int c = (lane & 7) ^ rin;                      // source chunk that belongs in LDS slot (lane & 7)
 #pragma unroll
@@ -148,16 +151,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < BI; ++i)
             srcB[i] = a.B + (int64_t)min(n0 + (i * NW + wave_s) * 8 + rin, N - 1) * a.ldb + c * 8;
+    } else {
+        // [64 k][256 cols] tiles, 512-B rows: a 1-KiB piece is 2 k-rows; physical 16-B chunk = logical ^ f(row) with
+        // f(row) = 2*(row & 3) + 8*((row >> 3) & 1) so that the 8 rows x 2 chunks of one tr-read half-wave hit 16 distinct slots
+        static_assert(!TNL || (BM == 256 && BN == 256), "TN layout: 256x256 tile only");
+        const int rinT = lane >> 5, pcT = lane & 31;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = (i * NW + wave_s) * 2 + rinT;
+            const int c = pcT ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
+            srcA[i] = a.A + (int64_t)row * a.lda + min(m0 + c * 8, M - 8);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int row = (i * NW + wave_s) * 2 + rinT;
+            const int c = pcT ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
+            srcB[i] = a.B + (int64_t)row * a.ldb + min(n0 + c * 8, N - 8);
+        }
     }
     auto gdma = [&](int kt, int buf) {
         const int k0 = kt << 6;
+        const int64_t ka = TNL ? (int64_t)k0 * a.lda : (int64_t)k0, kb = TNL ? (int64_t)k0 * a.ldb : (int64_t)k0;
         unsigned char* sb = smem + buf * STAGE + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sb + i * NW * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + ka), (lptr_t)(sb + i * NW * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sb + A_BYTES + i * NW * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kb), (lptr_t)(sb + A_BYTES + i * NW * 1024), 16, 0, 0);
     };
 
     // ---- main loop -----------------------------------------------------------------------------
@@ -211,17 +232,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         // sets X/Y and two B sets P/Q, each refilled from LDS one unit before it is consumed.
         bf16x8 X[HM], Y[HM], P[FN], Q[FN];
         bool kt_live = false;                            // ablation builds only: skip LDS reads once the loop runs
-        auto rdA = [&](bf16x8 (&af)[HM], int buf, int half, int sw) {
-            if constexpr (PIPE >= 3) { if (kt_live) return; }
-            const unsigned char* sb = smem + buf * STAGE + a_off + half * HM * 2048 + sw;
+        // TN layout: per-lane byte offsets of the 8-byte transposed-read granules (excluding the k-step immediate)
+        int toA[TNL ? FM : 1], toB[TNL ? FN : 1];
+        if constexpr (TNL) {
+            const int j4 = fr >> 2, q = fr & 3, f = 2 * j4 + 8 * (fq & 1);
 #pragma unroll
-            for (int i = 0; i < HM; ++i) af[i] = *(const bf16x8*)(sb + i * 2048);
+            for (int i = 0; i < FM; ++i)
+                toA[i] = (fq * 8 + j4) * 512 + ((((wm * TM) >> 3) + i * 2 + (q >> 1)) ^ f) * 16 + (q & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                toB[j] = A_BYTES + (fq * 8 + j4) * 512 + ((((wn * TN) >> 3) + j * 2 + (q >> 1)) ^ f) * 16 + (q & 1) * 8;
+        }
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds4_t;
+        auto trfrag = [&](const unsigned char* p) -> bf16x8 {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)p);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p + 4 * 512));
+            return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
-        auto rdB = [&](bf16x8 (&bf)[FN], int buf, int sw) {
-            if constexpr (PIPE >= 3) { if (kt_live) return; }
-            const unsigned char* sb = smem + buf * STAGE + b_off + sw;
+        auto rdA = [&](bf16x8 (&af)[HM], int buf, int half, int kk) {
+            const int sw = kk ? sw1 : sw0;
+            if constexpr (PIPE == 3 || PIPE == 4) { if (kt_live) return; }
+            if constexpr (TNL) {
+                const unsigned char* sb = smem + buf * STAGE + kk * 32 * 512;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *(const bf16x8*)(sb + j * 2048);
+                for (int i = 0; i < HM; ++i) af[i] = trfrag(sb + toA[half * HM + i]);
+            } else {
+                const unsigned char* sb = smem + buf * STAGE + a_off + half * HM * 2048 + sw;
+#pragma unroll
+                for (int i = 0; i < HM; ++i) af[i] = *(const bf16x8*)(sb + i * 2048);
+            }
+        };
+        auto rdB = [&](bf16x8 (&bf)[FN], int buf, int kk) {
+            const int sw = kk ? sw1 : sw0;
+            if constexpr (PIPE == 3 || PIPE == 4) { if (kt_live) return; }
+            if constexpr (TNL) {
+                const unsigned char* sb = smem + buf * STAGE + kk * 32 * 512;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[j] = trfrag(sb + toB[j]);
+            } else {
+                const unsigned char* sb = smem + buf * STAGE + b_off + sw;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[j] = *(const bf16x8*)(sb + j * 2048);
+            }
         };
         auto mm = [&](const bf16x8 (&af)[HM], const bf16x8 (&bf)[FN], int half) {
             __builtin_amdgcn_s_setprio(1);
@@ -232,32 +285,53 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
                     acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[half * HM + i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
+        // L2 warm-up stream (PIPE == 5): one 4-byte LDS-DMA per lane into a scratch slab touches every 128-B line of
+        // a future tile (thread i -> row i of A for i < BM, row i-BM of B) two barriers before its real DMA is issued,
+        // so that the real DMA finds its lines in L2 and completes inside its one-tile window.
+        const uint16_t* tsrc = (tid < BM) ? a.A + (int64_t)min(m0 + tid, M - 1) * a.lda
+                                          : a.B + (int64_t)min(n0 + (tid - BM), N - 1) * a.ldb;
+        auto touch = [&](int kt) {
+            if constexpr (PIPE == 5) {
+                const int kc = min(kt, nk - 1) << 6;          // clamp: always exactly one touch per iteration (vmcnt bookkeeping)
+                __builtin_amdgcn_global_load_lds((gptr_t)(tsrc + kc), (lptr_t)(smem + 2 * STAGE + wave_s * 256), 4, 0, 0);
+            }
+        };
         gdma(0, 0);
         __syncthreads();
         if (nk > 1) gdma(1, 1);
-        rdA(X, 0, 0, sw0);
-        rdB(P, 0, sw0);
-        if constexpr (PIPE >= 3) { rdA(Y, 0, 1, sw0); rdB(Q, 0, sw1); kt_live = true; }
+        touch(2);
+        rdA(X, 0, 0, 0);
+        rdB(P, 0, 0);
+        if constexpr (PIPE == 3 || PIPE == 4) { rdA(Y, 0, 1, 0); rdB(Q, 0, 1); kt_live = true; }
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            rdA(Y, cur, 1, sw0);                              // unit 0: (k0, lo)
+            rdA(Y, cur, 1, 0);                              // unit 0: (k0, lo)
             __builtin_amdgcn_sched_barrier(0);
             mm(X, P, 0);
             __builtin_amdgcn_sched_barrier(0);
-            rdA(X, cur, 0, sw1);                              // unit 1: (k0, hi)
-            rdB(Q, cur, sw1);
+            rdA(X, cur, 0, 1);                              // unit 1: (k0, hi)
+            rdB(Q, cur, 1);
             __builtin_amdgcn_sched_barrier(0);
             mm(Y, P, 1);
             __builtin_amdgcn_sched_barrier(0);
-            rdA(Y, cur, 1, sw1);                              // unit 2: (k1, lo)
+            rdA(Y, cur, 1, 1);                              // unit 2: (k1, lo)
             __builtin_amdgcn_sched_barrier(0);
             mm(X, Q, 0);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                 // tile kt+1 landed everywhere; buffer `cur` fully read
-            if constexpr (PIPE == 1 || PIPE == 3) { if (kt + 2 < nk) gdma(kt + 2, cur); }
+            if constexpr (PIPE == 5) {
+                // counted wait: everything but the newest VMEM op (the L2 touch of tile kt+3, issued after the DMAs of
+                // tile kt+1... kt+2) must have landed; raw barrier so the compiler does not drain the touch as well
+                asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 2 < nk) gdma(kt + 2, cur);
+                touch(kt + 3);
+            } else {
+                __syncthreads();                             // tile kt+1 landed everywhere; buffer `cur` fully read
+                if constexpr (PIPE == 1 || PIPE == 3) { if (kt + 2 < nk) gdma(kt + 2, cur); }
+            }
             if (kt + 1 < nk) {                                // unit 3: (k1, hi)
-                rdA(X, cur ^ 1, 0, sw0);
-                rdB(P, cur ^ 1, sw0);
+                rdA(X, cur ^ 1, 0, 0);
+                rdB(P, cur ^ 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             mm(Y, Q, 1);
@@ -343,11 +417,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0>
+template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0, bool TNL = false>
 int launch_gemm(GemmArgs a, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int LDS = 2 * STAGE;
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS, PIPE>;
+    constexpr int LDS = 2 * STAGE + (PIPE == 5 ? WM * WN * 256 : 0);
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS, PIPE, TNL>;
     static bool attr_done = false;                       // idempotent one-time attribute (benign race)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -416,7 +490,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 8; }
+extern "C" int mm355_gemm_num_variants(void) { return 9; }
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -451,11 +525,27 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 6: return launch_gemm<256, 256, 2, 4, true>(a, s);
         case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
+        case 9: return launch_gemm<256, 256, 2, 4, true, 5>(a, s);
         case 92: return launch_gemm<256, 256, 2, 4, true, 2>(a, s);   // ablations (wrong results, timing only)
         case 93: return launch_gemm<256, 256, 2, 4, true, 3>(a, s);
         case 94: return launch_gemm<256, 256, 2, 4, true, 4>(a, s);
         default: return MM355_EUNSUPPORTED;
     }
+}
+
+extern "C" int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                  int64_t N, int64_t K, uint32_t flags, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!At || !Bt || !C || M < 8 || N < 8 || K <= 0) return MM355_EINVAL;
+    if ((M & 7) || (N & 7) || (lda & 7) || (ldb & 7) || !mm_aligned16(At) || !mm_aligned16(Bt) || !mm_aligned16(C)) return MM355_EINVAL;
+    if (K % 64) return MM355_EUNSUPPORTED;                  // contraction rows are DMA'd unmasked: whole 64-row tiles only
+    if (flags & ~(MM355_GEMM_ACCUMULATE | MM355_GEMM_OUT_F32)) return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemmArgs a;
+    a.A = At; a.B = Bt; a.C = C; a.bias = nullptr; a.res = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = 0; a.res_mod = 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
+    return launch_gemm<256, 256, 2, 4, true, 1, true>(a, (hipStream_t)stream);
 }
 
 extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols, mm355_bf16* out,

@@ -84,6 +84,23 @@ def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, 
     return out
 
 
+def gemm_tn(at, bt, out, accumulate=False):
+    """out[M,N] (+)= at[K,M]^T . bt[K,N]   (weight-gradient form, operands untransposed).  Raises Mm355Error(-2) when K % 64."""
+    _chk_dev(at, bt, out)
+    pa, K, M, lda = _rows2d(at)
+    pb, Kb, N, ldb = _rows2d(bt)
+    assert K == Kb and at.dtype == BF16 and bt.dtype == BF16
+    po, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N)
+    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_OUT_F32 if out.dtype == torch.float32 else 0)
+    _lib.check(_L().mm355_gemm_tn_bf16(pa, lda, pb, ldb, po, ldc, M, N, K, flags, _stream()), f"mm355_gemm_tn_bf16 M={M} N={N} K={K}")
+    return out
+
+
+def gemm_tn_supported(at, bt):
+    return at.shape[0] % 64 == 0 and at.shape[1] % 8 == 0 and bt.shape[1] % 8 == 0 and at.shape[1] >= 8 and bt.shape[1] >= 8
+
+
 def transpose(x, out=None, ld_out=None):
     """out[c, r] = x[r, c]"""
     _chk_dev(x, out)
@@ -204,12 +221,13 @@ def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlen
     qt = head_transpose(q2d, 0, B, L, Hq, d)
     kt = head_transpose(k2d, 0, B, L, Hkv, d)
     dq = torch.zeros((M, Hq * d), device=o.device, dtype=torch.float32)
+    ws = torch.empty((2, M, Hq * d), device=o.device, dtype=torch.float32) if Hq != Hkv else None
     pdk, _, _, lddk = _rows2d(dk2d)
     pdv, _, _, lddv = _rows2d(dv2d)
     assert lddk == lddv
     _lib.check(_L().mm355_attn_bwd(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), qt.data_ptr(), kt.data_ptr(), dot.data_ptr(),
                                    lse.data_ptr(), delta.data_ptr(), _p(seqlens), dq.data_ptr(), pdk, pdv, lddk,
-                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_bwd")
+                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _p(ws), _stream()), "mm355_attn_bwd")
     return dq
 
 

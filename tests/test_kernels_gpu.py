@@ -103,6 +103,35 @@ def test_gemm_strided_views(ops):
     assert float(out_big[:, :64].abs().max()) == 0 and float(out_big[:, 64 + N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 768, 256), (264, 136, 128), (4096, 1152, 1024), (1152, 4096, 448), (8, 16, 64)])
+def test_gemm_tn(ops, shape):
+    """dW form on untransposed operands: C[M,N] = At[K,M]^T Bt[K,N] (ds_read_b64_tr_b16 fragment gather)."""
+    M, N, K = shape
+    at, bt = rnd(K, M, seed=11, scale=0.5), rnd(K, N, seed=12, scale=0.5)
+    ref = at.float().t() @ bt.float()
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_tn(at.to(DEV), bt.to(DEV), out)
+    close(out, ref, 1e-2, 0.02 * math.sqrt(K), f"gemm_tn {shape}")
+    c0 = rnd(M, N, seed=13)
+    c = c0.to(DEV).clone()
+    ops.gemm_tn(at.to(DEV), bt.to(DEV), c, accumulate=True)
+    close(c, ref + c0.float(), 1e-2, 0.02 * math.sqrt(K) + 0.03, "gemm_tn accumulate")
+    cf = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_tn(at.to(DEV), bt.to(DEV), cf)
+    close(cf, ref, 1e-4, 2e-3, "gemm_tn f32")
+    # strided operands (column blocks of wider activations)
+    big = rnd(K, M + 64, seed=14, scale=0.5)
+    ops.gemm_tn(big.to(DEV)[:, 32:32 + M] if M % 8 == 0 else big.to(DEV)[:, :M], bt.to(DEV), out)
+    close(out, big[:, 32:32 + M].float().t() @ bt.float(), 1e-2, 0.02 * math.sqrt(K), "gemm_tn strided A")
+
+
+def test_gemm_tn_rejects_ragged_k(ops):
+    from metamorph_amd.lib import Mm355Error
+    at, bt = rnd(100, 64, seed=1).to(DEV), rnd(100, 64, seed=2).to(DEV)
+    with pytest.raises(Mm355Error):
+        ops.gemm_tn(at, bt, torch.empty(64, 64, device=DEV, dtype=torch.bfloat16))
+
+
 def test_transpose_and_colsum(ops):
     for (r, c) in [(64, 64), (200, 136), (729, 1152), (130, 72)]:
         x = rnd(r, c, seed=r)
