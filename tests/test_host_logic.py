@@ -238,3 +238,19 @@ def test_fused_weight_views_survive_dtype_cast():
     assert all(p.grad is not None and float(p.grad.sum()) == p.numel() for p in ps)
     fb2, acc2, _ = F.fused_grad_target(ps)
     assert acc2 is True and fb2.data_ptr() == fb.data_ptr()
+
+
+def test_save_and_from_pretrained_round_trip(tmp_path):
+    """HF plumbing the reference relies on (train.py:1411-1423 / save_pretrained): same keys, same values back."""
+    from metamorph_amd.factory import build_model
+    from metamorph_amd.model import MetaMorphLlamaForCausalLM
+    llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+               vocab_size=300, rms_norm_eps=1e-5, rope_theta=500000.0)
+    m = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
+    m.save_pretrained(tmp_path)
+    m2 = MetaMorphLlamaForCausalLM.from_pretrained(tmp_path, torch_dtype=torch.bfloat16, vision_head="mlp", normalize_vision=True)
+    sd1, sd2 = m.state_dict(), m2.state_dict()
+    for k, v in sd1.items():
+        if "vision_tower" not in k:
+            assert torch.equal(v, sd2[k]), k
+    assert m2.config.num_image_tokens == 4 and m2.config.model_type == "metamorph_llama"
