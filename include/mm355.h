@@ -103,44 +103,34 @@ int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_
 int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                   const mm355_bf16* cos_t, const mm355_bf16* sin_t, int inverse, void* stream);
 
-/* out[b][h][dd][l] = in[(b*L + l)*ld + col0 + h*d + dd]   (per-head transposes for attention).
- * Lp >= L is the padded row length of `out` (columns [L,Lp) are zero filled). */
-int mm355_head_transpose(const mm355_bf16* in, int64_t ld, int64_t col0, int64_t B, int64_t L, int64_t H,
-                         int64_t d, mm355_bf16* out, int64_t Lp, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Attention -- torch SDPA as driven by HF LlamaModel (causal + key padding, GQA, fp32 softmax; K10)
  * and by HF SiglipAttention (non causal, d = 72; K2).
- * q/k/v are column blocks of row-major activations: element (b,l,head,dd) at
- *   ptr[(b*L + l)*ld + head*d + dd].   vt = V transposed per kv head [B][Hkv][d][Lp].
- * seqlens[b] = number of valid (non padding) keys of sample b (right padding); NULL = L.
- * o: [B*L][Hq*d] bf16; lse: [B][Hq][L] f32 (natural-log sum-exp of the scaled scores).
- * Rows l >= seqlens[b] produce o = 0, lse = 0.
- * Supported d: 64, 128 (LLaMA), 72 (SigLIP SO400M), any d % 8 == 0 and d <= 128.
+ * q/k/v are column blocks of row-major activations: element (b,l,head,dd) at ptr[(b*L + l)*ld + head*d + dd]
+ * (k and v share ld_k).  No transposed copies are needed: the kernels gather contraction-over-rows operands with
+ * ds_read_b64_tr_b16.  seqlens[b] = number of valid (non padding) keys of sample b (right padding); NULL = L.
+ * o: [B*L][>= Hq*d] bf16; lse: [B][Hq][L] f32 (natural-log sum-exp of the scaled scores).
+ * Rows l >= seqlens[b] produce o = 0, lse = 0 (and zero gradients).
+ * Supported d: any d % 8 == 0 and d <= 128 (64 / 128 LLaMA, 72 SigLIP SO400M).
  * ------------------------------------------------------------------------------------------------ */
-int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* vt, int64_t ld_q, int64_t ld_k,
+int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
                    mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
-                   int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d,
-                   float scale, int causal, void* stream);
+                   int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, void* stream);
 
-/* delta[b][h][l] = sum_dd dO*O ; also writes dOt = dO transposed per head [B][Hq][d][Lp]. */
+/* delta[b][h][l] = sum_dd dO*O  (softmax-backward row term). */
 int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta,
-                        mm355_bf16* dot, int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t d, void* stream);
+                        int64_t B, int64_t L, int64_t Hq, int64_t d, void* stream);
 
-/* Backward.  qt/kt/dot are per-head transposes [B][H][d][Lp]; dq_f32 [B*L][Hq*d] must be zeroed by the
- * caller; dk/dv written as column blocks with leading dimension ld_dkv.
- * workspace: NULL, or 2*B*L*Hq*d floats of scratch; with GQA (Hq > Hkv) it lets the dK/dV kernel run one
- * workgroup per (KV tile, query head) and sum the group afterwards (better balance under causal masking). */
+/* Backward: dq / dk / dv are written as bf16 column blocks (leading dimensions ld_dq / ld_dkv), no atomics.
+ * workspace: 2*B*L*Hq*d floats, required when Hq > Hkv (GQA): the dK/dV kernel runs one workgroup per
+ * (KV tile, query head) and the group is summed afterwards (NULL allowed when Hq == Hkv). */
 int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
-                   const mm355_bf16* d_o, int64_t ld_o,
-                   const mm355_bf16* qt, const mm355_bf16* kt, const mm355_bf16* dot,
-                   const float* lse, const float* delta, const int32_t* seqlens,
-                   float* dq_f32, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
-                   int64_t B, int64_t L, int64_t Lp, int64_t Hq, int64_t Hkv, int64_t d,
-                   float scale, int causal, float* workspace, void* stream);
+                   const mm355_bf16* d_o, int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens,
+                   mm355_bf16* dq, int64_t ld_dq, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
+                   int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
+                   float* workspace, void* stream);
 
-/* dq_f32 [M][Hq*d] -> bf16 into the q column block of dqkv (optionally through the inverse RoPE);
- * used after mm355_attn_bwd.  cos_t/sin_t NULL = plain cast. */
+/* f32 [rows][cols] -> bf16 column block (generic helper). */
 int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int64_t ld_out,
                            int64_t rows, int64_t cols, void* stream);
 

@@ -1,18 +1,21 @@
-// Attention, second generation (gfx950): "swapped" formulation, P never leaves registers.
+// Attention, second generation (gfx950): "swapped" formulation on NATURAL tiles.
 //
-//   forward   S^T = K Q^T   (A = K tile from LDS, B = Q fragments in registers)
-//             lane holds S^T[key = j*16 + fq*4 + r][q = fr]  -> a query row lives in 4 lanes x 16 registers:
-//             row max / sum = 15 in-register ops + 2 shuffles; the exponentiated P^T accumulators ARE the
-//             B operand of O^T += Vt P^T (k-slot e of lane group fq <-> key fq*4+e / 16+fq*4+e-4, and the
-//             A operand Vt[d][key] is read from LDS with the same permutation as two 8-byte reads).
-//             No P round trip through LDS, no block barrier inside a KV tile.
-//   dQ        same structure with three MFMA groups per KV tile:  S^T = K Q^T,  dP^T = V dO^T,
-//             dQ^T += Kt dS^T.  One workgroup owns its query rows => plain stores, no atomics.
-//   K/V tiles are double buffered in LDS with register-staged prefetch (global loads for tile t+1 are issued
-//   before the MFMAs of tile t, written to the other buffer after them; one barrier per tile).
-//
-// Workgroup = 4 waves, each wave owns RQ*16 query rows.  Replaces torch SDPA as driven by HF LlamaModel /
-// SiglipAttention (reference call sites metamorph_llama.py:349-359, siglip_encoder.py:141).
+// Every kernel stages only row-major [rows][d] tiles of Q / K / V / dO in LDS (16-B chunk XOR 2*(row&7): conflict-free for
+// both access patterns below) and obtains its two kinds of MFMA operands from them:
+//   * contraction over d   : ds_read_b128 of a tile row (8 consecutive d)                       -> S^T = K Q^T, dP^T = V dO^T
+//   * contraction over rows: ds_read_b64_tr_b16 (hardware 4x16 transpose read) of 4 consecutive rows at one column, in the
+//     k-slot permutation of the MFMA accumulator layout, so that P^T / dS^T accumulators are used as the other operand
+//     WITHOUT leaving registers                                                                 -> O^T += V^T P^T, dQ^T += K^T dS^T,
+//                                                                                                  dV += P^T dO, dK += dS^T Q
+// No transposed copies of any tensor exist in HBM, P never goes through LDS, dQ / dK / dV need no atomics:
+//   fwd_kernel  : workgroup = 64 query rows (16 per wave), loops over KV tiles of 64 keys, online softmax in log2 domain
+//                 with deferred rescale; a query row lives in 4 lanes x 16 registers (2 shuffles per reduction)
+//   dq_kernel   : same ownership, three MFMA groups per KV tile
+//   dkdv_kernel : workgroup = (KV tile of 64 keys, query head); wave owns 16 keys (K/V fragments in registers), loops over
+//                 64-row query tiles; GQA groups are summed afterwards from fp32 partials
+// All kernels prefetch the next tile into registers while the current one is consumed.
+// Replaces torch SDPA as driven by HF LlamaModel / SiglipAttention (reference call sites metamorph_llama.py:349-359,
+// siglip_encoder.py:141).
 #include "attn2.h"
 #include <cstdlib>
 
@@ -22,75 +25,69 @@ constexpr int NT = 256;
 
 MM_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// [rows][128 el] tile (256-B rows): 16-B chunk ^ (row & 15);  [rows][64 el] tile (128-B rows): chunk ^ swz64(row)
-MM_DEV int off128(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
-MM_DEV int swz64(int row) { return (row & 7) ^ ((row >> 3) & 1); }
-MM_DEV int off64(int row, int chunk) { return row * 128 + ((chunk ^ swz64(row)) << 4); }
-
-
 template <int DP> struct Geo {
-    static constexpr int DS = DP == 64 ? 64 : 128;          // LDS row length of [key][d] tiles
+    static constexpr int DS = DP == 64 ? 64 : 128;          // LDS row length (elements) of a [rows][d] tile
     static constexpr int KS = DP / 32;                      // k-steps over d
     static constexpr int NF = DP / 16;                      // 16-wide fragments over d
-    static constexpr int KD_BYTES = 64 * DS * 2;            // [64 keys][DS]
-    static constexpr int T_BYTES = DP * 128;                // [DP][64 keys]
-    static constexpr int KD_VEC = 64 * (DP / 8);            // 16-B vectors of a [64][DP] tile
-    static constexpr int T_VEC = DP * 8;
+    static constexpr int T64 = 64 * DS * 2;                 // bytes of a [64][DS] tile
+    static constexpr int V64 = 64 * (DP / 8);               // 16-B vectors of a [64][DP] tile
 };
-
-template <int DP> MM_DEV int off_kd(int row, int chunk) { return Geo<DP>::DS == 64 ? off64(row, chunk) : off128(row, chunk); }
-
-// register-staged tile movers --------------------------------------------------------------------
-template <int DP, int NV>
-MM_DEV void load_kd(u32x4 (&r)[NV], const uint16_t* base, int64_t ld, int kv0, int L, int d, int tid) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT;
-        const int row = v / (DP / 8), c = v % (DP / 8);
-        r[i] = u32x4{0u, 0u, 0u, 0u};
-        if (v < Geo<DP>::KD_VEC && c * 8 < d) r[i] = *(const u32x4*)(base + (int64_t)min(kv0 + row, L - 1) * ld + c * 8);
-    }
-}
-template <int DP, int NV>
-MM_DEV void store_kd(const u32x4 (&r)[NV], unsigned char* s, int tid) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT;
-        if (v < Geo<DP>::KD_VEC) *(u32x4*)(s + off_kd<DP>(v / (DP / 8), v % (DP / 8))) = r[i];
-    }
-}
-template <int DP, int NV>
-MM_DEV void load_t(u32x4 (&r)[NV], const uint16_t* base, int64_t Lp, int kv0, int d, int tid) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT;
-        const int row = v >> 3, c = v & 7;
-        r[i] = u32x4{0u, 0u, 0u, 0u};
-        if (v < Geo<DP>::T_VEC && row < d) r[i] = *(const u32x4*)(base + (int64_t)row * Lp + kv0 + c * 8);
-    }
-}
-template <int DP, int NV>
-MM_DEV void store_t(const u32x4 (&r)[NV], unsigned char* s, int tid) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * NT;
-        if (v < Geo<DP>::T_VEC) *(u32x4*)(s + off64(v >> 3, v & 7)) = r[i];
-    }
-}
-
-// A operand from a [DP][64 keys] transposed tile with the accumulator-order key permutation:
-// lane (row = f*16 + fr, fq) takes keys kk*32 + fq*4 .. +4 and kk*32 + 16 + fq*4 .. +4
-MM_DEV bf16x8 read_t_perm(const unsigned char* s, int row, int kk, int fq) {
-    const int sub = (fq & 1) * 8;
-    const bf16x4 lo = *(const bf16x4*)(s + off64(row, kk * 4 + (fq >> 1)) + sub);
-    const bf16x4 hi = *(const bf16x4*)(s + off64(row, kk * 4 + 2 + (fq >> 1)) + sub);
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
 
 MM_DEV bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
     u32x4 w;
     w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]); w.z = pack2bf(b[0], b[1]); w.w = pack2bf(b[2], b[3]);
     return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int DS> MM_DEV int swzN(int row) { return DS == 128 ? 2 * (row & 7) : 2 * ((row >> 1) & 3); }
+template <int DS> MM_DEV int offN(int row, int chunk) { return row * (DS * 2) + ((chunk ^ swzN<DS>(row)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds4_t;
+
+// X[row0 + fq*4 + e][c16*16 + fr] (e < 4) and X[row0 + 16 + fq*4 + e - 4][c16*16 + fr] (e >= 4) from a natural tile
+template <int DS>
+MM_DEV bf16x8 read_nat_perm(const unsigned char* s, int row0, int c16, int fr, int fq) {
+    const int j = fr >> 2, q4 = fr & 3;
+    const int chunk = c16 * 2 + (q4 >> 1), sub = (q4 & 1) * 8;
+    const int r_lo = row0 + fq * 4 + j, r_hi = r_lo + 16;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(s + offN<DS>(r_lo, chunk) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(s + offN<DS>(r_hi, chunk) + sub));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+
+// ---- [64][DP] tile movers with per-thread precomputed byte offsets (tile base is wave-uniform: saddr + voffset loads) ----
+template <int DP, int NV>
+MM_DEV void init_tile_io(uint32_t (&g)[NV], uint32_t (&sO)[NV], int64_t ld, int d, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT, row = v / (DP / 8), c = v % (DP / 8);
+        const bool in = v < Geo<DP>::V64;
+        g[i] = (in && c * 8 < d) ? (uint32_t)(row * ld * 2 + c * 16) : 0xffffffffu;
+        sO[i] = in ? (uint32_t)offN<Geo<DP>::DS>(row, c) : 0xffffffffu;
+    }
+}
+template <int DP, int NV>
+MM_DEV void load_tile(u32x4 (&r)[NV], const uint16_t* base, int64_t ld, int row0, int L, int d, int tid, const uint32_t (&g)[NV]) {
+    if (row0 + 64 <= L) {
+        const unsigned char* tb = (const unsigned char*)(base + (int64_t)row0 * ld);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = (g[i] != 0xffffffffu) ? *(const u32x4*)(tb + g[i]) : u32x4{0u, 0u, 0u, 0u};
+    } else {                                                 // ragged last tile: clamp the rows (masked by the caller)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * NT, row = v / (DP / 8), c = v % (DP / 8);
+            r[i] = u32x4{0u, 0u, 0u, 0u};
+            if (v < Geo<DP>::V64 && c * 8 < d) r[i] = *(const u32x4*)(base + (int64_t)min(row0 + row, L - 1) * ld + c * 8);
+        }
+    }
+}
+template <int NV>
+MM_DEV void store_tile(const u32x4 (&r)[NV], unsigned char* s, const uint32_t (&sO)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (sO[i] != 0xffffffffu) *(u32x4*)(s + sO[i]) = r[i];
 }
 
 // ================================================================================================
@@ -99,14 +96,15 @@ MM_DEV bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
 template <int DP, int RQ>
 __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
     using G = Geo<DP>;
-    constexpr int KS = G::KS, NF = G::NF;
-    constexpr int NVK = (G::KD_VEC + NT - 1) / NT, NVT = (G::T_VEC + NT - 1) / NT;
-    constexpr int STAGE = G::KD_BYTES + G::T_BYTES;
+    constexpr int DS = G::DS, KS = G::KS, NF = G::NF;
+    constexpr int NV = (G::V64 + NT - 1) / NT;
     constexpr int ROWS = RQ * 16;                           // query rows per wave
     constexpr int BQ = 4 * ROWS;
     constexpr int EPI = 4 * ROWS * DP * 2;                  // bf16 output staging
-    constexpr int SMEM = STAGE > EPI ? STAGE : EPI;          // single stage: tile t+1 waits in registers while tile t is consumed
+    constexpr int SMEM = 2 * G::T64 > EPI ? 2 * G::T64 : EPI;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + G::T64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -151,25 +149,25 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
     const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
     const int ntiles = (kv_end + 63) >> 6;
     const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * d;
-    const uint16_t* vtbase = a.vt + (((int64_t)b * a.Hkv + hk) * d) * a.Lp;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * d;
     const float sl2 = a.scale * 1.4426950408889634f;         // scores in log2 domain: exp2(s*sl2 - m)
 
-    u32x4 rk[NVK], rv[NVT];
-    load_kd<DP, NVK>(rk, kbase, a.ld_k, 0, L, d, tid);
-    load_t<DP, NVT>(rv, vtbase, a.Lp, 0, d, tid);
-    store_kd<DP, NVK>(rk, smem, tid);
-    store_t<DP, NVT>(rv, smem + G::KD_BYTES, tid);
+    u32x4 rk[NV], rv[NV];
+    uint32_t g[NV], sO[NV];
+    init_tile_io<DP, NV>(g, sO, a.ld_k, d, tid);
+    load_tile<DP, NV>(rk, kbase, a.ld_k, 0, L, d, tid, g);
+    load_tile<DP, NV>(rv, vbase, a.ld_k, 0, L, d, tid, g);
+    store_tile<NV>(rk, sK, sO);
+    store_tile<NV>(rv, sV, sO);
     __syncthreads();
     constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         const bool more = t + 1 < ntiles;
         if (more) {
-            load_kd<DP, NVK>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid);
-            load_t<DP, NVT>(rv, vtbase, a.Lp, kv0 + 64, d, tid);
+            load_tile<DP, NV>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid, g);
+            load_tile<DP, NV>(rv, vbase, a.ld_k, kv0 + 64, L, d, tid, g);
         }
-        const unsigned char* sK = smem;
-        const unsigned char* sV = sK + G::KD_BYTES;
         // a wave whose rows all precede this tile (causal) has nothing to do here
         const bool active = !a.causal || kv0 <= qw0 + ROWS - 1;
         if (active) {
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
+                    const bf16x8 kf = *(const bf16x8*)(sK + offN<DS>(j * 16 + fr, kk * 4 + fq));
 #pragma unroll
                     for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
                 }
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 mx *= sl2;
                 // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew
-                // by more than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR, exact in fp32/bf16 range)
+                // by more than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR)
                 const bool grow = mx > m_run[rq] + RESCALE_THR || m_run[rq] == -INFINITY;
                 if (__any(grow && mx > -INFINITY)) {
                     const float mn = fmaxf(m_run[rq], mx);
@@ -239,7 +237,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
                 for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const bf16x8 va = read_t_perm(sV, j * 16 + fr, kk, fq);
+                    const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);      // V^T[d][keys perm]
 #pragma unroll
                     for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
                 }
@@ -247,8 +245,8 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
         }
         __syncthreads();                                     // every wave is done reading this tile
         if (more) {
-            store_kd<DP, NVK>(rk, smem, tid);
-            store_t<DP, NVT>(rv, smem + G::KD_BYTES, tid);
+            store_tile<NV>(rk, sK, sO);
+            store_tile<NV>(rv, sV, sO);
             __syncthreads();
         }
     }
@@ -278,17 +276,17 @@ __global__ __launch_bounds__(NT) void fwd_kernel(Args a) {
 }
 
 // ================================================================================================
-// dQ (block owns its query rows; three MFMA groups per KV tile; no atomics)
+// dQ (block owns its query rows; three MFMA groups per KV tile; bf16 result written straight to its column block)
 // ================================================================================================
-template <int DP, int RQ>
+template <int DP>
 __global__ __launch_bounds__(NT) void dq_kernel(Args a) {
     using G = Geo<DP>;
-    constexpr int KS = G::KS, NF = G::NF;
-    constexpr int NVK = (G::KD_VEC + NT - 1) / NT, NVT = (G::T_VEC + NT - 1) / NT;
-    constexpr int STAGE = 2 * G::KD_BYTES + G::T_BYTES;     // K tile, V tile, Kt tile
-    constexpr int ROWS = RQ * 16;
-    constexpr int BQ = 4 * ROWS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE];   // single stage (48 KiB at d=128): 3 workgroups per CU
+    constexpr int DS = G::DS, KS = G::KS, NF = G::NF;
+    constexpr int NV = (G::V64 + NT - 1) / NT;
+    constexpr int BQ = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::T64];
+    unsigned char* sK = smem;
+    unsigned char* sV = smem + G::T64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -297,124 +295,297 @@ __global__ __launch_bounds__(NT) void dq_kernel(Args a) {
     const int d = a.d, L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
     const int64_t row_base = (int64_t)b * L;
-    const int64_t ld_dq = (int64_t)a.Hq * d;
-    float* dq_base = a.dq + row_base * ld_dq + (int64_t)hq * d;
-    if (q0 >= seqlen) return;                                // dq is pre-zeroed by the caller
+    uint16_t* dq_base = a.dqb + row_base * a.ld_dq + (int64_t)hq * d;
+    const int qw0 = q0 + wave * 16;
+    const int qg = qw0 + fr;
 
-    const int qw0 = q0 + wave * ROWS;
-    bf16x8 qf[RQ][KS], dof[RQ][KS];
-    float lse_r[RQ], del_r[RQ];
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-        const int qg = min(qw0 + rq * 16 + fr, L - 1);
-        const uint16_t* qp = a.q + (row_base + qg) * a.ld_q + (int64_t)hq * d;
-        const uint16_t* dp = a.d_o + (row_base + qg) * a.ld_o + (int64_t)hq * d;
+    if (q0 >= seqlen) {                                      // padded query rows carry zero gradient
+        for (int v = tid; v < BQ * (d >> 3); v += NT) {
+            const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
+            if (q0 + r < L) *(u32x4*)(dq_base + (int64_t)(q0 + r) * a.ld_dq + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
+    bf16x8 qf[KS], dof[KS];
+    {
+        const int qc = min(qg, L - 1);
+        const uint16_t* qp = a.q + (row_base + qc) * a.ld_q + (int64_t)hq * d;
+        const uint16_t* dp = a.d_o + (row_base + qc) * a.ld_o + (int64_t)hq * d;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const int c = kk * 32 + fq * 8;
-            qf[rq][kk] = (c < d) ? *(const bf16x8*)(qp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            dof[rq][kk] = (c < d) ? *(const bf16x8*)(dp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            qf[kk] = (c < d) ? *(const bf16x8*)(qp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            dof[kk] = (c < d) ? *(const bf16x8*)(dp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        lse_r[rq] = a.lse_in[((int64_t)b * a.Hq + hq) * L + qg] * 1.4426950408889634f;   // log2 domain
-        del_r[rq] = a.delta[((int64_t)b * a.Hq + hq) * L + qg];
     }
-    f32x4 dqt[RQ][NF];                                       // dQ^T[d = j*16 + fq*4 + r][q = fr]
+    const float lse_r = a.lse_in[((int64_t)b * a.Hq + hq) * L + min(qg, L - 1)] * 1.4426950408889634f;   // log2 domain
+    const float del_r = a.delta[((int64_t)b * a.Hq + hq) * L + min(qg, L - 1)];
+    f32x4 dqt[NF];                                           // dQ^T[d = j*16 + fq*4 + r][q = fr]
 #pragma unroll
-    for (int rq = 0; rq < RQ; ++rq)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) dqt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NF; ++j) dqt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
     const int ntiles = (kv_end + 63) >> 6;
     const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * d;
     const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * d;
-    const uint16_t* ktbase = a.kt + (((int64_t)b * a.Hkv + hk) * d) * a.Lp;
     const float sl2 = a.scale * 1.4426950408889634f;
 
-    u32x4 rk[NVK], rv[NVK], rt[NVT];
-    load_kd<DP, NVK>(rk, kbase, a.ld_k, 0, L, d, tid);
-    load_kd<DP, NVK>(rv, vbase, a.ld_k, 0, L, d, tid);
-    load_t<DP, NVT>(rt, ktbase, a.Lp, 0, d, tid);
-    store_kd<DP, NVK>(rk, smem, tid);
-    store_kd<DP, NVK>(rv, smem + G::KD_BYTES, tid);
-    store_t<DP, NVT>(rt, smem + 2 * G::KD_BYTES, tid);
+    u32x4 rk[NV], rv[NV];
+    uint32_t g[NV], sO[NV];
+    init_tile_io<DP, NV>(g, sO, a.ld_k, d, tid);
+    load_tile<DP, NV>(rk, kbase, a.ld_k, 0, L, d, tid, g);
+    load_tile<DP, NV>(rv, vbase, a.ld_k, 0, L, d, tid, g);
+    store_tile<NV>(rk, sK, sO);
+    store_tile<NV>(rv, sV, sO);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         const bool more = t + 1 < ntiles;
         if (more) {
-            load_kd<DP, NVK>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid);
-            load_kd<DP, NVK>(rv, vbase, a.ld_k, kv0 + 64, L, d, tid);
-            load_t<DP, NVT>(rt, ktbase, a.Lp, kv0 + 64, d, tid);
+            load_tile<DP, NV>(rk, kbase, a.ld_k, kv0 + 64, L, d, tid, g);
+            load_tile<DP, NV>(rv, vbase, a.ld_k, kv0 + 64, L, d, tid, g);
         }
-        const unsigned char* sK = smem;
-        const unsigned char* sV = sK + G::KD_BYTES;
-        const unsigned char* sKt = sK + 2 * G::KD_BYTES;
-        const bool active = !a.causal || kv0 <= qw0 + ROWS - 1;
+        const bool active = !a.causal || kv0 <= qw0 + 15;
         if (active) {
-            f32x4 st[RQ][4], dpt[RQ][4];
+            f32x4 st[4], dpt[4];
 #pragma unroll
-            for (int rq = 0; rq < RQ; ++rq)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < 4; ++j) { st[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
-                    const bf16x8 vf = *(const bf16x8*)(sV + off_kd<DP>(j * 16 + fr, kk * 4 + fq));
+                    const bf16x8 kf = *(const bf16x8*)(sK + offN<DS>(j * 16 + fr, kk * 4 + fq));
+                    const bf16x8 vf = *(const bf16x8*)(sV + offN<DS>(j * 16 + fr, kk * 4 + fq));
+                    st[j] = mfma16(kf, qf[kk], st[j]);
+                    dpt[j] = mfma16(vf, dof[kk], dpt[j]);
+                }
+            const bool need_mask = (kv0 + 64 > seqlen) || (qw0 + 16 > seqlen) || (a.causal && kv0 + 63 > qw0);
 #pragma unroll
-                    for (int rq = 0; rq < RQ; ++rq) {
-                        st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
-                        dpt[rq][j] = mfma16(vf, dof[rq][kk], dpt[rq][j]);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[j][r], sl2, -lse_r));
+                    if (need_mask) {
+                        const int kg = kv0 + j * 16 + fq * 4 + r;
+                        if (!((qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg))) p = 0.f;
                     }
+                    st[j][r] = p * (dpt[j][r] - del_r) * a.scale;                       // dS^T
                 }
 #pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-                const int qg = qw0 + rq * 16 + fr;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kg = kv0 + j * 16 + fq * 4 + r;
-                        const bool ok = (qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg);
-                        const float p = ok ? exp2f(st[rq][j][r] * sl2 - lse_r[rq]) : 0.f;
-                        st[rq][j][r] = p * (dpt[rq][j][r] - del_r[rq]) * a.scale;      // dS^T
-                    }
-            }
-#pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 sb[RQ];
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) sb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+                const bf16x8 sb = pack_acc(st[2 * kk], st[2 * kk + 1]);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const bf16x8 ka = read_t_perm(sKt, j * 16 + fr, kk, fq);
-#pragma unroll
-                    for (int rq = 0; rq < RQ; ++rq) dqt[rq][j] = mfma16(ka, sb[rq], dqt[rq][j]);
+                    const bf16x8 ka = read_nat_perm<DS>(sK, kk * 32, j, fr, fq);          // K^T[d][keys perm]
+                    dqt[j] = mfma16(ka, sb, dqt[j]);
                 }
             }
         }
         __syncthreads();                                     // every wave is done reading this tile
         if (more) {
-            store_kd<DP, NVK>(rk, smem, tid);
-            store_kd<DP, NVK>(rv, smem + G::KD_BYTES, tid);
-            store_t<DP, NVT>(rt, smem + 2 * G::KD_BYTES, tid);
+            store_tile<NV>(rk, sK, sO);
+            store_tile<NV>(rv, sV, sO);
             __syncthreads();
         }
     }
-    // dq[q][d] fp32: lane holds 4 consecutive d of one row -> 16-B stores
+    // dq[q][d] bf16 -> LDS [16 q][DP] per wave -> row-contiguous 16-B stores (rows >= seqlen are zero)
+    unsigned char* so = smem + wave * (16 * DP * 2);
+    const float keep = qg < seqlen ? 1.0f : 0.0f;
 #pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-        const int qg = qw0 + rq * 16 + fr;
-        if (qg < seqlen) {
+    for (int j = 0; j < NF; ++j) {
+        u32x2 w;
+        w.x = pack2bf(dqt[j][0] * keep, dqt[j][1] * keep);
+        w.y = pack2bf(dqt[j][2] * keep, dqt[j][3] * keep);
+        *(u32x2*)(so + fr * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+    }
+    __syncthreads();
+    for (int v = lane; v < 16 * (d >> 3); v += 64) {
+        const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
+        if (qw0 + r < L) *(u32x4*)(dq_base + (int64_t)(qw0 + r) * a.ld_dq + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+// ================================================================================================
+// dK / dV
+// ================================================================================================
+template <int DP>
+__global__ __launch_bounds__(NT) void dkdv_kernel(Args a) {
+    using G = Geo<DP>;
+    constexpr int DS = G::DS, KS = G::KS, NF = G::NF;
+    constexpr int QT = 64;                                   // query rows per iteration
+    constexpr int TILE = QT * DS * 2;
+    constexpr int NVQ = (QT * (DP / 8) + NT - 1) / NT;
+    constexpr int EPI = 4 * 16 * DP * 4;
+    constexpr int SMEM = 2 * TILE > EPI ? 2 * TILE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    __shared__ __attribute__((aligned(16))) float sStat[2 * QT];           // lse[64] | delta[64] (log2-domain lse)
+    unsigned char* sQ = smem;
+    unsigned char* sDO = smem + TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int group = a.Hq / a.Hkv;
+    const int kv0 = blockIdx.x * 64, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / group;
+    const int d = a.d, L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    const int mykey0 = kv0 + wave * 16;
+    const int64_t ld_p = (int64_t)a.Hq * d;
+
+    auto store_rows = [&](const f32x4 (&acc)[NF], bool is_dv, bool zero) {
+        // wave's 16 keys x d -> LDS (fp32) -> row-contiguous stores (fp32 partial or bf16 direct)
+        float* so = (float*)smem + wave * (16 * DP);
+        if (!zero) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(fq * 4 + r) * DP + j * 16 + fr] = acc[j][r];
+        }
+        __syncthreads();
+        for (int v = lane; v < 16 * (d >> 3); v += 64) {
+            const int r = v / (d >> 3), c = (v % (d >> 3)) * 8;
+            const int key = mykey0 + r;
+            if (key >= L) continue;
+            f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (!zero) { x0 = *(const f32x4*)(so + r * DP + c); x1 = *(const f32x4*)(so + r * DP + c + 4); }
+            if (a.dkp) {
+                float* pp = (is_dv ? a.dvp : a.dkp) + (row_base + key) * ld_p + (int64_t)hq * d + c;
+                *(f32x4*)pp = x0; *(f32x4*)(pp + 4) = x1;
+            } else {
+                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                *(u32x4*)((is_dv ? a.dv : a.dk) + (row_base + key) * a.ld_dkv + (int64_t)hk * d + c) = pack8(f);
+            }
+        }
+        __syncthreads();
+    };
+
+    f32x4 dkacc[NF], dvacc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) { dkacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (kv0 >= seqlen) {                                     // keys are all padding: zero gradients
+        store_rows(dkacc, false, true);
+        store_rows(dvacc, true, true);
+        return;
+    }
+
+    // K / V fragments of this wave's 16 keys (B operands): lane holds X[key = fr][kk*32 + fq*8 ..]
+    bf16x8 kf[KS], vf[KS];
+    {
+        const int key = min(mykey0 + fr, L - 1);
+        const uint16_t* kp = a.k + (row_base + key) * a.ld_k + (int64_t)hk * d;
+        const uint16_t* vp = a.v + (row_base + key) * a.ld_k + (int64_t)hk * d;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk * 32 + fq * 8;
+            kf[kk] = (c < d) ? *(const bf16x8*)(kp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            vf[kk] = (c < d) ? *(const bf16x8*)(vp + c) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int q_start = a.causal ? kv0 : 0;                  // kv0 is a multiple of 64 = QT
+    const int n_it = seqlen > q_start ? (seqlen - q_start + QT - 1) / QT : 0;
+    const uint16_t* qb = a.q + row_base * a.ld_q + (int64_t)hq * d;
+    const uint16_t* dob = a.d_o + row_base * a.ld_o + (int64_t)hq * d;
+    const float* lse_b = a.lse_in + ((int64_t)b * a.Hq + hq) * L;
+    const float* del_b = a.delta + ((int64_t)b * a.Hq + hq) * L;
+
+    u32x4 pq[NVQ], pdo[NVQ];
+    uint32_t gq[NVQ], gdo[NVQ], sq[NVQ];
+    float pstat = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVQ; ++i) {
+        const int v = tid + i * NT, r = v / (DP / 8), c = v % (DP / 8);
+        const bool ok = v < QT * (DP / 8) && c * 8 < d;
+        gq[i] = ok ? (uint32_t)(r * a.ld_q * 2 + c * 16) : 0xffffffffu;
+        gdo[i] = ok ? (uint32_t)(r * a.ld_o * 2 + c * 16) : 0xffffffffu;
+        sq[i] = (v < QT * (DP / 8)) ? (uint32_t)offN<DS>(r, c) : 0xffffffffu;
+    }
+    auto fetch = [&](int it) {
+        const int qt0 = q_start + it * QT;
+        if (qt0 + QT <= L) {
+            const unsigned char* qtile = (const unsigned char*)(qb + (int64_t)qt0 * a.ld_q);
+            const unsigned char* dtile = (const unsigned char*)(dob + (int64_t)qt0 * a.ld_o);
+#pragma unroll
+            for (int i = 0; i < NVQ; ++i) {
+                pq[i] = (gq[i] != 0xffffffffu) ? *(const u32x4*)(qtile + gq[i]) : u32x4{0u, 0u, 0u, 0u};
+                pdo[i] = (gdo[i] != 0xffffffffu) ? *(const u32x4*)(dtile + gdo[i]) : u32x4{0u, 0u, 0u, 0u};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVQ; ++i) {
+                const int v = tid + i * NT, r = v / (DP / 8), c = v % (DP / 8);
+                pq[i] = u32x4{0u, 0u, 0u, 0u}; pdo[i] = u32x4{0u, 0u, 0u, 0u};
+                if (v < QT * (DP / 8) && c * 8 < d) {
+                    const int qrow = min(qt0 + r, L - 1);
+                    pq[i] = *(const u32x4*)(qb + (int64_t)qrow * a.ld_q + c * 8);
+                    pdo[i] = *(const u32x4*)(dob + (int64_t)qrow * a.ld_o + c * 8);
+                }
+            }
+        }
+        if (tid < 2 * QT) {
+            const int qrow = min(qt0 + (tid & (QT - 1)), L - 1);
+            pstat = (tid < QT) ? lse_b[qrow] * 1.4426950408889634f : del_b[qrow];
+        }
+    };
+    const float sl2 = a.scale * 1.4426950408889634f;
+    if (n_it > 0) fetch(0);
+    for (int it = 0; it < n_it; ++it) {
+        const int qt0 = q_start + it * QT;
+        __syncthreads();                                     // previous iteration's LDS reads done
+#pragma unroll
+        for (int i = 0; i < NVQ; ++i)
+            if (sq[i] != 0xffffffffu) { *(u32x4*)(sQ + sq[i]) = pq[i]; *(u32x4*)(sDO + sq[i]) = pdo[i]; }
+        if (tid < 2 * QT) sStat[tid] = pstat;
+        __syncthreads();
+        if (it + 1 < n_it) fetch(it + 1);
+
+        // S[i], dP[i] for the four 16-row fragments: lane holds X[q = i*16 + fq*4 + r][key = fr]
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const bf16x8 qa = *(const bf16x8*)(sQ + offN<DS>(i * 16 + fr, kk * 4 + fq));
+                const bf16x8 da = *(const bf16x8*)(sDO + offN<DS>(i * 16 + fr, kk * 4 + fq));
+                s[i] = mfma16(qa, kf[kk], s[i]);
+                dp[i] = mfma16(da, vf[kk], dp[i]);
+            }
+        }
+        const int kg = mykey0 + fr;
+        const bool need_mask = (qt0 + QT > seqlen) || (kv0 + 64 > seqlen) || (a.causal && qt0 < kv0 + 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
+            const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r]));
+                if (need_mask) {
+                    const int qg = qt0 + i * 16 + fq * 4 + r;
+                    if (!((qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg))) p = 0.f;
+                }
+                s[i][r] = p;
+                dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;                  // dS
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
+            const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const int c = j * 16 + fq * 4;
-                if (c < d) *(f32x4*)(dq_base + (int64_t)qg * ld_dq + c) = dqt[rq][j];
+                const bf16x8 dob8 = read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
+                const bf16x8 qb8 = read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
+                dvacc[j] = mfma16(pa, dob8, dvacc[j]);
+                dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
             }
         }
     }
+    __syncthreads();
+    store_rows(dkacc, false, false);
+    store_rows(dvacc, true, false);
 }
 
 }  // namespace attn2
@@ -439,12 +610,22 @@ int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
 
 int mm355_attn2_dq_launch(const attn2::Args& a, int dp, hipStream_t s) {
     using namespace attn2;
-    constexpr int RQ = 1;
-    dim3 grid((unsigned)((a.L + 4 * RQ * 16 - 1) / (4 * RQ * 16)), (unsigned)a.Hq, (unsigned)a.B);
+    dim3 grid((unsigned)((a.L + 63) / 64), (unsigned)a.Hq, (unsigned)a.B);
     switch (dp) {
-        case 64: hipLaunchKernelGGL((dq_kernel<64, RQ>), grid, dim3(NT), 0, s, a); break;
-        case 96: hipLaunchKernelGGL((dq_kernel<96, RQ>), grid, dim3(NT), 0, s, a); break;
-        default: hipLaunchKernelGGL((dq_kernel<128, RQ>), grid, dim3(NT), 0, s, a); break;
+        case 64: hipLaunchKernelGGL((dq_kernel<64>), grid, dim3(NT), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((dq_kernel<96>), grid, dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL((dq_kernel<128>), grid, dim3(NT), 0, s, a); break;
+    }
+    return mm_launch_status();
+}
+
+int mm355_attn2_dkdv_launch(const attn2::Args& a, int dp, hipStream_t s) {
+    using namespace attn2;
+    dim3 grid((unsigned)((a.L + 63) / 64), (unsigned)a.Hq, (unsigned)a.B);
+    switch (dp) {
+        case 64: hipLaunchKernelGGL((dkdv_kernel<64>), grid, dim3(NT), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((dkdv_kernel<96>), grid, dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL((dkdv_kernel<128>), grid, dim3(NT), 0, s, a); break;
     }
     return mm_launch_status();
 }

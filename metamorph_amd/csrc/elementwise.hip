@@ -62,33 +62,6 @@ __global__ __launch_bounds__(NT) void rope_qk_kernel(uint16_t* __restrict__ qkv,
     }
 }
 
-// ------------------------------------------------------------------------------------------------ per-head transpose
-// out[b][h][dd][l] (row length Lp) = in[(b*L + l)*ld + col0 + h*d + dd]; 64-row l tiles through LDS.
-__global__ __launch_bounds__(NT) void head_transpose_kernel(const uint16_t* __restrict__ in, int64_t ld, int64_t col0, int L, int H, int d,
-                                                            uint16_t* __restrict__ out, int Lp) {
-    __shared__ uint16_t tile[64][128 + 2];
-    const int l0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int dv = d >> 3;                                   // vectors per row
-    for (int v = threadIdx.x; v < 64 * dv; v += NT) {
-        const int r = v / dv, c = (v % dv) * 8;
-        const int l = l0 + r;
-        uint16_t tmp[8];
-        if (l < L) *(u32x4*)tmp = *(const u32x4*)(in + ((int64_t)b * L + l) * ld + col0 + (int64_t)h * d + c);
-        else *(u32x4*)tmp = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tile[r][c + e] = tmp[e];
-    }
-    __syncthreads();
-    uint16_t* ob = out + (((int64_t)b * H + h) * d) * Lp + l0;
-    for (int v = threadIdx.x; v < d * 8; v += NT) {
-        const int dd = v >> 3, r = (v & 7) * 8;
-        uint16_t tmp[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tmp[e] = tile[r + e][dd];
-        *(u32x4*)(ob + (int64_t)dd * Lp + r) = *(const u32x4*)tmp;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ SwiGLU / GELU
 __global__ __launch_bounds__(NT) void swiglu_fwd_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ act, int64_t M, int I) {
     const int iv = I >> 3;
@@ -329,14 +302,6 @@ extern "C" int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, 
     if (!qkv || !cos_t || !sin_t || B <= 0 || L <= 0 || Hq <= 0 || Hkv < 0 || d <= 0 || (d & 15) || (ld & 7)) return MM355_EINVAL;
     const int64_t H = Hq + Hkv;                              // q heads then k heads are contiguous column blocks
     LAUNCH(rope_qk_kernel, grid_for(B * L * H * (d / 16)), qkv, ld, (int)B, (int)L, (int)H, (int)d, cos_t, sin_t, inverse);
-}
-extern "C" int mm355_head_transpose(const mm355_bf16* in, int64_t ld, int64_t col0, int64_t B, int64_t L, int64_t H, int64_t d, mm355_bf16* out,
-                                    int64_t Lp, void* stream) {
-    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
-    if (!in || !out || B <= 0 || L <= 0 || H <= 0 || d <= 0 || d > 128 || (d & 7) || (ld & 7) || (col0 & 7) || (Lp & 63) || Lp < L) return MM355_EINVAL;
-    hipLaunchKernelGGL(head_transpose_kernel, dim3((unsigned)(Lp / 64), (unsigned)H, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, in, ld, col0,
-                       (int)L, (int)H, (int)d, out, (int)Lp);
-    return mm_launch_status();
 }
 extern "C" int mm355_swiglu_fwd(const mm355_bf16* gu, mm355_bf16* act, int64_t M, int64_t I, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch

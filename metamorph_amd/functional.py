@@ -174,9 +174,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     del n1
     ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin)
     nq, nk = m.Hq * m.d, m.Hkv * m.d
-    vt = ops.head_transpose(qkv, nq + nk, m.B, m.L, m.Hkv, m.d)
-    o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], vt, m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
-    del vt
+    o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
     n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps)
     gu = ops.gemm(n2, wgu)
@@ -239,11 +237,9 @@ class DecoderLayerFn(Function):
             weight_grad_gemm(dx2, o, buf, acc)
             commit_grad(att.o_proj.weight, buf)
         dqkv = torch.empty_like(qkv)
-        dq = ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
-                          m.scale, True, m.seqlens, dqkv[:, nq:nq + nk], dqkv[:, nq + nk:])
+        ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
+                     m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:])
         del do
-        ops.cast_f32_to_bf16_2d(dq, dqkv[:, :nq])
-        del dq
         ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True)
         qkv_params = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
         wqkv = fused_weight(qkv_params)

@@ -188,8 +188,7 @@ class HipSiglipVisionTransformer(nn.Module):
             h1 = layer.layer_norm1(x)
             wqkv, bqkv = self._qkv(j)
             qkv = ops.gemm(h1, wqkv, bias=bqkv)
-            vt = ops.head_transpose(qkv, 2 * hv, N, P, heads, d)
-            o, _ = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], vt, N, P, heads, heads, d, d ** -0.5, False, None)
+            o, _ = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], qkv[:, 2 * hv:], N, P, heads, heads, d, d ** -0.5, False, None)
             a = layer.self_attn
             x = ops.gemm(o, a.out_proj.weight.data, bias=a.out_proj.bias.data, residual=x)
             h2 = layer.layer_norm2(x)

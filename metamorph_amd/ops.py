@@ -176,59 +176,39 @@ def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False):
     return qkv
 
 
-def pad64(L):
-    return (L + 63) // 64 * 64
-
-
-def head_transpose(x2d, col0, B, L, H, d):
-    """[B*L, ld] column block -> [B, H, d, Lp]"""
-    _chk_dev(x2d)
-    p, M, _, ld = _rows2d(x2d)
-    assert M == B * L
-    Lp = pad64(L)
-    out = torch.empty((B, H, d, Lp), device=x2d.device, dtype=BF16)
-    _lib.check(_L().mm355_head_transpose(p, ld, col0, B, L, H, d, out.data_ptr(), Lp, _stream()), "mm355_head_transpose")
-    return out
-
-
-def attn_fwd(q2d, k2d, vt, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None):
-    """q2d/k2d: [B*L, ld] views starting at the q / k column blocks; vt: [B,Hkv,d,Lp]."""
-    _chk_dev(q2d, k2d, vt)
+def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None):
+    """q2d/k2d/v2d: [B*L, ld] views starting at the q / k / v column blocks (k and v share the leading dimension)."""
+    _chk_dev(q2d, k2d, v2d)
     pq, M, _, ldq = _rows2d(q2d)
     pk, _, _, ldk = _rows2d(k2d)
-    Lp = vt.shape[-1]
+    pv, _, _, ldv = _rows2d(v2d)
+    assert ldv == ldk and M == B * L
     if out is None:
         out = torch.empty((M, Hq * d), device=q2d.device, dtype=BF16)
     lse = torch.empty((B, Hq, L), device=q2d.device, dtype=torch.float32)
-    _lib.check(_L().mm355_attn_fwd(pq, pk, vt.data_ptr(), ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
-                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_fwd")
+    _lib.check(_L().mm355_attn_fwd(pq, pk, pv, ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
+                                   B, L, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_fwd")
     return out, lse
 
 
-def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlens, dk2d, dv2d):
-    """Returns dq_f32 [B*L, Hq*d]; writes dk/dv into the given column-block views."""
-    _chk_dev(q2d, k2d, v2d, o, d_o)
+def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlens, dq2d, dk2d, dv2d):
+    """Writes dq / dk / dv (bf16) into the given column-block views."""
+    _chk_dev(q2d, k2d, v2d, o, d_o, dq2d, dk2d, dv2d)
     pq, M, _, ldq = _rows2d(q2d)
     pk, _, _, ldk = _rows2d(k2d)
     pv, _, _, ldv = _rows2d(v2d)
     assert ldv == ldk
-    Lp = pad64(L)
     assert o.is_contiguous() and d_o.is_contiguous()
     delta = torch.empty((B, Hq, L), device=o.device, dtype=torch.float32)
-    dot = torch.empty((B, Hq, d, Lp), device=o.device, dtype=BF16)
-    _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), dot.data_ptr(),
-                                        B, L, Lp, Hq, d, _stream()), "mm355_attn_bwd_prep")
-    qt = head_transpose(q2d, 0, B, L, Hq, d)
-    kt = head_transpose(k2d, 0, B, L, Hkv, d)
-    dq = torch.zeros((M, Hq * d), device=o.device, dtype=torch.float32)
+    _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), B, L, Hq, d, _stream()),
+               "mm355_attn_bwd_prep")
     ws = torch.empty((2, M, Hq * d), device=o.device, dtype=torch.float32) if Hq != Hkv else None
+    pdq, _, _, lddq = _rows2d(dq2d)
     pdk, _, _, lddk = _rows2d(dk2d)
     pdv, _, _, lddv = _rows2d(dv2d)
     assert lddk == lddv
-    _lib.check(_L().mm355_attn_bwd(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), qt.data_ptr(), kt.data_ptr(), dot.data_ptr(),
-                                   lse.data_ptr(), delta.data_ptr(), _p(seqlens), dq.data_ptr(), pdk, pdv, lddk,
-                                   B, L, Lp, Hq, Hkv, d, scale, int(causal), _p(ws), _stream()), "mm355_attn_bwd")
-    return dq
+    _lib.check(_L().mm355_attn_bwd(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), lse.data_ptr(), delta.data_ptr(), _p(seqlens),
+                                   pdq, lddq, pdk, pdv, lddk, B, L, Hq, Hkv, d, scale, int(causal), _p(ws), _stream()), "mm355_attn_bwd")
 
 
 def cast_f32_to_bf16_2d(src_f32, dst2d):

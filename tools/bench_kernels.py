@@ -57,17 +57,16 @@ def main():
     for (B, L) in ((M // 2048, 2048),):
         Hq, Hkv, d = 32, 8, 128
         qkv = (torch.randn(B * L, (Hq + 2 * Hkv) * d, device=DEV) * 0.5).bfloat16()
-        vt = ops.head_transpose(qkv, (Hq + Hkv) * d, B, L, Hkv, d)
         q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
-        t = timeit(lambda: ops.attn_fwd(q2, k2, vt, B, L, Hq, Hkv, d, d ** -0.5, True, None))
+        t = timeit(lambda: ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, True, None))
         fl = 4.0 * B * Hq * L * L * d / 2
         print(f"attn_fwd B={B} L={L}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TF/s (causal-halved flops)", flush=True)
         res.append(dict(kernel="attn_fwd", B=B, L=L, ms=t * 1e3, tflops=fl / t / 1e12))
-        o, lse = ops.attn_fwd(q2, k2, vt, B, L, Hq, Hkv, d, d ** -0.5, True, None)
+        o, lse = ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, True, None)
         do = torch.randn_like(o)
         dqkv = torch.empty_like(qkv)
         t = timeit(lambda: ops.attn_bwd(q2, k2, v2, o, do, lse, B, L, Hq, Hkv, d, d ** -0.5, True, None,
-                                        dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:]), iters=5)
+                                        dqkv[:, :Hq * d], dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:]), iters=5)
         print(f"attn_bwd B={B} L={L}: {t*1e3:8.3f} ms {2.5*fl/t/1e12:7.1f} TF/s (incl. prep+transposes)", flush=True)
         res.append(dict(kernel="attn_bwd", B=B, L=L, ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
     # HBM-bound kernels

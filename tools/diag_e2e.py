@@ -91,8 +91,7 @@ def main():
             nq, nk = Hq * d, Hkv * d
             print(f"L{i} q rope              ", rel(qkv[:, :nq].reshape(B, L, Hq, d).transpose(1, 2), q))
             print(f"L{i} k rope              ", rel(qkv[:, nq:nq + nk].reshape(B, L, Hkv, d).transpose(1, 2), k))
-            vt = ops.head_transpose(qkv, nq + nk, B, L, Hkv, d)
-            o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], vt, B, L, Hq, Hkv, d, d ** -0.5, True, pd["seqlens"])
+            o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], B, L, Hq, Hkv, d, d ** -0.5, True, pd["seqlens"])
             ov = o.view(B, L, -1)
             for b in range(B):
                 nvalid = int(valid[b].sum())

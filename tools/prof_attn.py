@@ -7,12 +7,11 @@ from metamorph_amd import ops
 B, L, Hq, Hkv, d = 4, 2048, 32, 8, 128
 causal = os.environ.get("CAUSAL", "1") == "1"
 qkv = (torch.randn(B * L, (Hq + 2 * Hkv) * d, device="cuda") * 0.5).bfloat16()
-vt = ops.head_transpose(qkv, (Hq + Hkv) * d, B, L, Hkv, d)
 q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
 for _ in range(3):
-    o, lse = ops.attn_fwd(q2, k2, vt, B, L, Hq, Hkv, d, d ** -0.5, causal, None)
+    o, lse = ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, causal, None)
 do = torch.randn_like(o)
 dqkv = torch.empty_like(qkv)
 for _ in range(3):
-    ops.attn_bwd(q2, k2, v2, o, do, lse, B, L, Hq, Hkv, d, d ** -0.5, causal, None, dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:])
+    ops.attn_bwd(q2, k2, v2, o, do, lse, B, L, Hq, Hkv, d, d ** -0.5, causal, None, dqkv[:, :Hq * d], dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:])
 torch.cuda.synchronize()
