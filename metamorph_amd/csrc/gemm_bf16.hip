@@ -14,6 +14,7 @@
 //   * workgroup -> tile map: bijective XCD remap (block b runs on XCD b % 8) then grouped raster so the
 //     blocks sharing an XCD's L2 walk neighbouring tiles.
 #include "mm355_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -58,6 +59,86 @@ __device__ __attribute__((noinline)) void epi_scalar(void* C, int64_t ldc, const
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Shared epilogue: accumulators -> wave-private LDS slab -> row-contiguous 16-B stores with the fused epilogue.
+template <int TM, int TN, int FM, int FN>
+MM_DEV void gemm_epilogue(f32x4 (&acc)[FM][FN], const GemmArgs& a, unsigned char* smem, int m0, int n0, int wm, int wn, int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, N = a.N;
+    constexpr int CPL = TN / 4;                          // columns handled by one lane per row
+    float* stg = (float*)smem + wave * (16 * TN);
+    const uint32_t fl = a.flags;
+    const int row_l = lane >> 2, col_l = (lane & 3) * CPL;
+    uint16_t* Cb = (uint16_t*)a.C;
+    float* Cf = (float*)a.C;
+    const bool vec_ok = ((a.ldc & 7) == 0) && (!(fl & MM355_GEMM_RESIDUAL) || (a.ldr & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
+        __syncthreads();
+        const int grow = m0 + wm * TM + i * 16 + row_l;
+        if (grow < M) {
+            const int64_t rr = (fl & MM355_GEMM_RESIDUAL) ? (a.res_mod > 0 ? (int64_t)(grow % a.res_mod) : (int64_t)grow) : 0;
+#pragma unroll
+            for (int j = 0; j < CPL / 8; ++j) {
+                const int c = n0 + wn * TN + col_l + j * 8;
+                if (c >= N) continue;
+                float v[8];
+                const f32x4 s0 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8);
+                const f32x4 s1 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8 + 4);
+                v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w;
+                v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+                const bool full = (c + 8 <= N) && vec_ok;
+                if (full) {
+                    if (fl & MM355_GEMM_BIAS) {
+                        float b[8];
+                        unpack8(*(const u32x4*)(a.bias + c), b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += b[e];
+                    }
+                    if (fl & MM355_GEMM_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                    } else if (fl & MM355_GEMM_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    }
+                    if (fl & MM355_GEMM_RESIDUAL) {
+                        float b[8];
+                        unpack8(*(const u32x4*)(a.res + rr * a.ldr + c), b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += b[e];
+                    }
+                    if (fl & MM355_GEMM_OUT_F32) {
+                        float* p = Cf + (int64_t)grow * a.ldc + c;
+                        if (fl & MM355_GEMM_ACCUMULATE) {
+                            const f32x4 o0 = *(const f32x4*)p, o1 = *(const f32x4*)(p + 4);
+                            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
+                            v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                        }
+                        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        uint16_t* p = Cb + (int64_t)grow * a.ldc + c;
+                        if (fl & MM355_GEMM_ACCUMULATE) {
+                            float b[8];
+                            unpack8(*(const u32x4*)p, b);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += b[e];
+                        }
+                        *(u32x4*)p = pack8(v);
+                    }
+                } else {
+                    epi_scalar(a.C, a.ldc, a.bias, a.res, a.ldr, fl, N, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
+    }
+}
 
 // TNL = true: both operands are stored contraction-major ("TN": A = At[K][M], B = Bt[K][N], C = At^T Bt), which is the
 // weight-gradient form dW = dY^T X on the activations as they lie in memory -- no transposed copies.  LDS tiles are then
@@ -328,6 +409,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
             } else {
                 __syncthreads();                             // tile kt+1 landed everywhere; buffer `cur` fully read
                 if constexpr (PIPE == 1 || PIPE == 3) { if (kt + 2 < nk) gdma(kt + 2, cur); }
+                if constexpr (PIPE == 6) {                   // ablation: global loads to registers only
+                    if (kt + 2 < nk) {
+                        const int k0 = (kt + 2) << 6;
+#pragma unroll
+                        for (int i = 0; i < AI; ++i) { const u32x4 t = *(const u32x4*)(srcA[i] + k0); asm volatile("" :: "v"(t)); }
+#pragma unroll
+                        for (int i = 0; i < BI; ++i) { const u32x4 t = *(const u32x4*)(srcB[i] + k0); asm volatile("" :: "v"(t)); }
+                    }
+                }
+                if constexpr (PIPE == 7) {                   // ablation: half of the DMA pieces
+                    if (kt + 2 < nk) {
+                        const int k0 = (kt + 2) << 6;
+                        unsigned char* sb = smem + cur * STAGE + wave_s * 1024;
+#pragma unroll
+                        for (int i = 0; i < AI; ++i)
+                            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sb + i * NW * 1024), 16, 0, 0);
+                    }
+                }
             }
             if (kt + 1 < nk) {                                // unit 3: (k1, hi)
                 rdA(X, cur ^ 1, 0, 0);
@@ -342,79 +441,171 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    constexpr int CPL = TN / 4;                          // columns handled by one lane per row
-    float* stg = (float*)smem + wave * (16 * TN);
-    const uint32_t fl = a.flags;
-    const int row_l = lane >> 2, col_l = (lane & 3) * CPL;
-    uint16_t* Cb = (uint16_t*)a.C;
-    float* Cf = (float*)a.C;
-    const bool vec_ok = ((a.ldc & 7) == 0) && (!(fl & MM355_GEMM_RESIDUAL) || (a.ldr & 7) == 0);
+    gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring-pipelined 256x256 kernel: the K dimension is consumed in HALF tiles (BK = 32) from a ring of four 32-KiB LDS
+// slots.  Measurements (ablation variants above) showed that the cost of the staging is the BURST: when all eight waves
+// issue their LDS-DMAs right after a barrier they queue in the texture path and no wave issues MFMAs meanwhile.  Here
+//   * each wave issues its 4 DMA pieces of half-tile s+3 two at a time IN BETWEEN its 16-MFMA units,
+//   * waits are counted (s_waitcnt vmcnt(8): the two most recent half-tiles may still be in flight), never a drain,
+//   * a raw s_barrier per half-tile (32 MFMAs per wave) publishes half-tile s+1 and frees slot s for the DMA of s+4.
+// LDS half-tile layout: [512 rows (A then B)][32 bf16] (64-B rows); physical 16-B chunk = logical ^ 3*((row>>3)&1), which
+// makes every ds_read_b128 fragment read conflict free; the DMA applies the same XOR on its per-lane source address.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs a) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16, HM = FM / 2;
+    constexpr int SLOT = (BM + BN) * 64;                    // 32 KiB
+    constexpr int A_BYTES = BM * 64;
+    constexpr int GM = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int total = a.ntm * a.ntn;
+    const int bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int gsize = GM * a.ntn;
+    const int grp = logical / gsize;
+    const int first_m = grp * GM;
+    const int gm = min(a.ntm - first_m, GM);
+    const int in_g = logical - grp * gsize;
+    const int tm = first_m + in_g % gm;
+    const int tn = in_g / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_s / WN, wn = wave_s % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, N = a.N;
+    const int nh = a.K >> 5;                                 // half tiles (K % 64 == 0 => nh even, >= 2)
+
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        __syncthreads();
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA sources: half tile = 512 rows x 64 B = 32 pieces of 1 KiB (16 rows each); wave w owns pieces w, w+8, w+16, w+24
+    // (pieces 0..15 = A rows, 16..31 = B rows)
+    const uint16_t* src[4];
+    {
+        const int rin = lane >> 2;                           // row inside the 16-row piece
+        const int c = (lane & 3) ^ (3 * ((rin >> 3) & 1));   // logical chunk that belongs in physical slot (lane & 3)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
-        __syncthreads();
-        const int grow = m0 + wm * TM + i * 16 + row_l;
-        if (grow < M) {
-            const int64_t rr = (fl & MM355_GEMM_RESIDUAL) ? (a.res_mod > 0 ? (int64_t)(grow % a.res_mod) : (int64_t)grow) : 0;
-#pragma unroll
-            for (int j = 0; j < CPL / 8; ++j) {
-                const int c = n0 + wn * TN + col_l + j * 8;
-                if (c >= N) continue;
-                float v[8];
-                const f32x4 s0 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8);
-                const f32x4 s1 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8 + 4);
-                v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w;
-                v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
-                const bool full = (c + 8 <= N) && vec_ok;
-                if (full) {
-                    if (fl & MM355_GEMM_BIAS) {
-                        float b[8];
-                        unpack8(*(const u32x4*)(a.bias + c), b);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += b[e];
-                    }
-                    if (fl & MM355_GEMM_GELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-                    } else if (fl & MM355_GEMM_GELU_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                    }
-                    if (fl & MM355_GEMM_RESIDUAL) {
-                        float b[8];
-                        unpack8(*(const u32x4*)(a.res + rr * a.ldr + c), b);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += b[e];
-                    }
-                    if (fl & MM355_GEMM_OUT_F32) {
-                        float* p = Cf + (int64_t)grow * a.ldc + c;
-                        if (fl & MM355_GEMM_ACCUMULATE) {
-                            const f32x4 o0 = *(const f32x4*)p, o1 = *(const f32x4*)(p + 4);
-                            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
-                            v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
-                        }
-                        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    } else {
-                        uint16_t* p = Cb + (int64_t)grow * a.ldc + c;
-                        if (fl & MM355_GEMM_ACCUMULATE) {
-                            float b[8];
-                            unpack8(*(const u32x4*)p, b);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += b[e];
-                        }
-                        *(u32x4*)p = pack8(v);
-                    }
-                } else {
-                    epi_scalar(a.C, a.ldc, a.bias, a.res, a.ldr, fl, N, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int piece = i * NW + wave_s;
+            const int row = (piece & 15) * 16 + rin;
+            src[i] = (piece < 16) ? a.A + (int64_t)min(m0 + row, M - 1) * a.lda + c * 8
+                                  : a.B + (int64_t)min(n0 + row, N - 1) * a.ldb + c * 8;
         }
     }
+    auto dma = [&](int s, int i) {                           // piece i of half tile s
+        unsigned char* slot = smem + (s & 3) * SLOT + (i * NW + wave_s) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (s << 5)), (lptr_t)slot, 16, 0, 0);
+    };
+    const int sw = (fq ^ (3 * ((fr >> 3) & 1))) << 4;
+    const int a_off = (wm * TM + fr) * 64 + sw;
+    const int b_off = A_BYTES + (wn * TN + fr) * 64 + sw;
+    bf16x8 X[HM], Y[HM], P[FN];
+    auto rdA = [&](bf16x8 (&af)[HM], int s, int half) {
+        const unsigned char* sb = smem + (s & 3) * SLOT + a_off + half * HM * 1024;
+#pragma unroll
+        for (int i = 0; i < HM; ++i) af[i] = *(const bf16x8*)(sb + i * 1024);
+    };
+    auto rdB = [&](bf16x8 (&bf)[FN], int s) {
+        const unsigned char* sb = smem + (s & 3) * SLOT + b_off;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = *(const bf16x8*)(sb + j * 1024);
+    };
+    auto mm = [&](const bf16x8 (&af)[HM], const bf16x8 (&bf)[FN], int half) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[half * HM + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // one half tile: MODE 0 = steady state (issue s+3, keep 8 in flight), 1 = two tiles still in flight after this one,
+    // 2 = last staged tile is the next one (drain), 3 = final half tile (nothing to fetch or publish)
+    auto step = [&](auto mode_c, int s, bf16x8 (&Pc)[FN], bf16x8 (&Pn)[FN]) {
+        constexpr int MODE = decltype(mode_c)::value;
+        rdA(Y, s, 1);
+        if constexpr (MODE == 0) { dma(s + 3, 0); dma(s + 3, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(X, Pc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 0) {
+            dma(s + 3, 2); dma(s + 3, 3);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else if constexpr (MODE == 1) {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else if constexpr (MODE == 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (MODE != 3) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(X, s + 1, 0);
+            rdB(Pn, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(Y, Pc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    bf16x8 Q[FN];
+
+    // prologue: half tiles 0, 1, 2 in flight; wait for 0   (host guarantees nh >= 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(2, i);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rdA(X, 0, 0);
+    rdB(P, 0);
+    int s = 0;
+    for (; s < nh - 4; s += 2) {
+        step(M0{}, s, P, Q);
+        step(M0{}, s + 1, Q, P);
+    }
+    step(M0{}, s, P, Q);
+    step(M1{}, s + 1, Q, P);
+    step(M2{}, s + 2, P, Q);
+    step(M3{}, s + 3, Q, P);
+    __syncthreads();
+    gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+}
+
+template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE, bool TNL>
+int launch_gemm(GemmArgs a, hipStream_t s);
+
+int launch_gemm_ring(GemmArgs a, hipStream_t s) {
+    if (a.K < 128) return launch_gemm<256, 256, 2, 4, true, 0, false>(a, s);
+    constexpr int LDS = 4 * (256 + 256) * 64;               // 128 KiB
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    a.ntm = (a.M + 255) / 256;
+    a.ntn = (a.N + 255) / 256;
+    const int64_t total = (int64_t)a.ntm * a.ntn;
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3((unsigned)total), dim3(512), LDS, s, a);
+    return mm_launch_status();
 }
 
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0, bool TNL = false>
@@ -490,7 +681,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 9; }
+extern "C" int mm355_gemm_num_variants(void) { return 10; }
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -526,6 +717,9 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
         case 9: return launch_gemm<256, 256, 2, 4, true, 5>(a, s);
+        case 10: return launch_gemm_ring(a, s);
+        case 96: return launch_gemm<256, 256, 2, 4, true, 6>(a, s);
+        case 97: return launch_gemm<256, 256, 2, 4, true, 7>(a, s);
         case 92: return launch_gemm<256, 256, 2, 4, true, 2>(a, s);   // ablations (wrong results, timing only)
         case 93: return launch_gemm<256, 256, 2, 4, true, 3>(a, s);
         case 94: return launch_gemm<256, 256, 2, 4, true, 4>(a, s);

@@ -55,11 +55,11 @@ GEMM_SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (512, 384, 1152
                (200, 1152, 592), (1024, 1024, 4096)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_plain(ops, variant, shape):
     M, N, K = shape
-    if K % 64 and variant in (2, 4, 6):
+    if K % 64 and variant in (2, 4, 6, 7, 8, 10):
         pytest.skip("LDS-DMA variants need K % 64 == 0")
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     ref = a.float() @ b.float().t()
@@ -67,7 +67,7 @@ def test_gemm_plain(ops, variant, shape):
     close(out, ref, 1e-2, 0.02 * math.sqrt(K), f"gemm v{variant} {shape}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6])
+@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10])
 def test_gemm_epilogues(ops, variant):
     M, N, K = 320, 256, 128
     a, b = rnd(M, K, seed=3, scale=0.3), rnd(N, K, seed=4, scale=0.3)
