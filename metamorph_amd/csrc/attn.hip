@@ -5,6 +5,7 @@
 // metamorph_llama.py:349-359) and by HF SiglipAttention (non-causal, d = 72; siglip_encoder.py:141).
 #include "mm355_common.h"
 #include "attn2.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -57,6 +58,12 @@ bool bad_geom(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d) {
     return B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7) || L > 0x7fffffff;
 }
 
+// d == 128 goes to the LDS-DMA kernels of attn3.hip (MM355_ATTN_GEN2=1 forces the generic kernels: A/B and test knob)
+bool fast128(int64_t d, int64_t ld_k) {
+    static const bool gen2 = [] { const char* e = std::getenv("MM355_ATTN_GEN2"); return e && e[0] == '1'; }();
+    return d == 128 && !gen2 && ld_k * 2 * 64 < 0x7fffffff;
+}
+
 }  // namespace
 
 extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
@@ -67,6 +74,7 @@ extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7)) return MM355_EINVAL;
     attn2::Args a{q, k, v, nullptr, ld_q, ld_k, ld_o, o, lse, nullptr, nullptr, nullptr, 0, seqlens,
                   nullptr, nullptr, nullptr, nullptr, 0, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
+    if (fast128(d, ld_k)) return mm355_attn3_fwd_launch(a, (hipStream_t)stream);
     return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
 }
 
@@ -96,7 +104,8 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
     }
     attn2::Args a{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
                   dk, dv, dkp, dvp, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
-    int rc = mm355_attn2_dkdv_launch(a, pick_dp(d), s);
+    const bool fast = fast128(d, std::max(std::max(ld_q, ld_k), ld_o));
+    int rc = fast ? mm355_attn3_dkdv_launch(a, s) : mm355_attn2_dkdv_launch(a, pick_dp(d), s);
     if (rc != MM355_OK) return rc;
     if (dkp) {
         const int64_t rows = B * L;
@@ -106,5 +115,5 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
         rc = mm_launch_status();
         if (rc != MM355_OK) return rc;
     }
-    return mm355_attn2_dq_launch(a, pick_dp(d), s);
+    return fast ? mm355_attn3_dq_launch(a, s) : mm355_attn2_dq_launch(a, pick_dp(d), s);
 }

@@ -11,8 +11,79 @@ struct Args {
     int B, L, Hq, Hkv, d;
     float scale; int causal;
 };
+
+#ifdef __HIPCC__
+constexpr int NT = 256;
+
+MM_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <int DP> struct Geo {
+    static constexpr int DS = DP == 64 ? 64 : 128;          // LDS row length (elements) of a [rows][d] tile
+    static constexpr int KS = DP / 32;                      // k-steps over d
+    static constexpr int NF = DP / 16;                      // 16-wide fragments over d
+    static constexpr int T64 = 64 * DS * 2;                 // bytes of a [64][DS] tile
+    static constexpr int V64 = 64 * (DP / 8);               // 16-B vectors of a [64][DP] tile
+};
+
+MM_DEV bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
+    u32x4 w;
+    w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]); w.z = pack2bf(b[0], b[1]); w.w = pack2bf(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int DS> MM_DEV int swzN(int row) { return DS == 128 ? 2 * (row & 7) : 2 * ((row >> 1) & 3); }
+template <int DS> MM_DEV int offN(int row, int chunk) { return row * (DS * 2) + ((chunk ^ swzN<DS>(row)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds4_t;
+
+// X[row0 + fq*4 + e][c16*16 + fr] (e < 4) and X[row0 + 16 + fq*4 + e - 4][c16*16 + fr] (e >= 4) from a natural tile
+template <int DS>
+MM_DEV bf16x8 read_nat_perm(const unsigned char* s, int row0, int c16, int fr, int fq) {
+    const int j = fr >> 2, q4 = fr & 3;
+    const int chunk = c16 * 2 + (q4 >> 1), sub = (q4 & 1) * 8;
+    const int r_lo = row0 + fq * 4 + j, r_hi = r_lo + 16;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(s + offN<DS>(r_lo, chunk) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(s + offN<DS>(r_hi, chunk) + sub));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// all-reduce over the four lanes {l, l^16, l^32, l^48} that share one query column, on the VALU (v_permlane*_swap), no LDS
+MM_DEV void swap16(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __uint_as_float(r0); b = __uint_as_float(r1);
+}
+MM_DEV void swap32(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __uint_as_float(r0); b = __uint_as_float(r1);
+}
+MM_DEV float quad_max(float x) {
+    float a = x, b = x;
+    asm volatile("" : "+v"(b));
+    swap16(a, b);
+    a = fmaxf(a, b); b = a;
+    asm volatile("" : "+v"(b));
+    swap32(a, b);
+    return fmaxf(a, b);
+}
+MM_DEV float quad_sum(float x) {
+    float a = x, b = x;
+    asm volatile("" : "+v"(b));
+    swap16(a, b);
+    a = a + b; b = a;
+    asm volatile("" : "+v"(b));
+    swap32(a, b);
+    return a + b;
+}
+#endif
 }  // namespace attn2
 
 int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s);
 int mm355_attn2_dq_launch(const attn2::Args& a, int dp, hipStream_t s);
 int mm355_attn2_dkdv_launch(const attn2::Args& a, int dp, hipStream_t s);
+// d == 128 fast paths (attn3.hip): LDS-DMA staged, double-buffered
+int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s);
+int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s);
+int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s);

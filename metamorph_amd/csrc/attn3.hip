@@ -1,0 +1,528 @@
+// Attention, d == 128 fast path (gfx950): the formulation of attn2.hip (swapped products on natural [rows][128] tiles, P^T / dS^T
+// never leave registers) with the staging rebuilt around the LDS-DMA engine:
+//   * K / V tiles of 64 keys go HBM -> LDS with global_load_lds_dwordx4 (1 KiB = 4 tile rows per wave instruction; the XOR
+//     swizzle is applied on the per-lane SOURCE address, the LDS side is lane-linear) into a two-deep ring, so a tile costs
+//     no VGPRs, no ds_write and ONE barrier; tile t+1 is in flight while tile t is consumed
+//   * a wave owns 32 query rows (two 16-column fragments) and re-uses every K / V fragment read for both
+//   * the row maximum is all-reduced on the VALU (v_permlane16/32_swap); row sums stay per lane until the epilogue
+//   * heavy (late) causal query blocks are launched first
+// Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
+#include "attn2.h"
+
+namespace attn3 {
+using namespace attn2;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int DP = 128;
+constexpr int DS = 128;
+constexpr int TILE = 64 * DS * 2;                            // 16 KiB: [64 rows][128] bf16
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float M_INIT = -1.0e30f;                           // finite "minus infinity" of the running maximum (log2 domain)
+
+// per-lane source byte offsets of the four 1-KiB pieces a wave moves per tile: piece p = wave*4 + i covers tile rows 4p..4p+3
+struct TileSrc {
+    uint32_t off[4];
+    MM_DEV void init(int wave, int lane, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swzN<DS>(row);       // logical chunk that belongs in physical slot (lane & 15)
+            off[i] = (uint32_t)(row * ld * 2 + c * 16);
+        }
+    }
+};
+
+// tile rows [row0, row0 + 64) of a [L][ld] matrix -> LDS tile `dst` (this wave's four pieces)
+MM_DEV void dma_tile(const uint16_t* base, int64_t ld, int row0, int L, const TileSrc& ts, unsigned char* dst, int wave_s, int lane) {
+    unsigned char* d0 = dst + wave_s * 4096;
+    if (row0 + 64 <= L) {
+        const unsigned char* tb = (const unsigned char*)(base + (int64_t)row0 * ld);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(tb + ts.off[i]), (lptr_t)(d0 + i * 1024), 16, 0, 0);
+    } else {                                                 // ragged last tile: clamp the rows (masked by the caller)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave_s * 4 + i) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swzN<DS>(row);
+            const uint16_t* src = base + (int64_t)min(row0 + row, L - 1) * ld + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d0 + i * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// ================================================================================================
+// forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
+// ================================================================================================
+__global__ __launch_bounds__(256) void fwd_kernel(Args a) {
+    constexpr int KS = 4, NF = 8, RQ = 2, ROWS = 32, BQ = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * BQ, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    uint16_t* o_base = a.o + row_base * a.ld_o + (int64_t)hq * DP;
+    float* lse_base = a.lse + ((int64_t)b * a.Hq + hq) * L;
+
+    if (q0 >= seqlen) {                                      // whole block is padding: o = 0, lse = 0
+        for (int v = tid; v < BQ * (DP / 8); v += 256) {
+            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+            if (q0 + r < L) *(u32x4*)(o_base + (int64_t)(q0 + r) * a.ld_o + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int r = tid; r < BQ; r += 256)
+            if (q0 + r < L) lse_base[q0 + r] = 0.f;
+        return;
+    }
+
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * DP;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * DP;
+    TileSrc ts;
+    ts.init(wave, lane, a.ld_k);
+    dma_tile(kbase, a.ld_k, 0, L, ts, smem, wave, lane);
+    dma_tile(vbase, a.ld_k, 0, L, ts, smem + 2 * TILE, wave, lane);
+
+    const int qw0 = q0 + wave * ROWS;                        // first query row of this wave
+    bf16x8 qf[RQ][KS];                                       // B operand: Q[q = fr][d chunk]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const uint16_t* qp = a.q + (row_base + min(qw0 + rq * 16 + fr, L - 1)) * a.ld_q + (int64_t)hq * DP;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
+    }
+    f32x4 ot[RQ][NF];                                        // O^T[d = j*16 + fq*4 + r][q = fr]
+    float m_run[RQ], l_part[RQ];                             // l_part: this lane's share of the row sum
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        m_run[rq] = M_INIT; l_part[rq] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) ot[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // LDS read offsets inside a tile: K rows (b128) and V gathers (tr_b64)
+    int k_off[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);        // + j * 16 rows = j * 4096 B (swizzle period 8 rows)
+    const float sl2 = a.scale * LOG2E;                       // scores in log2 domain: exp2(s*sl2 - m)
+    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                        // everybody's have; everybody is done with tile t-1
+        if (t + 1 < ntiles) {
+            dma_tile(kbase, a.ld_k, kv0 + 64, L, ts, smem + ((t + 1) & 1) * TILE, wave, lane);
+            dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
+        }
+        const unsigned char* sK = smem + (t & 1) * TILE;
+        const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
+        // a wave whose rows all precede this tile (causal) has nothing to do here
+        if (a.causal && kv0 > qw0 + ROWS - 1) continue;
+
+        f32x4 st[RQ][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+            }
+        }
+        const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            if (need_mask) {
+                const int qg = qw0 + rq * 16 + fr;
+                const int kmax = a.causal ? min(qg, seqlen - 1) : seqlen - 1;        // last visible key
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + j * 16 + fq * 4 + r > kmax) st[rq][j][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(st[rq][0][0], st[rq][0][1]), fmaxf(st[rq][0][2], st[rq][0][3]));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(st[rq][j][0], st[rq][j][1]), fmaxf(st[rq][j][2], st[rq][j][3])));
+            mx = quad_max(mx) * sl2;                         // max of the RAW scores (scale > 0 commutes with max)
+            // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew by more
+            // than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR)
+            if (__any(mx > m_run[rq] + RESCALE_THR)) {
+                const float mn = fmaxf(m_run[rq], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
+                l_part[rq] *= alpha;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+                m_run[rq] = mn;
+            }
+            const float mref = m_run[rq];
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
+                    st[rq][j][r] = p;
+                    rs += p;
+                }
+            l_part[rq] += rs;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pb[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);          // V^T[d][keys perm]
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+            }
+        }
+    }
+    __syncthreads();                                         // ring is free: reuse it as the output staging area
+
+    // epilogue: O = O^T / l  -> bf16 [q][d] in LDS -> row-contiguous 16-B stores
+    unsigned char* so = smem + wave * (ROWS * DP * 2);
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qg = qw0 + rq * 16 + fr;
+        const bool valid = qg < seqlen;
+        const float l_run = quad_sum(l_part[rq]);
+        const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            u32x2 w;
+            w.x = pack2bf(ot[rq][j][0] * inv, ot[rq][j][1] * inv);
+            w.y = pack2bf(ot[rq][j][2] * inv, ot[rq][j][3] * inv);
+            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+        }
+        if (fq == 0 && qg < L) lse_base[qg] = valid ? (m_run[rq] + log2f(l_run)) * 0.6931471805599453f : 0.f;
+    }
+    __syncthreads();
+    for (int v = lane; v < ROWS * (DP / 8); v += 64) {
+        const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+        const int qg = qw0 + r;
+        if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+// ================================================================================================
+// dQ: workgroup = 128 query rows (4 waves x 32); per KV tile S^T = K Q^T and dP^T = V dO^T share the fragment reads of both
+// 16-row groups, dS^T feeds dQ^T += K^T dS^T from registers; bf16 result written straight to its column block
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
+    constexpr int KS = 4, NF = 8, RQ = 2, ROWS = 32, BQ = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * BQ, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    uint16_t* dq_base = a.dqb + row_base * a.ld_dq + (int64_t)hq * DP;
+
+    if (q0 >= seqlen) {                                      // padded query rows carry zero gradient
+        for (int v = tid; v < BQ * (DP / 8); v += 256) {
+            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+            if (q0 + r < L) *(u32x4*)(dq_base + (int64_t)(q0 + r) * a.ld_dq + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * DP;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * DP;
+    TileSrc ts;
+    ts.init(wave, lane, a.ld_k);
+    dma_tile(kbase, a.ld_k, 0, L, ts, smem, wave, lane);
+    dma_tile(vbase, a.ld_k, 0, L, ts, smem + 2 * TILE, wave, lane);
+
+    const int qw0 = q0 + wave * ROWS;
+    bf16x8 qf[RQ][KS], dof[RQ][KS];
+    float lse2[RQ], del[RQ];
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qc = min(qw0 + rq * 16 + fr, L - 1);
+        const uint16_t* qp = a.q + (row_base + qc) * a.ld_q + (int64_t)hq * DP;
+        const uint16_t* dp = a.d_o + (row_base + qc) * a.ld_o + (int64_t)hq * DP;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
+            dof[rq][kk] = *(const bf16x8*)(dp + kk * 32 + fq * 8);
+        }
+        lse2[rq] = a.lse_in[((int64_t)b * a.Hq + hq) * L + qc] * LOG2E;            // log2 domain
+        del[rq] = a.delta[((int64_t)b * a.Hq + hq) * L + qc];
+    }
+    f32x4 dqt[RQ][NF];                                       // dQ^T[d = j*16 + fq*4 + r][q = fr]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) dqt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k_off[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
+    const float sl2 = a.scale * LOG2E;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntiles) {
+            dma_tile(kbase, a.ld_k, kv0 + 64, L, ts, smem + ((t + 1) & 1) * TILE, wave, lane);
+            dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
+        }
+        const unsigned char* sK = smem + (t & 1) * TILE;
+        const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
+        if (a.causal && kv0 > qw0 + ROWS - 1) continue;
+
+        f32x4 st[RQ][4], dpt[RQ][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+                const bf16x8 vf = *(const bf16x8*)(sV + j * 4096 + k_off[kk]);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) {
+                    st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                    dpt[rq][j] = mfma16(vf, dof[rq][kk], dpt[rq][j]);
+                }
+            }
+        }
+        const bool need_mask = (kv0 + 64 > seqlen) || (qw0 + ROWS > seqlen) || (a.causal && kv0 + 63 > qw0);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            const int qg = qw0 + rq * 16 + fr;
+            const int kmax = qg >= seqlen ? -1 : (a.causal ? min(qg, seqlen - 1) : seqlen - 1);      // last visible key
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -lse2[rq]));
+                    if (need_mask && kv0 + j * 16 + fq * 4 + r > kmax) p = 0.f;
+                    st[rq][j][r] = p * (dpt[rq][j][r] - del[rq]) * a.scale;             // dS^T
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 sb[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) sb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 ka = read_nat_perm<DS>(sK, kk * 32, j, fr, fq);          // K^T[d][keys perm]
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) dqt[rq][j] = mfma16(ka, sb[rq], dqt[rq][j]);
+            }
+        }
+    }
+    __syncthreads();
+    // dq[q][d] bf16 -> LDS [32 q][128] per wave -> row-contiguous 16-B stores (rows >= seqlen are zero)
+    unsigned char* so = smem + wave * (ROWS * DP * 2);
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const float keep = (qw0 + rq * 16 + fr) < seqlen ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            u32x2 w;
+            w.x = pack2bf(dqt[rq][j][0] * keep, dqt[rq][j][1] * keep);
+            w.y = pack2bf(dqt[rq][j][2] * keep, dqt[rq][j][3] * keep);
+            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+        }
+    }
+    __syncthreads();
+    for (int v = lane; v < ROWS * (DP / 8); v += 64) {
+        const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+        if (qw0 + r < L) *(u32x4*)(dq_base + (int64_t)(qw0 + r) * a.ld_dq + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+// ================================================================================================
+// dK / dV: workgroup = (KV tile of 64 keys, query head); wave owns 16 keys (K / V fragments in registers) and loops over 64-row
+// query tiles whose Q / dO rows and lse / delta arrive by LDS-DMA into a two-deep ring; GQA groups are summed afterwards
+// from fp32 partials
+// ================================================================================================
+__global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
+    constexpr int KS = 4, NF = 8, QT = 64;
+    constexpr int STAT = 512;                                // lse[64] | delta[64] fp32 per ring slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // Q ring [2] | dO ring [2] | stats [2]  (65 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int group = a.Hq / a.Hkv;
+    const int kv0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64, hq = blockIdx.y, b = blockIdx.z;   // (non-causal: order is irrelevant)
+    const int hk = hq / group;
+    const int L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    const int mykey0 = kv0 + wave * 16;
+    const int64_t ld_p = (int64_t)a.Hq * DP;
+
+    auto store_rows = [&](const f32x4 (&acc)[NF], bool is_dv, bool zero) {
+        // wave's 16 keys x d -> LDS (fp32) -> row-contiguous stores (fp32 partial or bf16 direct)
+        float* so = (float*)smem + wave * (16 * DP);
+        if (!zero) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(fq * 4 + r) * DP + j * 16 + fr] = acc[j][r];
+        }
+        __syncthreads();
+        for (int v = lane; v < 16 * (DP / 8); v += 64) {
+            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+            const int key = mykey0 + r;
+            if (key >= L) continue;
+            f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (!zero) { x0 = *(const f32x4*)(so + r * DP + c); x1 = *(const f32x4*)(so + r * DP + c + 4); }
+            if (a.dkp) {
+                float* pp = (is_dv ? a.dvp : a.dkp) + (row_base + key) * ld_p + (int64_t)hq * DP + c;
+                *(f32x4*)pp = x0; *(f32x4*)(pp + 4) = x1;
+            } else {
+                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                *(u32x4*)((is_dv ? a.dv : a.dk) + (row_base + key) * a.ld_dkv + (int64_t)hk * DP + c) = pack8(f);
+            }
+        }
+        __syncthreads();
+    };
+
+    f32x4 dkacc[NF], dvacc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) { dkacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (kv0 >= seqlen) {                                     // keys are all padding: zero gradients
+        store_rows(dkacc, false, true);
+        store_rows(dvacc, true, true);
+        return;
+    }
+    const int q_start = a.causal ? kv0 : 0;                  // kv0 is a multiple of 64 = QT
+    const int n_it = seqlen > q_start ? (seqlen - q_start + QT - 1) / QT : 0;
+    const uint16_t* qb = a.q + row_base * a.ld_q + (int64_t)hq * DP;
+    const uint16_t* dob = a.d_o + row_base * a.ld_o + (int64_t)hq * DP;
+    const float* lse_b = a.lse_in + ((int64_t)b * a.Hq + hq) * L;
+    const float* del_b = a.delta + ((int64_t)b * a.Hq + hq) * L;
+    TileSrc tq, td;
+    tq.init(wave, lane, a.ld_q);
+    td.init(wave, lane, a.ld_o);
+    auto fetch = [&](int it) {                               // Q / dO / stats of query tile `it` -> ring slot it & 1
+        const int qt0 = q_start + it * QT, slot = it & 1;
+        dma_tile(qb, a.ld_q, qt0, L, tq, smem + slot * TILE, wave, lane);
+        dma_tile(dob, a.ld_o, qt0, L, td, smem + (2 + slot) * TILE, wave, lane);
+        if (wave < 2) {                                      // wave 0: lse, wave 1: delta (64 floats = one 256-B piece each)
+            const float* sp = (wave == 0 ? lse_b : del_b) + min(qt0 + lane, L - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(smem + 4 * TILE + slot * STAT + wave * 256), 4, 0, 0);
+        }
+    };
+    if (n_it > 0) fetch(0);
+
+    // K / V fragments of this wave's 16 keys (B operands): lane holds X[key = fr][kk*32 + fq*8 ..]
+    bf16x8 kf[KS], vf[KS];
+    {
+        const int key = min(mykey0 + fr, L - 1);
+        const uint16_t* kp = a.k + (row_base + key) * a.ld_k + (int64_t)hk * DP;
+        const uint16_t* vp = a.v + (row_base + key) * a.ld_k + (int64_t)hk * DP;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32 + fq * 8);
+            vf[kk] = *(const bf16x8*)(vp + kk * 32 + fq * 8);
+        }
+    }
+    int k_off[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
+    const float sl2 = a.scale * LOG2E;
+    const int kg = mykey0 + fr;
+
+    for (int it = 0; it < n_it; ++it) {
+        const int qt0 = q_start + it * QT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 < n_it) fetch(it + 1);
+        const unsigned char* sQ = smem + (it & 1) * TILE;
+        const unsigned char* sDO = smem + (2 + (it & 1)) * TILE;
+        const float* sStat = (const float*)(smem + 4 * TILE + (it & 1) * STAT);
+
+        // S[i], dP[i] for the four 16-row fragments: lane holds X[q = i*16 + fq*4 + r][key = fr]
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const bf16x8 qa = *(const bf16x8*)(sQ + i * 4096 + k_off[kk]);
+                const bf16x8 da = *(const bf16x8*)(sDO + i * 4096 + k_off[kk]);
+                s[i] = mfma16(qa, kf[kk], s[i]);
+                dp[i] = mfma16(da, vf[kk], dp[i]);
+            }
+        }
+        const bool need_mask = (qt0 + QT > seqlen) || (kv0 + 64 > seqlen) || (a.causal && qt0 < kv0 + 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
+            const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
+                if (need_mask) {
+                    const int qg = qt0 + i * 16 + fq * 4 + r;
+                    if (!((qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg))) p = 0.f;
+                }
+                s[i][r] = p;
+                dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;                  // dS
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
+            const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 dob8 = read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
+                const bf16x8 qb8 = read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
+                dvacc[j] = mfma16(pa, dob8, dvacc[j]);
+                dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
+            }
+        }
+    }
+    __syncthreads();
+    store_rows(dkacc, false, false);
+    store_rows(dvacc, true, false);
+}
+
+}  // namespace attn3
+
+int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.L + 127) / 128), (unsigned)a.Hq, (unsigned)a.B);
+    hipLaunchKernelGGL(attn3::fwd_kernel, grid, dim3(256), 0, s, a);
+    return mm_launch_status();
+}
+
+int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.L + 127) / 128), (unsigned)a.Hq, (unsigned)a.B);
+    hipLaunchKernelGGL(attn3::dq_kernel, grid, dim3(256), 0, s, a);
+    return mm_launch_status();
+}
+
+int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
+    constexpr int LDS = 4 * attn3::TILE + 2 * 512;           // 65 KiB > the default cap: raise it once
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((a.L + 63) / 64), (unsigned)a.Hq, (unsigned)a.B);
+    hipLaunchKernelGGL(attn3::dkdv_kernel, grid, dim3(256), LDS, s, a);
+    return mm_launch_status();
+}

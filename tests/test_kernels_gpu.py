@@ -207,6 +207,9 @@ ATT_CASES = [  # B, L, Hq, Hkv, d, causal, seqlens
     (2, 100, 3, 3, 72, False, None),
     (1, 729, 2, 2, 72, False, None),
     (2, 333, 8, 2, 128, True, [333, 256]),
+    (1, 513, 4, 2, 128, True, None),                    # d == 128 LDS-DMA kernels: several 128-row query blocks, ragged tail
+    (2, 200, 2, 2, 128, False, [200, 77]),
+    (2, 256, 4, 1, 128, True, [1, 256]),
 ]
 
 
