@@ -52,6 +52,20 @@ MM_DEV void dma_tile(const uint16_t* base, int64_t ld, int row0, int L, const Ti
     }
 }
 
+// 1-D grid -> (x, head, sample) with all blocks that share K / V (fwd, dQ: the query blocks of a GQA group) or Q / dO (dK/dV:
+// the key blocks of a query head) on ONE XCD, so the shared tiles stay in that XCD's 4-MiB L2: hardware deals consecutive
+// block ids round-robin over the 8 XCDs, so XCD x is given the x-th contiguous eighth of the logical order
+// (x fastest, then head, then sample).  x is reversed: heavy (late) causal blocks first.
+MM_DEV void block_coords(int nx, int Hq, int& x, int& hq, int& b) {
+    const int total = gridDim.x, bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    x = nx - 1 - logical % nx;
+    const int rest = logical / nx;
+    hq = rest % Hq;
+    b = rest / Hq;
+}
+
 // ================================================================================================
 // forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
 // ================================================================================================
@@ -61,7 +75,9 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * BQ, hq = blockIdx.y, b = blockIdx.z;
+    int xb, hq, b;
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, xb, hq, b);
+    const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
@@ -224,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * BQ, hq = blockIdx.y, b = blockIdx.z;
+    int xb, hq, b;
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, xb, hq, b);
+    const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
@@ -362,7 +380,9 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int group = a.Hq / a.Hkv;
-    const int kv0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64, hq = blockIdx.y, b = blockIdx.z;   // (non-causal: order is irrelevant)
+    int xb, hq, b;
+    block_coords((a.L + 63) / 64, a.Hq, xb, hq, b);
+    const int kv0 = xb * 64;
     const int hk = hq / group;
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
@@ -503,13 +523,17 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
 }  // namespace attn3
 
 int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.L + 127) / 128), (unsigned)a.Hq, (unsigned)a.B);
+    const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
+    if (nblk > 0x7fffffff) return MM355_EINVAL;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(attn3::fwd_kernel, grid, dim3(256), 0, s, a);
     return mm_launch_status();
 }
 
 int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.L + 127) / 128), (unsigned)a.Hq, (unsigned)a.B);
+    const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
+    if (nblk > 0x7fffffff) return MM355_EINVAL;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(attn3::dq_kernel, grid, dim3(256), 0, s, a);
     return mm_launch_status();
 }
@@ -522,7 +546,9 @@ int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
             return MM355_ELAUNCH;
         attr_done = true;
     }
-    dim3 grid((unsigned)((a.L + 63) / 64), (unsigned)a.Hq, (unsigned)a.B);
+    const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hq * a.B;
+    if (nblk > 0x7fffffff) return MM355_EINVAL;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(attn3::dkdv_kernel, grid, dim3(256), LDS, s, a);
     return mm_launch_status();
 }
