@@ -94,17 +94,18 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (ld_dq & 7)) return MM355_EINVAL;
-    if (Hq != Hkv && !workspace) return MM355_EINVAL;        // GQA: the group is summed from fp32 partials in the workspace
+    const bool fast = fast128(d, std::max(std::max(ld_q, ld_k), ld_o));
+    // GQA on the generic kernels: the group is summed from fp32 partials in the workspace (the d == 128 kernel sums in registers)
+    if (Hq != Hkv && !fast && !workspace) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* dkp = nullptr;
     float* dvp = nullptr;
-    if (Hq != Hkv) {
+    if (Hq != Hkv && !fast) {
         dkp = workspace;
         dvp = workspace + (int64_t)B * L * Hq * d;
     }
     attn2::Args a{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
                   dk, dv, dkp, dvp, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
-    const bool fast = fast128(d, std::max(std::max(ld_q, ld_k), ld_o));
     int rc = fast ? mm355_attn3_dkdv_launch(a, s) : mm355_attn2_dkdv_launch(a, pick_dp(d), s);
     if (rc != MM355_OK) return rc;
     if (dkp) {

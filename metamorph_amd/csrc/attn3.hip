@@ -8,6 +8,7 @@
 //   * heavy (late) causal query blocks are launched first
 // Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
 #include "attn2.h"
+#include <type_traits>
 
 namespace attn3 {
 using namespace attn2;
@@ -55,12 +56,13 @@ MM_DEV void dma_tile(const uint16_t* base, int64_t ld, int row0, int L, const Ti
 // 1-D grid -> (x, head, sample) with all blocks that share K / V (fwd, dQ: the query blocks of a GQA group) or Q / dO (dK/dV:
 // the key blocks of a query head) on ONE XCD, so the shared tiles stay in that XCD's 4-MiB L2: hardware deals consecutive
 // block ids round-robin over the 8 XCDs, so XCD x is given the x-th contiguous eighth of the logical order
-// (x fastest, then head, then sample).  x is reversed: heavy (late) causal blocks first.
-MM_DEV void block_coords(int nx, int Hq, int& x, int& hq, int& b) {
+// (x fastest, then head, then sample).  `reverse` walks x downwards: causal work grows with the query block index (fwd, dQ)
+// and shrinks with the key block index (dK/dV); the heavy blocks go first either way.
+MM_DEV void block_coords(int nx, int Hq, bool reverse, int& x, int& hq, int& b) {
     const int total = gridDim.x, bid = blockIdx.x;
     const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    x = nx - 1 - logical % nx;
+    x = reverse ? nx - 1 - logical % nx : logical % nx;
     const int rest = logical / nx;
     hq = rest % Hq;
     b = rest / Hq;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, xb, hq, b);
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
     const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
@@ -157,12 +159,11 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
         for (int rq = 0; rq < RQ; ++rq) {
             if (need_mask) {
                 const int qg = qw0 + rq * 16 + fr;
-                const int kmax = a.causal ? min(qg, seqlen - 1) : seqlen - 1;        // last visible key
+                const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kv0 + j * 16 + fq * 4 + r > kmax) st[rq][j][r] = -INFINITY;
+                    for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
             }
             float mx = fmaxf(fmaxf(st[rq][0][0], st[rq][0][1]), fmaxf(st[rq][0][2], st[rq][0][3]));
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, xb, hq, b);
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
     const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
@@ -303,36 +304,45 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
         const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
         if (a.causal && kv0 > qw0 + ROWS - 1) continue;
 
-        f32x4 st[RQ][4], dpt[RQ][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
-                const bf16x8 vf = *(const bf16x8*)(sV + j * 4096 + k_off[kk]);
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-                    st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
-                    dpt[rq][j] = mfma16(vf, dof[rq][kk], dpt[rq][j]);
-                }
-            }
-        }
+        // per 16-key group j: S^T and dP^T for both row groups, then dS^T = P^T o (dP^T - delta) * scale in place of S^T
+        // (dP^T is transient: 8 registers instead of 32)
         const bool need_mask = (kv0 + 64 > seqlen) || (qw0 + ROWS > seqlen) || (a.causal && kv0 + 63 > qw0);
+        int lim[RQ];
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
             const int qg = qw0 + rq * 16 + fr;
             const int kmax = qg >= seqlen ? -1 : (a.causal ? min(qg, seqlen - 1) : seqlen - 1);      // last visible key
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -lse2[rq]));
-                    if (need_mask && kv0 + j * 16 + fq * 4 + r > kmax) p = 0.f;
-                    st[rq][j][r] = p * (dpt[rq][j][r] - del[rq]) * a.scale;             // dS^T
-                }
+            lim[rq] = kmax - kv0 - fq * 4;
         }
+        f32x4 st[RQ][4];
+        auto scores = [&](auto mask_c) {
+            constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 dpt[RQ];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+                    const bf16x8 vf = *(const bf16x8*)(sV + j * 4096 + k_off[kk]);
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) {
+                        st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                        dpt[rq] = mfma16(vf, dof[rq][kk], dpt[rq]);
+                    }
+                }
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -lse2[rq]));
+                        if (MASK) p = (j * 16 + r > lim[rq]) ? 0.f : p;
+                        st[rq][j][r] = p * (dpt[rq][r] - del[rq]) * a.scale;
+                    }
+            }
+        };
+        if (need_mask) scores(std::true_type{}); else scores(std::false_type{});
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 sb[RQ];
@@ -368,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
 }
 
 // ================================================================================================
-// dK / dV: workgroup = (KV tile of 64 keys, query head); wave owns 16 keys (K / V fragments in registers) and loops over 64-row
-// query tiles whose Q / dO rows and lse / delta arrive by LDS-DMA into a two-deep ring; GQA groups are summed afterwards
-// from fp32 partials
+// dK / dV: workgroup = (KV tile of 64 keys, KV head); wave owns 16 keys (K / V fragments in registers) and walks the 64-row
+// query tiles of every query head of its GQA group, whose Q / dO rows and lse / delta arrive by LDS-DMA into a two-deep ring;
+// the group sum happens in the accumulators (no partials, no atomics)
 // ================================================================================================
 __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     constexpr int KS = 4, NF = 8, QT = 64;
@@ -380,15 +390,13 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int group = a.Hq / a.Hkv;
-    int xb, hq, b;
-    block_coords((a.L + 63) / 64, a.Hq, xb, hq, b);
+    int xb, hk, b;
+    block_coords((a.L + 63) / 64, a.Hkv, false, xb, hk, b);        // one block per KV head: it walks the query heads of its group
     const int kv0 = xb * 64;
-    const int hk = hq / group;
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
     const int64_t row_base = (int64_t)b * L;
     const int mykey0 = kv0 + wave * 16;
-    const int64_t ld_p = (int64_t)a.Hq * DP;
 
     auto store_rows = [&](const f32x4 (&acc)[NF], bool is_dv, bool zero) {
         // wave's 16 keys x d -> LDS (fp32) -> row-contiguous stores (fp32 partial or bf16 direct)
@@ -406,13 +414,8 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
             if (key >= L) continue;
             f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
             if (!zero) { x0 = *(const f32x4*)(so + r * DP + c); x1 = *(const f32x4*)(so + r * DP + c + 4); }
-            if (a.dkp) {
-                float* pp = (is_dv ? a.dvp : a.dkp) + (row_base + key) * ld_p + (int64_t)hq * DP + c;
-                *(f32x4*)pp = x0; *(f32x4*)(pp + 4) = x1;
-            } else {
-                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                *(u32x4*)((is_dv ? a.dv : a.dk) + (row_base + key) * a.ld_dkv + (int64_t)hk * DP + c) = pack8(f);
-            }
+            const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            *(u32x4*)((is_dv ? a.dv : a.dk) + (row_base + key) * a.ld_dkv + (int64_t)hk * DP + c) = pack8(f);
         }
         __syncthreads();
     };
@@ -427,23 +430,24 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     }
     const int q_start = a.causal ? kv0 : 0;                  // kv0 is a multiple of 64 = QT
     const int n_it = seqlen > q_start ? (seqlen - q_start + QT - 1) / QT : 0;
-    const uint16_t* qb = a.q + row_base * a.ld_q + (int64_t)hq * DP;
-    const uint16_t* dob = a.d_o + row_base * a.ld_o + (int64_t)hq * DP;
-    const float* lse_b = a.lse_in + ((int64_t)b * a.Hq + hq) * L;
-    const float* del_b = a.delta + ((int64_t)b * a.Hq + hq) * L;
+    const int n_tot = n_it * group;                          // flattened (query head of the group, query tile) walk
+    const uint16_t* qb = a.q + row_base * a.ld_q + (int64_t)hk * group * DP;
+    const uint16_t* dob = a.d_o + row_base * a.ld_o + (int64_t)hk * group * DP;
+    const float* lse_b = a.lse_in + ((int64_t)b * a.Hq + hk * group) * L;
+    const float* del_b = a.delta + ((int64_t)b * a.Hq + hk * group) * L;
     TileSrc tq, td;
     tq.init(wave, lane, a.ld_q);
     td.init(wave, lane, a.ld_o);
-    auto fetch = [&](int it) {                               // Q / dO / stats of query tile `it` -> ring slot it & 1
-        const int qt0 = q_start + it * QT, slot = it & 1;
-        dma_tile(qb, a.ld_q, qt0, L, tq, smem + slot * TILE, wave, lane);
-        dma_tile(dob, a.ld_o, qt0, L, td, smem + (2 + slot) * TILE, wave, lane);
+    auto fetch = [&](int u) {                                // Q / dO / stats of walk step u -> ring slot u & 1
+        const int g = u / n_it, qt0 = q_start + (u - g * n_it) * QT, slot = u & 1;
+        dma_tile(qb + g * DP, a.ld_q, qt0, L, tq, smem + slot * TILE, wave, lane);
+        dma_tile(dob + g * DP, a.ld_o, qt0, L, td, smem + (2 + slot) * TILE, wave, lane);
         if (wave < 2) {                                      // wave 0: lse, wave 1: delta (64 floats = one 256-B piece each)
-            const float* sp = (wave == 0 ? lse_b : del_b) + min(qt0 + lane, L - 1);
+            const float* sp = (wave == 0 ? lse_b : del_b) + (int64_t)g * L + min(qt0 + lane, L - 1);
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(smem + 4 * TILE + slot * STAT + wave * 256), 4, 0, 0);
         }
     };
-    if (n_it > 0) fetch(0);
+    if (n_tot > 0) fetch(0);
 
     // K / V fragments of this wave's 16 keys (B operands): lane holds X[key = fr][kk*32 + fq*8 ..]
     bf16x8 kf[KS], vf[KS];
@@ -463,11 +467,11 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     const float sl2 = a.scale * LOG2E;
     const int kg = mykey0 + fr;
 
-    for (int it = 0; it < n_it; ++it) {
-        const int qt0 = q_start + it * QT;
+    for (int it = 0, itq = 0; it < n_tot; ++it, itq = (itq + 1 == n_it ? 0 : itq + 1)) {
+        const int qt0 = q_start + itq * QT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 < n_it) fetch(it + 1);
+        if (it + 1 < n_tot) fetch(it + 1);
         const unsigned char* sQ = smem + (it & 1) * TILE;
         const unsigned char* sDO = smem + (2 + (it & 1)) * TILE;
         const float* sStat = (const float*)(smem + 4 * TILE + (it & 1) * STAT);
@@ -487,21 +491,26 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
             }
         }
         const bool need_mask = (qt0 + QT > seqlen) || (kv0 + 64 > seqlen) || (a.causal && qt0 < kv0 + 64);
+        auto softmax_bwd = [&](auto mask_c) {               // P in place of S, dS = P o (dP - delta) * scale in place of dP
+            constexpr bool MASK = decltype(mask_c)::value;
+            // visible query rows of this lane's key: [qmin, seqlen) -> tile-relative window [lo, lo + span)
+            const int qmin = kg >= seqlen ? seqlen : (a.causal ? kg : 0);
+            const int lo = qmin - qt0 - fq * 4;
+            const unsigned span = (unsigned)(seqlen - qmin);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
-            const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
+                const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
-                if (need_mask) {
-                    const int qg = qt0 + i * 16 + fq * 4 + r;
-                    if (!((qg < seqlen) && (kg < seqlen) && (!a.causal || kg <= qg))) p = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
+                    if (MASK) p = ((unsigned)(i * 16 + r - lo) < span) ? p : 0.f;
+                    s[i][r] = p;
+                    dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;
                 }
-                s[i][r] = p;
-                dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;                  // dS
             }
-        }
+        };
+        if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
@@ -546,7 +555,7 @@ int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
             return MM355_ELAUNCH;
         attr_done = true;
     }
-    const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hq * a.B;
+    const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hkv * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(attn3::dkdv_kernel, grid, dim3(256), LDS, s, a);

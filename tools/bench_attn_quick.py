@@ -9,7 +9,7 @@ def t(fn, it=10):
     s.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)/it
-B, L, Hq, Hkv, d = 4, 2048, 32, 8, 128
+B, L, Hq, Hkv, d = int(os.environ.get('B', 4)), 2048, 32, 8, 128
 qkv = (torch.randn(B * L, (Hq + 2 * Hkv) * d, device="cuda") * 0.5).bfloat16()
 q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
 fl = 4.0 * B * Hq * L * L * d / 2
