@@ -88,7 +88,7 @@ class GemmTimer:
             e.record()
             M, K = a.shape
             N = kw.get("n") or b.shape[0]
-            self.records.append((s, e, 2.0 * M * N * K))
+            self.records.append((s, e, 2.0 * M * N * K, (M, N, K)))
             return r
         self.ops.gemm = timed
         import metamorph_amd.functional as F
@@ -96,8 +96,15 @@ class GemmTimer:
 
     def summary(self):
         torch.cuda.synchronize()
-        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
-        fl = sum(f for _, _, f in self.records)
+        t = sum(s.elapsed_time(e) for s, e, _, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f, _ in self.records)
+        if os.environ.get("MM355_BENCH_GEMM_TABLE") == "1":   # per-shape breakdown on stderr (tuning aid)
+            by = {}
+            for s, e, f, shp in self.records:
+                c = by.setdefault(shp, [0, 0.0, 0.0])
+                c[0] += 1; c[1] += s.elapsed_time(e) * 1e-3; c[2] += f
+            for shp, (n, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                print(f"[gemm] M,N,K={shp} calls={n} total={tt * 1e3:8.2f} ms  {ff / tt / 1e12:7.1f} TF/s", file=sys.stderr)
         return len(self.records), t, fl
 
 

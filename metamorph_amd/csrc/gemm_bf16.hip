@@ -588,8 +588,211 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs a) {
     gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ping-pong 256x256x64 kernel.  The eight waves form two groups (wave w and w + 4 share a SIMD; group = M half of the tile)
+// that run ONE BARRIER APART: while one group issues its 16-MFMA cluster (one 64x32 quadrant of its 128x64 output x K = 64),
+// the other does everything else (fragment ds_reads for its next cluster, two LDS-DMA pieces, counted waits), then they swap.
+// The matrix pipe of every SIMD always has exactly one wave feeding it and nothing else competes for issue in that wave.
+//   phase p of a K tile (per wave):  quadrant   fragments read in the load section      LDS-DMA issued (one 16-KiB quarter tile)
+//        0                            (a0, b0)   B cols block 0 of THIS tile             quarter phi + 6 in need order
+//        1                            (a0, b1)   B cols block 1
+//        2                            (a1, b1)   A rows block 1
+//        3                            (a1, b0)   A rows block 0 of the NEXT tile
+// A K tile is staged as four quarters in the order they are first needed (A rows 0-63 of both halves, B cols 0-31 of each wave
+// column, B cols 32-63, A rows 64-127) into a two-tile ring; quarter s is issued in phase s - 6, needed in phase s - 1, and
+// overwrites quarter s - 8, whose last read was >= 3 phases earlier.  Waits are counted (vmcnt(8): four quarters stay in
+// flight), placed one phase before the first read of the retired quarter with a barrier in between (both groups).
+// LDS image per tile as in the other LDS-DMA variants: [256 rows][64 k] for A then B, 128-B rows, 16-B chunk ^ (row & 7).
+// ------------------------------------------------------------------------------------------------
+template <int N> MM_DEV void wait_vmcnt() {
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8, "unsupported count");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs a) {
+    constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
+    constexpr int A_BYTES = BM * 128;
+    constexpr int GM = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int total = a.ntm * a.ntn;
+    const int bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int gsize = GM * a.ntn;
+    const int grp = logical / gsize;
+    const int first_m = grp * GM;
+    const int gm = min(a.ntm - first_m, GM);
+    const int in_g = logical - grp * gsize;
+    const int tm = first_m + in_g % gm;
+    const int tn = in_g / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_s >> 2, wn = wave_s & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, N = a.N;
+    const int nk = a.K >> 6;                                 // host guarantees K % 128 == 0, K >= 128
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- LDS-DMA: quarter kinds in need order 0: A rows block 0, 1: B cols block 0, 2: B cols block 1, 3: A rows block 1;
+    //      16 pieces of 8 rows each, this wave moves pieces wave and wave + 8 of every quarter
+    uint32_t src[4][2];                                      // per-lane source byte offset from A / B (host: operands < 4 GiB)
+    int dst[4][2];                                           // tile-relative LDS byte offset of the piece (wave-uniform)
+    {
+        const int rin = lane >> 3;                           // row inside the 8-row piece
+        const int c = (lane & 7) ^ rin;                      // source chunk that belongs in LDS slot (lane & 7)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = wave_s + 8 * h;
+            const int ra = h * 128 + wave_s * 8;             // A rows block 0 of M half h
+            const int rb = (q >> 2) * 64 + (q & 3) * 8;      // B cols block 0 of wave column q >> 2
+            const int rows[4] = {ra, rb, rb + 32, ra + 64};
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) {
+                const bool isA = kd == 0 || kd == 3;
+                src[kd][h] = isA ? (uint32_t)((int64_t)min(m0 + rows[kd] + rin, M - 1) * a.lda * 2 + c * 16)
+                                 : (uint32_t)((int64_t)min(n0 + rows[kd] + rin, N - 1) * a.ldb * 2 + c * 16);
+                dst[kd][h] = (isA ? 0 : A_BYTES) + rows[kd] * 128;
+            }
+        }
+    }
+    // buffer-addressed DMA (resource in SGPRs + 32-bit lane offset + scalar K offset): no 64-bit per-lane address arithmetic
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
+    auto issue = [&](int kd, int tile) {                     // quarter kd of K tile `tile`
+        unsigned char* sb = smem + (tile & 1) * BUF;
+        const bool isA = kd == 0 || kd == 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(sb + dst[kd][h]), 16, src[kd][h], tile << 7, 0, 0);
+    };
+
+    // ---- fragments
+    const int sw0 = ((fq) ^ (fr & 7)) << 4;
+    const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const int a_off = (wm * TM + fr) * 128;
+    const int b_off = A_BYTES + (wn * TN + fr) * 128;
+    bf16x8 A[2][4][2], B[2][2][2];
+    auto rdA = [&](int ah, int tile) {
+        const unsigned char* sb = smem + (tile & 1) * BUF + a_off + ah * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A[ah][i][0] = *(const bf16x8*)(sb + i * 2048 + sw0);
+            A[ah][i][1] = *(const bf16x8*)(sb + i * 2048 + sw1);
+        }
+    };
+    auto rdB = [&](int bh, int tile) {
+        const unsigned char* sb = smem + (tile & 1) * BUF + b_off + bh * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            B[bh][j][0] = *(const bf16x8*)(sb + j * 2048 + sw0);
+            B[bh][j][1] = *(const bf16x8*)(sb + j * 2048 + sw1);
+        }
+    };
+    // one phase; P = phase of the K tile, VM = vmcnt to keep in flight, ISSUE: stage quarter (P + 2) & 3 of tile st,
+    // NEXTA: tile + 1 exists (read its A rows block 0 in phase 3)
+    auto phase = [&](auto p_c, auto vm_c, auto issue_c, auto nexta_c, int tile, int st) {
+        constexpr int P = decltype(p_c)::value, VM = decltype(vm_c)::value;
+        constexpr bool ISSUE = decltype(issue_c)::value, NEXTA = decltype(nexta_c)::value;
+        constexpr int ah = P >> 1, bh = (P == 1 || P == 2) ? 1 : 0;
+        if constexpr (P == 0) rdB(0, tile);
+        if constexpr (P == 1) rdB(1, tile);
+        if constexpr (P == 2) rdA(1, tile);
+        if constexpr (P == 3 && NEXTA) rdA(0, tile + 1);
+        if constexpr (ISSUE) issue((P + 2) & 3, st);
+        wait_vmcnt<VM>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ah * 4 + i][bh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ah][i][kk], B[bh][j][kk], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I6 = std::integral_constant<int, 6>;
+    using I8 = std::integral_constant<int, 8>;
+    using T = std::true_type; using F = std::false_type;
+
+    // prologue: quarters 0..5 (tile 0 complete, tile 1 first half) in flight; quarters 0, 1 landed; A rows block 0 of tile 0
+#pragma unroll
+    for (int kd = 0; kd < 4; ++kd) issue(kd, 0);
+    issue(0, 1);
+    issue(1, 1);
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    rdA(0, 0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // the second group runs one barrier behind the first
+
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {                             // steady state: two K tiles = eight phases per trip
+        phase(I0{}, I8{}, T{}, T{}, t, t + 1);
+        phase(I1{}, I8{}, T{}, T{}, t, t + 1);
+        phase(I2{}, I8{}, T{}, T{}, t, t + 2);
+        phase(I3{}, I8{}, T{}, T{}, t, t + 2);
+        phase(I0{}, I8{}, T{}, T{}, t + 1, t + 2);
+        phase(I1{}, I8{}, T{}, T{}, t + 1, t + 2);
+        phase(I2{}, I8{}, T{}, T{}, t + 1, t + 3);
+        phase(I3{}, I8{}, T{}, T{}, t + 1, t + 3);
+    }
+    // last two K tiles: the last two quarters go out, then the ring drains
+    phase(I0{}, I8{}, T{}, T{}, t, t + 1);
+    phase(I1{}, I8{}, T{}, T{}, t, t + 1);
+    phase(I2{}, I6{}, F{}, T{}, t, 0);
+    phase(I3{}, I4{}, F{}, T{}, t, 0);
+    phase(I0{}, I2{}, F{}, T{}, t + 1, 0);
+    phase(I1{}, I0{}, F{}, T{}, t + 1, 0);
+    phase(I2{}, I0{}, F{}, T{}, t + 1, 0);
+    phase(I3{}, I0{}, F{}, F{}, t + 1, 0);
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // the first group catches the barrier count up
+    __syncthreads();
+    gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+}
+
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE, bool TNL>
 int launch_gemm(GemmArgs a, hipStream_t s);
+
+int launch_gemm_pp(GemmArgs a, hipStream_t s) {
+    // needs whole pairs of K tiles and 32-bit source offsets
+    if (a.K < 128 || (a.K & 127) || ((int64_t)a.M * a.lda + a.K) * 2 >= 0x7fffffffLL || ((int64_t)a.N * a.ldb + a.K) * 2 >= 0x7fffffffLL)
+        return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
+    constexpr int LDS = 2 * (256 + 256) * 128;              // 128 KiB
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    a.ntm = (a.M + 255) / 256;
+    a.ntn = (a.N + 255) / 256;
+    const int64_t total = (int64_t)a.ntm * a.ntn;
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3((unsigned)total), dim3(512), LDS, s, a);
+    return mm_launch_status();
+}
 
 int launch_gemm_ring(GemmArgs a, hipStream_t s) {
     if (a.K < 128) return launch_gemm<256, 256, 2, 4, true, 0, false>(a, s);
@@ -681,7 +884,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 10; }
+extern "C" int mm355_gemm_num_variants(void) { return 11; }
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -700,10 +903,10 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
     hipStream_t s = (hipStream_t)stream;
     const bool dma_ok = (K % 64) == 0;
     if (variant == 0) {
-        // auto: LDS-DMA staging whenever K is a whole number of 64-wide tiles; the 256x256 tile once it
+        // auto: LDS-DMA staging whenever K is a whole number of 64-wide tiles; the 256x256 ping-pong kernel once it
         // still yields at least one full wave of workgroups over the 256 CUs.
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (dma_ok) variant = (t256 >= 200) ? 7 : 2;
+        if (dma_ok) variant = (t256 >= 200) ? 11 : 2;         // 11 falls back to 7 when K is not a whole number of tile pairs
         else variant = 1;
     }
     if (!dma_ok && (variant == 2 || variant == 4 || variant >= 6)) return MM355_EUNSUPPORTED;
@@ -718,6 +921,7 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
         case 9: return launch_gemm<256, 256, 2, 4, true, 5>(a, s);
         case 10: return launch_gemm_ring(a, s);
+        case 11: return launch_gemm_pp(a, s);
         case 96: return launch_gemm<256, 256, 2, 4, true, 6>(a, s);
         case 97: return launch_gemm<256, 256, 2, 4, true, 7>(a, s);
         case 92: return launch_gemm<256, 256, 2, 4, true, 2>(a, s);   // ablations (wrong results, timing only)

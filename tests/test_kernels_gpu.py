@@ -55,11 +55,11 @@ GEMM_SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (512, 384, 1152
                (200, 1152, 592), (1024, 1024, 4096)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_plain(ops, variant, shape):
     M, N, K = shape
-    if K % 64 and variant in (2, 4, 6, 7, 8, 10):
+    if K % 64 and variant in (2, 4, 6, 7, 8, 10, 11):
         pytest.skip("LDS-DMA variants need K % 64 == 0")
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     ref = a.float() @ b.float().t()
@@ -67,7 +67,22 @@ def test_gemm_plain(ops, variant, shape):
     close(out, ref, 1e-2, 0.02 * math.sqrt(K), f"gemm v{variant} {shape}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (700, 520, 256), (1024, 768, 2048), (2304, 2048, 1152), (4096, 4096, 8192)])
+def test_gemm_pingpong_race_screen(ops, shape):
+    """The staggered two-group 256x256 kernel (variant 11): counted waits + barriers are the only ordering between the LDS-DMA
+    writes and the fragment reads, so screen it repeatedly (different data each round) against the plain 128x128 kernel, which
+    is bit-comparable (same bf16 products, fp32 accumulation in the same K order per 32-wide MFMA step)."""
+    M, N, K = shape
+    for rep in range(4):
+        a, b = rnd(M, K, seed=10 + rep).to(DEV), rnd(N, K, seed=20 + rep).to(DEV)
+        out = ops.gemm(a, b, variant=11)
+        ref = ops.gemm(a, b, variant=1)
+        assert torch.equal(out, ref), f"variant 11 differs from variant 1 at {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    close(ops.gemm(a.to(DEV), b.to(DEV), variant=11), a.float() @ b.float().t(), 1e-2, 0.02 * math.sqrt(K), f"gemm v11 {shape}")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11])
 def test_gemm_epilogues(ops, variant):
     M, N, K = 320, 256, 128
     a, b = rnd(M, K, seed=3, scale=0.3), rnd(N, K, seed=4, scale=0.3)
