@@ -81,12 +81,15 @@ int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, fl
 /* ------------------------------------------------------------------------------------------------
  * RMSNorm -- HF LlamaRMSNorm (fp32 normalise, cast to bf16, THEN multiply by weight); K7.
  * bwd: dx[m] = (dres ? dres[m] : 0) + d/dx ; dw_f32[h] += sum_m dy*xhat (caller zeroes dw_f32).
+ * workspace (optional, mm355_rmsnorm_bwd_ws_floats(M, h) floats, 16-B aligned): the weight gradient is then summed
+ * from per-workgroup partial rows in a fixed order (deterministic, no atomics); NULL = fp32 atomics on dw_f32.
  * ------------------------------------------------------------------------------------------------ */
 int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h,
                       float eps, void* stream);
 int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w,
-                      const mm355_bf16* dres, mm355_bf16* dx, float* dw_f32,
+                      const mm355_bf16* dres, mm355_bf16* dx, float* dw_f32, float* workspace,
                       int64_t M, int64_t h, float eps, void* stream);
+int64_t mm355_rmsnorm_bwd_ws_floats(int64_t M, int64_t h);
 
 /* LayerNorm forward (SigLIP encoder, eps 1e-6); the tower is frozen in every shipped recipe. */
 int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y,

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const uint16_t* __restr
 template <int VPT>
 __global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                          const uint16_t* __restrict__ w, const uint16_t* __restrict__ dres,
-                                                         uint16_t* __restrict__ dx, float* __restrict__ dw, int M, int h,
-                                                         float eps, int rows_per_block) {
+                                                         uint16_t* __restrict__ dx, float* __restrict__ dw,
+                                                         float* __restrict__ ws, int M, int h, float eps, int rows_per_block) {
     __shared__ float red[NT / 64];
     const int nv = h >> 3;
     float wv[VPT][8], dwacc[VPT][8];
@@ -111,7 +111,17 @@ __global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const uint16_t* __restr
             }
         }
     }
-    if (dw) {
+    if (ws) {                                                // per-workgroup partial row: summed by rmsnorm_dw_reduce_kernel
+        float* wr = ws + (int64_t)blockIdx.x * h;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+                *(f32x4*)(wr + v * 8) = f32x4{dwacc[i][0], dwacc[i][1], dwacc[i][2], dwacc[i][3]};
+                *(f32x4*)(wr + v * 8 + 4) = f32x4{dwacc[i][4], dwacc[i][5], dwacc[i][6], dwacc[i][7]};
+            }
+        }
+    } else if (dw) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = threadIdx.x + i * NT;
@@ -361,17 +371,46 @@ extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355
     });
 }
 
+// dw[c] += sum_g ws[g][c]: 64 columns per workgroup, four row lanes, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int G, int h) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < h)
+        for (int g = rl; g < G; g += 4) acc += ws[(int64_t)g * h + c];
+    part[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < h) dw[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+static int rmsnorm_bwd_rows_per_block(int64_t M, bool two_stage) {
+    if (two_stage) return M >= 8192 ? 32 : (M >= 1024 ? 8 : 1);
+    return M >= 8192 ? 16 : (M >= 1024 ? 4 : 1);
+}
+
+extern "C" int64_t mm355_rmsnorm_bwd_ws_floats(int64_t M, int64_t h) {
+    if (M <= 0 || h <= 0) return 0;
+    const int rpb = rmsnorm_bwd_rows_per_block(M, true);
+    return ((M + rpb - 1) / rpb) * h;
+}
+
 extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres,
-                                 mm355_bf16* dx, float* dw_f32, int64_t M, int64_t h, float eps, void* stream) {
+                                 mm355_bf16* dx, float* dw_f32, float* workspace, int64_t M, int64_t h, float eps, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dy || !x || !w || !dx || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
-    const int rpb = M >= 8192 ? 16 : (M >= 1024 ? 4 : 1);
+    const bool two_stage = dw_f32 && workspace;
+    if (two_stage && !mm_aligned16(workspace)) return MM355_EINVAL;
+    const int rpb = rmsnorm_bwd_rows_per_block(M, two_stage);
     const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
-    return dispatch_vpt((int)h, [&](auto vpt) {
+    int rc = dispatch_vpt((int)h, [&](auto vpt) {
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<decltype(vpt)::value>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, x, w, dres, dx,
-                           dw_f32, (int)M, (int)h, eps, rpb);
+                           dw_f32, two_stage ? workspace : nullptr, (int)M, (int)h, eps, rpb);
         return mm_launch_status();
     });
+    if (rc != MM355_OK || !two_stage) return rc;
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, (hipStream_t)stream, workspace, dw_f32,
+                       (int)grid, (int)h);
+    return mm_launch_status();
 }
 
 extern "C" int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y, int64_t M, int64_t h,

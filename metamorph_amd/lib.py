@@ -36,7 +36,7 @@ def _parse_header():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(mm355_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(mm355_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":
@@ -47,7 +47,7 @@ def _parse_header():
                 else:
                     base = a.replace("const", "").split()[0]
                     types.append(_CTYPE[base])
-        protos[name] = (c_char_p if ret != "int" else c_int, types)
+        protos[name] = ({"int": c_int, "int64_t": c_int64}.get(ret, c_char_p), types)
     return protos
 
 

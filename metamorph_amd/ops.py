@@ -135,13 +135,16 @@ def rmsnorm_fwd(x, w, eps, out=None):
     return out
 
 
-def rmsnorm_bwd(dy, x, w, eps, dres=None, dw_f32=None, dx=None):
+def rmsnorm_bwd(dy, x, w, eps, dres=None, dw_f32=None, dx=None, atomic=False):
     _chk_dev(dy, x, w)
     assert dy.is_contiguous() and x.is_contiguous()
     h = x.shape[-1]
     M = x.numel() // h
     dx = torch.empty_like(x) if dx is None else dx
-    _lib.check(_L().mm355_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), _p(dw_f32),
+    ws = None
+    if dw_f32 is not None and atomic is False:               # deterministic two-stage weight-gradient sum
+        ws = torch.empty(int(_L().mm355_rmsnorm_bwd_ws_floats(M, h)), dtype=torch.float32, device=x.device)
+    _lib.check(_L().mm355_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), _p(dw_f32), _p(ws),
                                       M, h, eps, _stream()), "mm355_rmsnorm_bwd")
     return dx
 

@@ -170,10 +170,24 @@ def test_rmsnorm_fwd_bwd(ops, h):
     xf = x.float().requires_grad_(True)
     wf = w.float().requires_grad_(True)
     R.rmsnorm(xf, wf, 1e-5).backward(dy.float())
-    dw = torch.zeros(h, device=DEV)
-    dx = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-5, dres=dres.to(DEV), dw_f32=dw)
-    close(dx, xf.grad + dres.float(), 1e-2, 2e-2, "rmsnorm dx")
-    close(dw, wf.grad, 1e-2, 5e-2, "rmsnorm dw")
+    for atomic in (False, True):                                # two-stage (workspace) and fp32-atomic weight gradient
+        dw = torch.full((h,), 0.5, device=DEV)                  # accumulates onto what is there
+        dx = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-5, dres=dres.to(DEV), dw_f32=dw, atomic=atomic)
+        close(dx, xf.grad + dres.float(), 1e-2, 2e-2, "rmsnorm dx")
+        close(dw - 0.5, wf.grad, 1e-2, 5e-2, f"rmsnorm dw atomic={atomic}")
+
+
+def test_rmsnorm_bwd_large_deterministic(ops):
+    M, h = 9000, 4096                                           # several rows per workgroup, ragged last workgroup
+    x, w, dy = rnd(M, h, seed=1).to(DEV), (1 + 0.1 * rnd(h, seed=2).float()).bfloat16().to(DEV), rnd(M, h, seed=3).to(DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(h, device=DEV)
+        ops.rmsnorm_bwd(dy, x, w, 1e-5, dw_f32=dw)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    xh = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).bfloat16().float()
+    close(outs[0], (dy.float() * xh).sum(0), 1e-3, 1e-3 * math.sqrt(M), "rmsnorm dw two-stage")
 
 
 def test_layernorm_fwd(ops):
