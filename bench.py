@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step (each 2048 spliced tokens)")
+    ap.add_argument("--batch", type=int, default=12, help="samples per GPU per step (each 2048 spliced tokens)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--image-tokens", type=int, default=256)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
