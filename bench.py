@@ -240,9 +240,21 @@ def main():
     roofline = None
     if n_gemm:
         ach = fl_gemm / t_gemm / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
+        # the gfx950 x2 read correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed
+        # under profiles/; they only apply to the configuration they were taken on.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "r1_step_b12_hbm_traffic_d.json")
+        if args.batch == 12 and args.layers == 32 and os.path.exists(tpath):
+            for k in json.load(open(tpath))["kernels"]:
+                if k["kernel"].startswith("gemm_pp_kernel<false, false>"):
+                    traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/r1_step_b12_hbm_traffic_d.json"
+        alg_bytes = sum(2.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k) in timer.records) / n_gemm
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": n_gemm, "gemm_seconds_per_step": round(t_gemm / args.steps, 4),
+                    "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over launches",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
+                    "launches": n_gemm, "gemm_seconds_per_step": round(t_gemm / args.steps, 4),
                     "algorithmic_flops_per_step": fl_gemm / args.steps}
     # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
     h, V, L = 4096, 128258, args.seq

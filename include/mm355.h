@@ -71,6 +71,15 @@ int mm355_gemm_num_variants(void);
 int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc,
                        int64_t M, int64_t N, int64_t K, uint32_t flags, void* stream);
 
+/* Input-gradient form on the weight AS IT LIES IN MEMORY:
+ *   C[M,N] = A[M,K] . Bt[K,N] (+ residual)      e.g. dX[tokens,in] = dY[tokens,out] . W[out,in]
+ * A fragments by ds_read_b128, Bt fragments by ds_read_b64_tr_b16 (ping-pong 256x256 kernel).
+ * Requirements: K % 128 == 0, N, lda, ldb, ldc % 8 == 0, operands below 2 GiB (else MM355_EUNSUPPORTED: use
+ * mm355_transpose_bf16 + mm355_gemm_bf16).  flags: MM355_GEMM_RESIDUAL, MM355_GEMM_ACCUMULATE, MM355_GEMM_OUT_F32. */
+int mm355_gemm_nn_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr,
+                       uint32_t flags, void* stream);
+
 /* out[c][r] = in[r][c]   (rows x cols -> cols x rows), bf16.  Used for the backward GEMM operands. */
 int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols,
                          mm355_bf16* out, int64_t ld_out, void* stream);

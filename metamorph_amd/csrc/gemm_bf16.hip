@@ -15,6 +15,7 @@
 //     blocks sharing an XCD's L2 walk neighbouring tiles.
 #include "mm355_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -28,6 +29,7 @@ struct GemmArgs {
     int M, N, K;
     uint32_t flags;
     int ntm, ntn;
+    int gm;                                                  // raster group height in tiles (ping-pong kernel)
 };
 
 // ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
@@ -613,11 +615,11 @@ template <int N> MM_DEV void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs a) {
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
     constexpr int A_BYTES = BM * 128;
-    constexpr int GM = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int total = a.ntm * a.ntn;
@@ -625,6 +627,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs a) {
     const int q8 = total >> 3, r8 = total & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int GM = a.gm;
     const int gsize = GM * a.ntn;
     const int grp = logical / gsize;
     const int first_m = grp * GM;
@@ -649,57 +652,106 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs a) {
 
     // ---- LDS-DMA: quarter kinds in need order 0: A rows block 0, 1: B cols block 0, 2: B cols block 1, 3: A rows block 1;
     //      16 pieces of 8 rows each, this wave moves pieces wave and wave + 8 of every quarter
-    uint32_t src[4][2];                                      // per-lane source byte offset from A / B (host: operands < 4 GiB)
+    uint32_t src[4][2];                                      // per-lane source byte offset from A / B (host: operands < 2 GiB)
     int dst[4][2];                                           // tile-relative LDS byte offset of the piece (wave-uniform)
-    {
-        const int rin = lane >> 3;                           // row inside the 8-row piece
-        const int c = (lane & 7) ^ rin;                      // source chunk that belongs in LDS slot (lane & 7)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = wave_s + 8 * h;
-            const int ra = h * 128 + wave_s * 8;             // A rows block 0 of M half h
-            const int rb = (q >> 2) * 64 + (q & 3) * 8;      // B cols block 0 of wave column q >> 2
-            const int rows[4] = {ra, rb, rb + 32, ra + 64};
+    for (int h = 0; h < 2; ++h) {
+        const int q = wave_s + 8 * h;
 #pragma unroll
-            for (int kd = 0; kd < 4; ++kd) {
-                const bool isA = kd == 0 || kd == 3;
-                src[kd][h] = isA ? (uint32_t)((int64_t)min(m0 + rows[kd] + rin, M - 1) * a.lda * 2 + c * 16)
-                                 : (uint32_t)((int64_t)min(n0 + rows[kd] + rin, N - 1) * a.ldb * 2 + c * 16);
-                dst[kd][h] = (isA ? 0 : A_BYTES) + rows[kd] * 128;
+        for (int kd = 0; kd < 4; ++kd) {
+            const bool isA = kd == 0 || kd == 3;
+            const int blk = isA ? (kd == 3) : (kd - 1);      // rows / cols block 0 or 1 of the wave tile
+            if (isA && !TA) {                                // [256 m][64 k] image, piece = 8 rows x 128 B
+                const int rin = lane >> 3, c = (lane & 7) ^ rin;
+                const int row = h * 128 + blk * 64 + wave_s * 8;
+                src[kd][h] = (uint32_t)((int64_t)min(m0 + row + rin, M - 1) * a.lda * 2 + c * 16);
+                dst[kd][h] = row * 128;
+            } else if (isA && TA) {                          // four [64 k][64 m] images (128-B rows), piece = 8 k rows
+                const int krow = wave_s * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (2 * ((krow >> 1) & 1) + 4 * ((krow >> 3) & 1));
+                src[kd][h] = (uint32_t)((int64_t)krow * a.lda * 2 + min(m0 + h * 128 + blk * 64 + c * 8, M - 8) * 2);
+                dst[kd][h] = (h * 2 + blk) * 8192 + wave_s * 1024;
+            } else if (!TB) {                                // [256 n][64 k] image
+                const int rin = lane >> 3, c = (lane & 7) ^ rin;
+                const int row = (q >> 2) * 64 + blk * 32 + (q & 3) * 8;
+                src[kd][h] = (uint32_t)((int64_t)min(n0 + row + rin, N - 1) * a.ldb * 2 + c * 16);
+                dst[kd][h] = A_BYTES + row * 128;
+            } else {                                         // eight [64 k][32 n] images (64-B rows), piece = 16 k rows
+                const int krow = (q & 3) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ (2 * ((krow >> 3) & 1));
+                src[kd][h] = (uint32_t)((int64_t)krow * a.ldb * 2 + min(n0 + (q >> 2) * 64 + blk * 32 + c * 8, N - 8) * 2);
+                dst[kd][h] = A_BYTES + ((q >> 2) * 2 + blk) * 4096 + (q & 3) * 1024;
             }
         }
     }
     // buffer-addressed DMA (resource in SGPRs + 32-bit lane offset + scalar K offset): no 64-bit per-lane address arithmetic
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
+    const int kstepA = TA ? (int)(a.lda * 128) : 128, kstepB = TB ? (int)(a.ldb * 128) : 128;   // bytes per K tile
     auto issue = [&](int kd, int tile) {                     // quarter kd of K tile `tile`
         unsigned char* sb = smem + (tile & 1) * BUF;
         const bool isA = kd == 0 || kd == 3;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(sb + dst[kd][h]), 16, src[kd][h], tile << 7, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(sb + dst[kd][h]), 16, src[kd][h],
+                                                     tile * (isA ? kstepA : kstepB), 0, 0);
     };
 
-    // ---- fragments
+    // ---- fragments: row-major operands by ds_read_b128, contraction-major ones by two ds_read_b64_tr_b16 (k rows j..j+3 and
+    //      j+4..j+7 of a [k][16 cols] block; chunk swizzles f(k) chosen so that a 32-lane gather touches every bank once)
     const int sw0 = ((fq) ^ (fr & 7)) << 4;
     const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;
     const int a_off = (wm * TM + fr) * 128;
     const int b_off = A_BYTES + (wn * TN + fr) * 128;
+    int toA[4], toB[2];
+    {
+        const int j4 = fr >> 2, q = fr & 3;
+        const int fa = 2 * ((j4 >> 1) & 1) + 4 * (fq & 1), fb = 2 * (fq & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) toA[i] = (fq * 8 + j4) * 128 + (((i * 2 + (q >> 1)) ^ fa) << 4) + (q & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) toB[j] = (fq * 8 + j4) * 64 + (((j * 2 + (q >> 1)) ^ fb) << 4) + (q & 1) * 8;
+    }
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds4_t;
+    auto trfrag = [&](const unsigned char* p, int hi_off) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p + hi_off));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
     bf16x8 A[2][4][2], B[2][2][2];
     auto rdA = [&](int ah, int tile) {
-        const unsigned char* sb = smem + (tile & 1) * BUF + a_off + ah * 8192;
+        if constexpr (!TA) {
+            const unsigned char* sb = smem + (tile & 1) * BUF + a_off + ah * 8192;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            A[ah][i][0] = *(const bf16x8*)(sb + i * 2048 + sw0);
-            A[ah][i][1] = *(const bf16x8*)(sb + i * 2048 + sw1);
+            for (int i = 0; i < 4; ++i) {
+                A[ah][i][0] = *(const bf16x8*)(sb + i * 2048 + sw0);
+                A[ah][i][1] = *(const bf16x8*)(sb + i * 2048 + sw1);
+            }
+        } else {
+            const unsigned char* sb = smem + (tile & 1) * BUF + (wm * 2 + ah) * 8192;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                A[ah][i][0] = trfrag(sb + toA[i], 4 * 128);
+                A[ah][i][1] = trfrag(sb + toA[i] + 32 * 128, 4 * 128);
+            }
         }
     };
     auto rdB = [&](int bh, int tile) {
-        const unsigned char* sb = smem + (tile & 1) * BUF + b_off + bh * 4096;
+        if constexpr (!TB) {
+            const unsigned char* sb = smem + (tile & 1) * BUF + b_off + bh * 4096;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            B[bh][j][0] = *(const bf16x8*)(sb + j * 2048 + sw0);
-            B[bh][j][1] = *(const bf16x8*)(sb + j * 2048 + sw1);
+            for (int j = 0; j < 2; ++j) {
+                B[bh][j][0] = *(const bf16x8*)(sb + j * 2048 + sw0);
+                B[bh][j][1] = *(const bf16x8*)(sb + j * 2048 + sw1);
+            }
+        } else {
+            const unsigned char* sb = smem + (tile & 1) * BUF + A_BYTES + (wn * 2 + bh) * 4096;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                B[bh][j][0] = trfrag(sb + toB[j], 4 * 64);
+                B[bh][j][1] = trfrag(sb + toB[j] + 32 * 64, 4 * 64);
+            }
         }
     };
     // one phase; P = phase of the K tile, VM = vmcnt to keep in flight, ISSUE: stage quarter (P + 2) & 3 of tile st,
@@ -775,23 +827,40 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs a) {
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE, bool TNL>
 int launch_gemm(GemmArgs a, hipStream_t s);
 
-int launch_gemm_pp(GemmArgs a, hipStream_t s) {
-    // needs whole pairs of K tiles and 32-bit source offsets
-    if (a.K < 128 || (a.K & 127) || ((int64_t)a.M * a.lda + a.K) * 2 >= 0x7fffffffLL || ((int64_t)a.N * a.ldb + a.K) * 2 >= 0x7fffffffLL)
-        return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
+// TA / TB: operand given contraction-major ([K][M] / [K][N]); eligibility of the K extent and the 31-bit byte offsets is the
+// caller's business (pp_eligible)
+template <bool TA, bool TB>
+int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
     constexpr int LDS = 2 * (256 + 256) * 128;              // 128 KiB
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MM355_ELAUNCH;
         attr_done = true;
     }
     a.ntm = (a.M + 255) / 256;
     a.ntn = (a.N + 255) / 256;
+    static const int gm_env = [] { const char* e = std::getenv("MM355_GEMM_GM"); return e ? atoi(e) : 0; }();   // tuning knob
+    a.gm = gm_env > 0 ? gm_env : 4;                         // 4 x ntn raster groups: sweep on LLaMA-3-8B shapes (2/4/8/16/32)
     const int64_t total = (int64_t)a.ntm * a.ntn;
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
-    hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3((unsigned)total), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), dim3((unsigned)total), dim3(512), LDS, s, a);
     return mm_launch_status();
+}
+
+// whole pairs of K tiles, and every source byte offset (row * ld + K extent) below 2 GiB
+bool pp_eligible(const GemmArgs& a, bool ta, bool tb) {
+    if (a.K < 128 || (a.K & 127)) return false;
+    const int64_t ea = ta ? ((int64_t)a.K * a.lda + a.M) * 2 : ((int64_t)a.M * a.lda + a.K) * 2;
+    const int64_t eb = tb ? ((int64_t)a.K * a.ldb + a.N) * 2 : ((int64_t)a.N * a.ldb + a.K) * 2;
+    if (ta && (a.M < 8 || (a.M & 7))) return false;
+    if (tb && (a.N < 8 || (a.N & 7))) return false;
+    return ea < 0x7fffffffLL && eb < 0x7fffffffLL;
+}
+
+int launch_gemm_pp(GemmArgs a, hipStream_t s) {
+    if (!pp_eligible(a, false, false)) return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
+    return launch_gemm_pp_t<false, false>(a, s);
 }
 
 int launch_gemm_ring(GemmArgs a, hipStream_t s) {
@@ -943,7 +1012,24 @@ extern "C" int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355
     a.A = At; a.B = Bt; a.C = C; a.bias = nullptr; a.res = nullptr;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = 0; a.res_mod = 0;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
+    if (pp_eligible(a, true, true)) return launch_gemm_pp_t<true, true>(a, (hipStream_t)stream);
     return launch_gemm<256, 256, 2, 4, true, 1, true>(a, (hipStream_t)stream);
+}
+
+extern "C" int mm355_gemm_nn_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                  int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr, uint32_t flags, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!A || !Bt || !C || M <= 0 || N < 8 || K <= 0) return MM355_EINVAL;
+    if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7) || !mm_aligned16(A) || !mm_aligned16(Bt) || !mm_aligned16(C)) return MM355_EINVAL;
+    if (flags & ~(MM355_GEMM_ACCUMULATE | MM355_GEMM_OUT_F32 | MM355_GEMM_RESIDUAL)) return MM355_EINVAL;
+    if ((flags & MM355_GEMM_RESIDUAL) && (!residual || !mm_aligned16(residual) || (ldr & 7))) return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemmArgs a;
+    a.A = A; a.B = Bt; a.C = C; a.bias = nullptr; a.res = residual;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
+    if (!pp_eligible(a, false, true)) return MM355_EUNSUPPORTED;   // caller: mm355_transpose_bf16 + mm355_gemm_bf16
+    return launch_gemm_pp_t<false, true>(a, (hipStream_t)stream);
 }
 
 extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols, mm355_bf16* out,

@@ -16,8 +16,9 @@ from torch.autograd import Function
 from . import ops
 
 BF16 = torch.bfloat16
-# MM355_DW_TN=1: weight gradients through the TN kernel (no transposed activation copies; measured ~5 % slower than
-# transpose + NT on LLaMA-3-8B shapes, so it is opt-in)
+# MM355_DW_TN=1: weight / input gradients on the operands as they lie in memory (contraction-major ping-pong GEMM, no
+# transposed copies).  Measured on LLaMA-3-8B shapes: TN 1.04-1.10 PFLOP/s, NN 1.25-1.30 vs 1.45-1.5 for the row-major
+# kernel -- explicit transposes + NT are still faster end to end (1.22-1.25 PFLOP/s including the copies), so it is opt-in.
 _DW_TN = os.environ.get("MM355_DW_TN", "0") == "1"
 
 
@@ -137,16 +138,21 @@ def transpose_padded(x2d):
 
 
 def weight_grad_gemm(dy2d, x2d, out, accumulate):
-    """out[N,K] (+)= dy[M,N]^T @ x[M,K].  Whole 64-row token tiles go straight through the TN kernel (operands as they
-    lie in memory, fragments gathered by ds_read_b64_tr_b16); ragged token counts fall back to explicit transposes."""
-    if _DW_TN and ops.gemm_tn_supported(dy2d, x2d):
+    """out[N,K] (+)= dy[M,N]^T @ x[M,K].  Token counts that are whole pairs of 64-row tiles go straight through the
+    contraction-major ping-pong kernel (operands as they lie in memory, fragments gathered by ds_read_b64_tr_b16); ragged
+    or small problems fall back to explicit transposes.  Opt-in (MM355_DW_TN=1): see the note at the top."""
+    M = dy2d.shape[0]
+    big = ((dy2d.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) >= 128
+    if _DW_TN and big and ops.gemm_tn_supported(dy2d, x2d) and ops.gemm_pp_operands_ok(M, dy2d, x2d):
         ops.gemm_tn(dy2d, x2d, out, accumulate=accumulate)
     else:
         ops.gemm(transpose_padded(dy2d), transpose_padded(x2d), out=out, accumulate=accumulate)
 
 
 def input_grad_gemm(dy2d, w, out=None, residual=None):
-    """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual)"""
+    """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual); the weight is read untransposed whenever the ping-pong kernel applies"""
+    if _DW_TN and ops.gemm_nn_supported(dy2d, w):
+        return ops.gemm_nn(dy2d, w, out=out, residual=residual)
     return ops.gemm(dy2d, transpose_padded(w), out=out, residual=residual)
 
 

@@ -101,6 +101,39 @@ def gemm_tn_supported(at, bt):
     return at.shape[0] % 64 == 0 and at.shape[1] % 8 == 0 and bt.shape[1] % 8 == 0 and at.shape[1] >= 8 and bt.shape[1] >= 8
 
 
+def gemm_pp_operands_ok(K, *mats):
+    """The ping-pong 256x256 kernel wants whole pairs of 64-wide K tiles and 31-bit byte offsets into every operand."""
+    return K >= 128 and K % 128 == 0 and all(m.shape[0] * m.stride(0) * 2 < 2 ** 31 - 2 ** 20 for m in mats)
+
+
+def gemm_nn(a, bt, out=None, residual=None, accumulate=False):
+    """out[M,N] = a[M,K] . bt[K,N] (+ residual)   (input-gradient form: the weight is read as it lies in memory)."""
+    _chk_dev(a, bt, out, residual)
+    pa, M, K, lda = _rows2d(a)
+    pb, Kb, N, ldb = _rows2d(bt)
+    assert K == Kb and a.dtype == BF16 and bt.dtype == BF16
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+    po, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N)
+    flags = (GEMM_ACCUMULATE if accumulate else 0) | (GEMM_OUT_F32 if out.dtype == torch.float32 else 0)
+    pr, ldr = 0, 0
+    if residual is not None:
+        pr, Mr, Nr, ldr = _rows2d(residual)
+        assert (Mr, Nr) == (M, N)
+        flags |= GEMM_RESIDUAL
+    _lib.check(_L().mm355_gemm_nn_bf16(pa, lda, pb, ldb, po, ldc, M, N, K, pr, ldr, flags, _stream()),
+               f"mm355_gemm_nn_bf16 M={M} N={N} K={K}")
+    return out
+
+
+def gemm_nn_supported(a, bt):
+    M, K = a.shape
+    N = bt.shape[1]
+    return (N % 8 == 0 and N >= 8 and gemm_pp_operands_ok(K, a, bt)
+            and ((M + 255) // 256) * ((N + 255) // 256) >= 128)
+
+
 def transpose(x, out=None, ld_out=None):
     """out[c, r] = x[r, c]"""
     _chk_dev(x, out)

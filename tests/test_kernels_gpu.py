@@ -140,6 +140,33 @@ def test_gemm_tn(ops, shape):
     close(out, big[:, 32:32 + M].float().t() @ bt.float(), 1e-2, 0.02 * math.sqrt(K), "gemm_tn strided A")
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 128), (520, 264, 256), (1024, 776, 1024), (2304, 2048, 2048)])
+def test_gemm_contraction_major_pingpong(ops, shape):
+    """TN (weight gradient) and NN (input gradient) forms of the ping-pong kernel against the NT kernel on explicitly
+    transposed copies: same bf16 products and fp32 accumulation order => bit-identical; repeated to screen for races."""
+    M, N, K = shape
+    for rep in range(3):
+        at, bt = rnd(K, M, seed=30 + rep, scale=0.5).to(DEV), rnd(K, N, seed=40 + rep, scale=0.5).to(DEV)
+        ref = ops.gemm(at.t().contiguous(), bt.t().contiguous(), variant=1)
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_tn(at, bt, out)
+        assert torch.equal(out, ref), f"gemm_tn (ping-pong) {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
+        a = rnd(M, K, seed=50 + rep, scale=0.5).to(DEV)
+        res = rnd(M, N, seed=60 + rep).to(DEV)
+        ref = ops.gemm(a, bt.t().contiguous(), residual=res, variant=1)
+        out = ops.gemm_nn(a, bt, residual=res)
+        assert torch.equal(out, ref), f"gemm_nn (ping-pong) {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
+    close(ops.gemm_nn(a, bt), a.float().cpu() @ bt.float().cpu(), 1e-2, 0.02 * math.sqrt(K), f"gemm_nn {shape}")
+    wide = rnd(K, N + 64, seed=70, scale=0.5).to(DEV)             # strided weight view (column block of a fused buffer)
+    close(ops.gemm_nn(a, wide[:, 32:32 + N]), a.float().cpu() @ wide[:, 32:32 + N].float().cpu(), 1e-2, 0.02 * math.sqrt(K), "gemm_nn strided")
+
+
+def test_gemm_nn_rejects_ragged_k(ops):
+    from metamorph_amd.lib import Mm355Error
+    with pytest.raises(Mm355Error):
+        ops.gemm_nn(rnd(64, 192, seed=1).to(DEV), rnd(192, 64, seed=2).to(DEV))
+
+
 def test_gemm_tn_rejects_ragged_k(ops):
     from metamorph_amd.lib import Mm355Error
     at, bt = rnd(100, 64, seed=1).to(DEV), rnd(100, 64, seed=2).to(DEV)
