@@ -184,7 +184,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
 
     from metamorph_amd.factory import LLAMA3_8B, build_model
-    from metamorph_amd.zero2 import Zero2AdamW
+    from metamorph_amd.zero2 import Zero2AdamW, tag_segments
 
     llm = dict(LLAMA3_8B, num_hidden_layers=args.layers)
     geo = dict(num_hidden_layers=args.vit_layers)
@@ -197,7 +197,8 @@ def main():
     if world > 1:                                                # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
-    opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    tag_segments(model)                                          # one gradient-reduction segment per decoder layer
+    opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
     ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank)
@@ -208,6 +209,7 @@ def main():
     def step():
         opt.zero_grad()
         out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images)
+        opt.arm_overlap()                                        # no accumulation: these gradients are final
         out.loss.backward()
         opt.step()
         return out.loss

@@ -66,6 +66,16 @@ def fused_weight(params):
     return buf
 
 
+_LAYER_GRAD_HOOK = None
+
+
+def set_layer_grad_hook(fn):
+    """fn(layer) is called at the end of every DecoderLayerFn.backward (Zero2AdamW starts that layer's gradient
+    reduce-scatter there, overlapping it with the backward of the earlier layers); None removes it."""
+    global _LAYER_GRAD_HOOK
+    _LAYER_GRAD_HOOK = fn
+
+
 def grad_target(p):
     """(buffer, accumulate) for the gradient of parameter `p`."""
     if p.grad is not None:
@@ -264,6 +274,8 @@ class DecoderLayerFn(Function):
             buf, acc = grad_target(ln1)
             ops.axpy_(buf, dw1, None, 1.0, acc)
             commit_grad(ln1, buf)
+        if _LAYER_GRAD_HOOK is not None:                                       # every gradient of this layer is final now
+            _LAYER_GRAD_HOOK(layer)
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 

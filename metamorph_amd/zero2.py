@@ -5,10 +5,13 @@ optim="adamw_torch", train.py:82):
 
   * all trainable parameters live in ONE flat bf16 buffer, their gradients in a second flat bf16 buffer
     (`contiguous_gradients`); the backward kernels write weight gradients straight into it;
-  * after backward the flat gradient buffer is reduce-scattered (sum; the 1/world mean is folded into the
-    update kernel) in large buckets -- xGMI is point-to-point, so few large collectives beat many small ones;
-  * every rank owns 1/world of the flat space: fp32 master weights + Adam moments for that shard only
-    (12 B/param sharded), updated by one fused HIP kernel (mm355_adamw_shard) that also emits the bf16 weights;
+  * the flat space is cut into SEGMENTS (one per decoder layer + the runs of parameters in between: a few hundred MB
+    each -- xGMI is point-to-point, so few large collectives beat many small ones); a segment's gradients are
+    reduce-scattered in place (sum; the 1/world mean is folded into the update kernel) as soon as the backward of its
+    decoder layer has finished, asynchronously on RCCL's stream, while the backward of the earlier layers keeps the
+    compute stream busy (`overlap_comm` of scripts/zero2.json:20); whatever is left goes out at step();
+  * every rank owns slice `rank` of every segment: fp32 master weights + Adam moments for those slices only
+    (12 B/param sharded), updated by the fused HIP kernel (mm355_adamw_shard) that also emits the bf16 weights;
   * global grad-norm clipping costs one 4-byte all-reduce;
   * updated bf16 shards are all-gathered back into the flat parameter buffer.
 
@@ -21,6 +24,7 @@ gloo backend in tests (the product default is the HIP kernels; there is no CPU f
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -45,9 +49,32 @@ def _hip_clip_coef(sumsq, max_norm, pre, out):
 
 
 
+def tag_segments(model):
+    """Mark the parameters of every decoder layer as one reduction segment (call BEFORE constructing Zero2AdamW).  The
+    layer module carries the same key so that DecoderLayerFn.backward can announce "this layer's gradients are final"."""
+    inner = model.get_model() if hasattr(model, "get_model") else model
+    for i, layer in enumerate(getattr(inner, "layers", [])):
+        layer._mm_segment = ("layer", i)
+        for p in layer.parameters():
+            p._mm_segment = ("layer", i)
+
+
+class _Pending:
+    """One in-flight segment reduction (RCCL reduce-scatter, or the all-reduce stand-in of the gloo tests)."""
+
+    def __init__(self, work, finish=None):
+        self.work, self.finish = work, finish
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.finish is not None:
+            self.finish()
+
+
 class Zero2AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, bucket_elems=0, shard_update=None, sumsq=None, clip_coef=None):
+                 process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=None):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("Zero2AdamW: no trainable parameters")
@@ -58,11 +85,13 @@ class Zero2AdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
         self.max_grad_norm = max_grad_norm
-        self.bucket_elems = int(bucket_elems)
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq
         self._clip_coef = clip_coef or _hip_clip_coef
+        self.overlap = (os.environ.get("MM355_ZERO2_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self._step = 0
+        self._armed = False
+        self._pending = {}                 # segment index -> _Pending
         self._flatten(params)
 
     # ------------------------------------------------------------------ layout
@@ -71,27 +100,48 @@ class Zero2AdamW(torch.optim.Optimizer):
         if any(p.dtype != dt or p.device != dev for p in params):
             raise ValueError("Zero2AdamW needs all trainable parameters on one device in one dtype")
         self.params = params
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += p.numel()            # NO padding between parameters: fused q/k/v and gate/up stay contiguous
         chunk = ALIGN * self.world
-        self.total = total
-        self.padded = (total + chunk - 1) // chunk * chunk
+        # consecutive parameters with the same `_mm_segment` key form a segment; NO padding inside a segment (fused q/k/v and
+        # gate/up stay contiguous), every segment is padded to a multiple of ALIGN * world so that all slices stay aligned
+        runs = []
+        for p in params:
+            key = getattr(p, "_mm_segment", None)
+            if runs and runs[-1][0] == key:
+                runs[-1][1].append(p)
+            else:
+                runs.append((key, [p]))
+        self.total = sum(p.numel() for p in params)
+        offs, segs, pos = {}, [], 0
+        for key, ps in runs:
+            lo = pos
+            for p in ps:
+                offs[id(p)] = pos
+                pos += p.numel()
+            n = (pos - lo + chunk - 1) // chunk * chunk
+            pos = lo + n
+            segs.append({"key": key, "lo": lo, "n": n, "params": ps})
+        self.padded = pos
         self.shard = self.padded // self.world
         self.flat_param = torch.zeros(self.padded, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(self.padded, device=dev, dtype=dt)
-        for p, o in zip(params, offs):
+        for p in params:
+            o = offs[id(p)]
             view = self.flat_param[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
             p._mm_grad_buf = self.flat_grad[o:o + p.numel()].view(p.shape)
             p.grad = None
-        self.offsets = offs
-        lo = self.rank * self.shard
-        self.my_param = self.flat_param[lo:lo + self.shard]
-        self.my_grad = self.flat_grad[lo:lo + self.shard]
-        self.master = self.my_param.float().clone()
+        self.offsets = [offs[id(p)] for p in params]
+        so = 0
+        for sg in segs:                    # this rank's slice of every segment, and where it sits in the shard arrays
+            m = sg["n"] // self.world
+            lo = sg["lo"] + self.rank * m
+            sg.update(m=m, so=so, grad=self.flat_grad[sg["lo"]:sg["lo"] + sg["n"]], param=self.flat_param[sg["lo"]:sg["lo"] + sg["n"]],
+                      my_grad=self.flat_grad[lo:lo + m], my_param=self.flat_param[lo:lo + m])
+            so += m
+        self.segs = segs
+        self.seg_of_key = {sg["key"]: i for i, sg in enumerate(segs) if sg["key"] is not None}
+        self.master = torch.cat([sg["my_param"] for sg in segs]).float()
         self.exp_avg = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self._norm_buf = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -99,40 +149,79 @@ class Zero2AdamW(torch.optim.Optimizer):
         self.grad_norm = None
 
     # ------------------------------------------------------------------ collectives
-    def _reduce_scatter_grads(self):
-        if self.world == 1:
+    @staticmethod
+    def _settle_grads(ps):
+        """Parameters that received no gradient this step contribute zeros; a gradient produced outside the flat buffer
+        (e.g. by autograd) is copied in."""
+        for p in ps:
+            if p.grad is None:
+                p._mm_grad_buf.zero_()
+            elif p.grad.data_ptr() != p._mm_grad_buf.data_ptr():
+                p._mm_grad_buf.copy_(p.grad)
+
+    def _launch_reduce(self, i, async_op):
+        """Sum segment i over the ranks; this rank's slice ends up in place (the other slices are don't-care afterwards)."""
+        sg = self.segs[i]
+        self._settle_grads(sg["params"])
+        if dist.get_backend(self.pg) == "nccl":           # RCCL: in-place reduce-scatter (output = input + rank * count)
+            w = dist.reduce_scatter_tensor(sg["my_grad"], sg["grad"], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+            self._pending[i] = _Pending(w if async_op else None)
+        else:                                             # gloo (CPU tests): no reduce_scatter -> all_reduce in fp32
+            g = sg["grad"].float() if sg["grad"].dtype == BF16 else sg["grad"]
+            w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+            fin = (lambda g=g, sg=sg: sg["grad"].copy_(g)) if g is not sg["grad"] else None
+            self._pending[i] = _Pending(w if async_op else None, fin)
+
+    def arm_overlap(self):
+        """Call before the backward pass whose gradients are final (the last micro-step of an accumulation window): from
+        now until step(), notify_segment_ready() starts that segment's reduction right away."""
+        self._armed = self.overlap and self.world > 1
+        return self
+
+    def notify_segment_ready(self, key):
+        if not self._armed:
             return
-        backend = dist.get_backend(self.pg)
-        if backend == "nccl":           # RCCL
-            # bucketed so that each collective moves >= hundreds of MB (launch-amortised on xGMI) while the
-            # scratch stays bounded: bucket b covers the same sub-range of every rank's shard.
-            # default (bucket_elems == 0): ONE in-place reduce-scatter over the whole flat buffer (RCCL pipelines it
-            # internally; output = input + rank*shard is NCCL's documented in-place form)
-            per = self.shard if self.bucket_elems <= 0 else max(ALIGN, min(self.shard, self.bucket_elems // self.world // ALIGN * ALIGN))
-            for s in range(0, self.shard, per):
-                n = min(per, self.shard - s)
-                if n == self.shard:
-                    dist.reduce_scatter_tensor(self.my_grad, self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-                else:
-                    stage = torch.cat([self.flat_grad[r * self.shard + s: r * self.shard + s + n] for r in range(self.world)])
-                    dist.reduce_scatter_tensor(self.my_grad[s:s + n], stage, op=dist.ReduceOp.SUM, group=self.pg)
-        else:                           # gloo (CPU tests): no reduce_scatter -> all_reduce, keep own shard
-            g = self.flat_grad.float() if self.flat_grad.dtype == BF16 else self.flat_grad
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-            if g is not self.flat_grad:
-                self.flat_grad.copy_(g)
+        i = self.seg_of_key.get(key)
+        if i is not None and i not in self._pending:
+            self._launch_reduce(i, async_op=True)
+
+    def enable_overlap(self):
+        """Route DecoderLayerFn's "layer gradients are final" announcements to this optimizer."""
+        from . import functional as F
+        F.set_layer_grad_hook(lambda layer: self.notify_segment_ready(getattr(layer, "_mm_segment", None)))
+        return self
+
+    def _reduce_grads(self):
+        if self.world == 1:
+            self._settle_grads(self.params)
+            return
+        for i in range(len(self.segs)):
+            if i not in self._pending:
+                self._launch_reduce(i, async_op=False)
+        for pend in self._pending.values():
+            pend.wait()
+        self._pending = {}
+        self._armed = False
 
     def _all_gather_params(self):
         if self.world == 1:
             return
-        backend = dist.get_backend(self.pg)
-        if backend == "nccl":
-            dist.all_gather_into_tensor(self.flat_param, self.my_param, group=self.pg)
+        if dist.get_backend(self.pg) == "nccl":
+            works = [dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg, async_op=True) for sg in self.segs]
+            for w in works:
+                w.wait()
         else:
-            parts = [torch.empty_like(self.my_param) for _ in range(self.world)]
-            dist.all_gather(parts, self.my_param.clone(), group=self.pg)
-            for r, t in enumerate(parts):
-                self.flat_param[r * self.shard:(r + 1) * self.shard].copy_(t)
+            for sg in self.segs:
+                parts = [torch.empty_like(sg["my_param"]) for _ in range(self.world)]
+                dist.all_gather(parts, sg["my_param"].clone(), group=self.pg)
+                for r, t in enumerate(parts):
+                    sg["param"][r * sg["m"]:(r + 1) * sg["m"]].copy_(t)
+
+    def _my_slices(self):
+        """(shard offset, length, gradient slice, parameter slice) runs of this rank; one run when the slices are adjacent."""
+        if self.world == 1:
+            return [(0, self.padded, self.flat_grad, self.flat_param)]
+        return [(sg["so"], sg["m"], sg["my_grad"], sg["my_param"]) for sg in self.segs]
 
     # ------------------------------------------------------------------ step
     def zero_grad(self, set_to_none: bool = True):
@@ -143,17 +232,12 @@ class Zero2AdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure")
-        # parameters that received no gradient this step contribute zeros
-        for p in self.params:
-            if p.grad is None:
-                p._mm_grad_buf.zero_()
-            elif p.grad.data_ptr() != p._mm_grad_buf.data_ptr():
-                p._mm_grad_buf.copy_(p.grad)        # a gradient produced outside the flat buffer (e.g. by autograd)
-        self._reduce_scatter_grads()
+        self._reduce_grads()
         inv_world = 1.0 / self.world
         # global L2 norm of the MEAN gradient: sqrt(sum over shards) * 1/world
         self._norm_buf.zero_()
-        self._sumsq(self.my_grad, self._norm_buf)
+        for _, _, g, _ in self._my_slices():
+            self._sumsq(g, self._norm_buf)
         if self.world > 1:
             dist.all_reduce(self._norm_buf, op=dist.ReduceOp.SUM, group=self.pg)
         # coef = min(1, max_norm / (||mean grad|| + 1e-6)) * (1/world), computed on the device (no host sync)
@@ -161,8 +245,9 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._step += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        self._shard_update(self.master, self.exp_avg, self.exp_avg_sq, self.my_grad, self.my_param, float(g["lr"]), b1, b2,
-                           g["eps"], g["weight_decay"], self._step, self._coef)
+        for so, m, gs, ps in self._my_slices():
+            self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, float(g["lr"]), b1, b2,
+                               g["eps"], g["weight_decay"], self._step, self._coef)
         self._all_gather_params()
         self.grad_norm = self._norm_buf        # sum of squares of the summed gradient (device scalar); see grad_norm_value()
         return None

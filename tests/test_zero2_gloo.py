@@ -39,24 +39,41 @@ def _grads_for(rank, step, params):
     return [torch.randn(p.shape, generator=g).to(p.dtype) * 3.0 for p in params]
 
 
-def _worker(rank, world, port, dtype, steps, tmp):
+# segment keys of _make_params' six tensors: two "decoder layers" ([0,1,2] fused q/k/v-like block, [3,4]) and a free tail
+_SEGMENTS = [("layer", 0), ("layer", 0), ("layer", 0), ("layer", 1), ("layer", 1), None]
+
+
+def _worker(rank, world, port, dtype, steps, tmp, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd.zero2 import Zero2AdamW
         params = _make_params(dtype)
+        for p, key in zip(params, _SEGMENTS):
+            if key is not None:
+                p._mm_segment = key
         opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
-                         shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
-        assert opt.world == world and opt.shard * world == opt.padded
+                         shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip, overlap=overlap)
+        assert opt.world == world and opt.shard * world == opt.padded and len(opt.segs) == 3
+        assert all(sg["n"] % (world * 256) == 0 for sg in opt.segs)
         # fused blocks stay contiguous in the flat buffer (q/k/v -> one GEMM operand)
         assert params[1].data_ptr() == params[0].data_ptr() + params[0].numel() * params[0].element_size()
         for s in range(1, steps + 1):
-            for p, g in zip(params, _grads_for(rank, s, params)):
-                p._mm_grad_buf.copy_(g)              # what the backward kernels do
-                p.grad = p._mm_grad_buf
-            if s == 2:
-                params[-1].grad = None               # a parameter without gradient this step contributes zeros
+            if overlap:
+                opt.arm_overlap()
+            grads = _grads_for(rank, s, params)
+            # backward order: the tail first, then layer 1, then layer 0 -- each layer announces itself when done
+            for idx in (5, 4, 3, 2, 1, 0):
+                if not (s == 2 and idx == 5):        # a parameter without gradient this step contributes zeros
+                    params[idx]._mm_grad_buf.copy_(grads[idx])   # what the backward kernels do
+                    params[idx].grad = params[idx]._mm_grad_buf
+                if idx == 3:
+                    opt.notify_segment_ready(("layer", 1))
+                    assert (1 in opt._pending) == (overlap and world > 1)
+                if idx == 0:
+                    opt.notify_segment_ready(("layer", 0))
             opt.step()
+            assert not opt._pending and not opt._armed
             opt.zero_grad()
             assert all(p.grad is None for p in params)
         flat = torch.cat([p.data.reshape(-1) for p in params])
@@ -73,10 +90,13 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_two_ranks_equal_one_rank(tmp_path, dtype):
+def test_two_ranks_equal_one_rank(tmp_path, dtype, overlap):
+    """overlap=True: each "layer" segment is reduced asynchronously as soon as it is announced (the RCCL reduce-scatter /
+    backward overlap of the product, here gloo all-reduce), the rest at step(); the result must not depend on it."""
     world, steps = 2, 3
-    mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path), overlap), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     assert torch.equal(r0, r1), "ranks must hold identical parameters after the all-gather"
