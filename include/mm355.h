@@ -153,6 +153,10 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 int mm355_swiglu_fwd(const mm355_bf16* gu, mm355_bf16* act, int64_t M, int64_t I, void* stream);
 int mm355_swiglu_bwd(const mm355_bf16* gu, const mm355_bf16* dact, mm355_bf16* dgu, mm355_bf16* act,
                      int64_t M, int64_t I, void* stream);
+/* same, additionally emitting the contraction-major copies the weight-gradient GEMMs consume: actT[I][M] and dguT[2I][M]
+ * (what mm355_transpose_bf16 would make of act and dgu).  M % 64 == 0 and I % 64 == 0, else MM355_EUNSUPPORTED. */
+int mm355_swiglu_bwd_t(const mm355_bf16* gu, const mm355_bf16* dact, mm355_bf16* dgu, mm355_bf16* actT,
+                       mm355_bf16* dguT, int64_t M, int64_t I, void* stream);
 #define MM355_GELU_ERF  0
 #define MM355_GELU_TANH 1
 int mm355_gelu_fwd(const mm355_bf16* x, mm355_bf16* y, int64_t n, int kind, void* stream);

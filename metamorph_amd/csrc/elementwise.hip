@@ -99,6 +99,50 @@ __global__ __launch_bounds__(NT) void swiglu_bwd_kernel(const uint16_t* __restri
         if (act) *(u32x4*)(act + row * I + v * 8) = pack8(a);
     }
 }
+// SwiGLU backward with the contraction-major copies the two weight-gradient GEMMs want, written from the same registers:
+// 64 x 64 tiles; dgu goes out row-major as usual, act / dgate / dup additionally through three LDS tiles as
+// actT[I][M], dguT[2I][M] (what mm355_transpose_bf16 would produce from act and dgu, without re-reading them).
+__global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const uint16_t* __restrict__ gu, const uint16_t* __restrict__ dact,
+                                                           uint16_t* __restrict__ dgu, uint16_t* __restrict__ actT,
+                                                           uint16_t* __restrict__ dguT, int64_t M, int I) {
+    __shared__ uint16_t tile[3][64][64 + 2];
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, r = v >> 3, c = (v & 7) * 8;
+        const int64_t row = r0 + r;
+        float g[8], u[8], da[8], dg[8], du[8], a[8];
+        unpack8(*(const u32x4*)(gu + row * 2 * I + c0 + c), g);
+        unpack8(*(const u32x4*)(gu + row * 2 * I + I + c0 + c), u);
+        unpack8(*(const u32x4*)(dact + row * I + c0 + c), da);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.0f / (1.0f + __expf(-g[e]));
+            const float silu = g[e] * sg;
+            a[e] = round_bf(silu) * u[e];
+            du[e] = da[e] * round_bf(silu);
+            dg[e] = da[e] * u[e] * (sg * (1.0f + g[e] * (1.0f - sg)));
+        }
+        const u32x4 pg = pack8(dg), pu = pack8(du), pa = pack8(a);
+        *(u32x4*)(dgu + row * 2 * I + c0 + c) = pg;
+        *(u32x4*)(dgu + row * 2 * I + I + c0 + c) = pu;
+        const uint16_t* sa = (const uint16_t*)&pa; const uint16_t* sg16 = (const uint16_t*)&pg; const uint16_t* su = (const uint16_t*)&pu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { tile[0][r][c + e] = sa[e]; tile[1][r][c + e] = sg16[e]; tile[2][r][c + e] = su[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, c = v >> 3, r = (v & 7) * 8;   // output row = input column c
+        uint16_t ta[8], tg[8], tu[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ta[e] = tile[0][r + e][c]; tg[e] = tile[1][r + e][c]; tu[e] = tile[2][r + e][c]; }
+        *(u32x4*)(actT + (int64_t)(c0 + c) * M + r0 + r) = *(const u32x4*)ta;
+        *(u32x4*)(dguT + (int64_t)(c0 + c) * M + r0 + r) = *(const u32x4*)tg;
+        *(u32x4*)(dguT + (int64_t)(I + c0 + c) * M + r0 + r) = *(const u32x4*)tu;
+    }
+}
 __global__ __launch_bounds__(NT) void gelu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int kind) {
     for (int64_t i = (blockIdx.x * (int64_t)NT + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * NT * 8) {
         float f[8];
@@ -312,6 +356,16 @@ extern "C" int mm355_swiglu_bwd(const mm355_bf16* gu, const mm355_bf16* dact, mm
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!gu || !dact || !dgu || M <= 0 || I <= 0 || (I & 7)) return MM355_EINVAL;
     LAUNCH(swiglu_bwd_kernel, grid_for(M * (I / 8)), gu, dact, dgu, act, M, (int)I);
+}
+extern "C" int mm355_swiglu_bwd_t(const mm355_bf16* gu, const mm355_bf16* dact, mm355_bf16* dgu, mm355_bf16* actT, mm355_bf16* dguT,
+                                  int64_t M, int64_t I, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!gu || !dact || !dgu || !actT || !dguT || M <= 0 || I <= 0) return MM355_EINVAL;
+    if ((M & 63) || (I & 63)) return MM355_EUNSUPPORTED;    // whole 64 x 64 tiles: else mm355_swiglu_bwd + mm355_transpose_bf16
+    if (M / 64 > 65535) return MM355_EINVAL;
+    hipLaunchKernelGGL(swiglu_bwd_t_kernel, dim3((unsigned)(I / 64), (unsigned)(M / 64)), dim3(256), 0, (hipStream_t)stream, gu, dact, dgu,
+                       actT, dguT, M, (int)I);
+    return mm_launch_status();
 }
 extern "C" int mm355_gelu_fwd(const mm355_bf16* x, mm355_bf16* y, int64_t n, int kind, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch

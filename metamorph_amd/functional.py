@@ -147,16 +147,18 @@ def transpose_padded(x2d):
     return buf
 
 
-def weight_grad_gemm(dy2d, x2d, out, accumulate):
+def weight_grad_gemm(dy2d, x2d, out, accumulate, dyT=None, xT=None):
     """out[N,K] (+)= dy[M,N]^T @ x[M,K].  Token counts that are whole pairs of 64-row tiles go straight through the
     contraction-major ping-pong kernel (operands as they lie in memory, fragments gathered by ds_read_b64_tr_b16); ragged
     or small problems fall back to explicit transposes.  Opt-in (MM355_DW_TN=1): see the note at the top."""
-    M = dy2d.shape[0]
-    big = ((dy2d.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) >= 128
-    if _DW_TN and big and ops.gemm_tn_supported(dy2d, x2d) and ops.gemm_pp_operands_ok(M, dy2d, x2d):
-        ops.gemm_tn(dy2d, x2d, out, accumulate=accumulate)
-    else:
-        ops.gemm(transpose_padded(dy2d), transpose_padded(x2d), out=out, accumulate=accumulate)
+    if dyT is None and xT is None and _DW_TN:
+        big = ((dy2d.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) >= 128
+        if big and ops.gemm_tn_supported(dy2d, x2d) and ops.gemm_pp_operands_ok(dy2d.shape[0], dy2d, x2d):
+            ops.gemm_tn(dy2d, x2d, out, accumulate=accumulate)
+            return
+    # dyT / xT: contraction-major copies a producer already wrote (the row-major argument may then be None)
+    ops.gemm(transpose_padded(dy2d) if dyT is None else dyT, transpose_padded(x2d) if xT is None else xT, out=out,
+             accumulate=accumulate)
 
 
 def input_grad_gemm(dy2d, w, out=None, residual=None):
@@ -220,23 +222,31 @@ class DecoderLayerFn(Function):
 
         # ---- MLP ----
         dact = input_grad_gemm(dy, mlp.down_proj.weight)                       # [M, I]
-        dgu, act = ops.swiglu_bwd(gu, dact, m.I, want_act=mlp.down_proj.weight.requires_grad)
+        gu_params = [mlp.gate_proj.weight, mlp.up_proj.weight]
+        # full fine-tune on whole 64-row tiles: SwiGLU backward writes act^T and dgu^T itself (no transpose passes over them)
+        fused_t = (not _DW_TN and dact.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
+                   and all(p.requires_grad for p in gu_params))
+        if fused_t:
+            dgu, actT, dguT = ops.swiglu_bwd_t(gu, dact, m.I)
+            act = None
+        else:
+            dgu, act = ops.swiglu_bwd(gu, dact, m.I, want_act=mlp.down_proj.weight.requires_grad)
+            actT = dguT = None
         del dact
         if mlp.down_proj.weight.requires_grad:
             buf, acc = grad_target(mlp.down_proj.weight)
-            weight_grad_gemm(dy, act, buf, acc)
+            weight_grad_gemm(dy, act, buf, acc, xT=actT)
             commit_grad(mlp.down_proj.weight, buf)
-        del act
-        gu_params = [mlp.gate_proj.weight, mlp.up_proj.weight]
+        del act, actT
         wgu = fused_weight(gu_params)
         dn2 = input_grad_gemm(dgu, wgu)                                         # [M, h]
         if any(p.requires_grad for p in gu_params):
             n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps)
             fb, acc, bufs = fused_grad_target(gu_params)
-            weight_grad_gemm(dgu, n2, fb, bool(acc))
+            weight_grad_gemm(dgu, n2, fb, bool(acc), dyT=dguT)
             commit_fused_grad(gu_params, fb, acc, bufs)
             del n2
-        del dgu
+        del dgu, dguT
         ln2 = layer.post_attention_layernorm.weight
         dw2 = torch.zeros(h, device=dev, dtype=torch.float32) if ln2.requires_grad else None
         dx2 = ops.rmsnorm_bwd(dn2, x2, ln2, m.eps, dres=dy, dw_f32=dw2)        # dy + d rmsnorm

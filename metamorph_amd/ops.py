@@ -276,6 +276,19 @@ def swiglu_bwd(gu, dact, I, want_act=True):
     return dgu, act
 
 
+def swiglu_bwd_t(gu, dact, I):
+    """(dgu [M,2I], actT [I,M], dguT [2I,M]) -- SwiGLU backward that also writes the transposed copies for the dW GEMMs."""
+    _chk_dev(gu, dact)
+    assert gu.is_contiguous() and dact.is_contiguous()
+    M = gu.numel() // (2 * I)
+    dgu = torch.empty_like(gu)
+    actT = torch.empty((I, M), device=gu.device, dtype=BF16)
+    dguT = torch.empty((2 * I, M), device=gu.device, dtype=BF16)
+    _lib.check(_L().mm355_swiglu_bwd_t(gu.data_ptr(), dact.data_ptr(), dgu.data_ptr(), actT.data_ptr(), dguT.data_ptr(), M, I, _stream()),
+               "mm355_swiglu_bwd_t")
+    return dgu, actT, dguT
+
+
 def gelu_fwd(x, kind=GELU_ERF):
     _chk_dev(x)
     assert x.is_contiguous()

@@ -443,6 +443,18 @@ def test_splice_and_rows(ops):
     close(de[3], 2 * (dout[0].float() + dout[6].float()), 1e-2, 2e-2, "embed grad accumulate")
 
 
+def test_swiglu_bwd_transposed_outputs(ops):
+    """mm355_swiglu_bwd_t == mm355_swiglu_bwd + transposes of act and dgu, bit for bit."""
+    M, I = 192, 320
+    gu, dact = rnd(M, 2 * I, seed=1).to(DEV), rnd(M, I, seed=2).to(DEV)
+    dgu0, act0 = ops.swiglu_bwd(gu, dact, I)
+    dgu, actT, dguT = ops.swiglu_bwd_t(gu, dact, I)
+    assert torch.equal(dgu, dgu0) and torch.equal(actT, act0.t()) and torch.equal(dguT, dgu0.t())
+    from metamorph_amd.lib import Mm355Error
+    with pytest.raises(Mm355Error):
+        ops.swiglu_bwd_t(rnd(100, 2 * I, seed=3).to(DEV), rnd(100, I, seed=4).to(DEV), I)
+
+
 # ------------------------------------------------------------------------------------------------ vision
 
 def test_im2col_matches_conv(ops):
