@@ -147,6 +147,24 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
                            int64_t rows, int64_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
+ * re-runs the prefix every step).  HBM-bound streaming kernels.
+ *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 8 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16); flags BIAS /
+ *         GELU_ERF / GELU_TANH / RESIDUAL / OUT_F32 as for the GEMM.
+ *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
+ *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
+ *         upper bound of them (sizes the launch and the workspace of mm355_attn_decode_ws_floats floats); GQA groups 1/2/4/8.
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* W, int64_t ldw, void* y, int64_t ldy,
+                    int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr,
+                    uint32_t flags, void* stream);
+int64_t mm355_attn_decode_ws_floats(int64_t B, int64_t Hq, int64_t d, int64_t max_kv_len);
+int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
+                      int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,
+                      mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,
+                      float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Elementwise: SwiGLU (HF LlamaMLP; K12), GELU (projector / vision_head), scaling helpers.
  * gu = [M][2I] with gate in columns [0,I) and up in [I,2I).
  * ------------------------------------------------------------------------------------------------ */

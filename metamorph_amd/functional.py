@@ -349,7 +349,64 @@ class LinearFn(Function):
 
 
 def linear(x2d, module):
+    if x2d.shape[0] <= 8 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad)):
+        # decode shape: a handful of rows, inference only -> stream the weight once (mm355_gemv_bf16)
+        return ops.gemv(x2d, module.weight.data, bias=None if module.bias is None else module.bias.data)
     return LinearFn.apply(x2d, module.weight, module.bias, module)
+
+
+class KVCache:
+    """Post-RoPE keys and values of every decoder layer for ONE sequence: [layers, 1, max_len, Hkv*d] bf16 each."""
+
+    def __init__(self, n_layers, max_len, width, device):
+        self.k = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
+        self.v = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
+        self.max_len = max_len
+        self.length = 0
+        self.len_dev = torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def decoder_prefill(x, layers, meta, cache):
+    """Prompt pass of a cached decode: the training-path layer forward, keeping each layer's post-RoPE k / v rows.
+    x [L, h] -> hidden rows [L, h] (pre final norm)."""
+    nq, nk = meta.Hq * meta.d, meta.Hkv * meta.d
+    L = x.shape[0]
+    for i, layer in enumerate(layers):
+        x, saved = decoder_layer_forward(x, layer, meta)
+        qkv = saved[0]
+        cache.k[i, 0, :L].copy_(qkv[:, nq:nq + nk])
+        cache.v[i, 0, :L].copy_(qkv[:, nq + nk:])
+        del saved
+    cache.length = L
+    return x
+
+
+def decoder_decode_row(x, layers, meta, cache, cos, sin):
+    """One new row against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values; the reference's own
+    greedy loop recomputes the prefix instead, metamorph_llama.py:502-597).  x [1, h] -> [1, h]; appends at cache.length."""
+    pos = cache.length
+    if pos >= cache.max_len:
+        raise ValueError(f"KV cache full ({cache.max_len} rows)")
+    nq, nk = meta.Hq * meta.d, meta.Hkv * meta.d
+    cache.len_dev.fill_(pos + 1)
+    cpos, spos = cos[pos:pos + 1], sin[pos:pos + 1]
+    for i, layer in enumerate(layers):
+        att, mlp = layer.self_attn, layer.mlp
+        wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
+        wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
+        n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
+        qkv = ops.gemv(n1, wqkv)
+        ops.rope_qk_(qkv, 1, 1, meta.Hq, meta.Hkv, meta.d, cpos, spos)
+        cache.k[i, 0, pos].copy_(qkv[0, nq:nq + nk])
+        cache.v[i, 0, pos].copy_(qkv[0, nq + nk:])
+        o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, pos + 1, meta.Hq, meta.Hkv, meta.d, meta.scale)
+        x2 = ops.gemv(o, att.o_proj.weight, residual=x)
+        n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
+        gu = ops.gemv(n2, wgu)
+        act = ops.swiglu_fwd(gu, meta.I)
+        x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
+    cache.length = pos + 1
+    return x
 
 
 class GeluFn(Function):

@@ -335,8 +335,12 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
     def greedy_decode(self, position_ids, attention_mask, inputs_embeds, start_image_token_id=DEFAULT_IMAGE_START_ID,
                       end_image_token_id=DEFAULT_IMAGE_END_ID, eos_token_id=(128001, 128009), do_sample=None,
                       temperature=None, top_p=None, num_beams=None, max_new_tokens=1024, use_cache=None, output_image=False):
-        """Token mode / continuous 'image mode' greedy loop, re-running the prefix every step exactly like the
-        reference (which forces use_cache=False); a KV-cache version is the next row N1."""
+        """Token mode / continuous 'image mode' greedy loop.  use_cache=False re-runs the prefix every step exactly like
+        the reference (which forces use_cache=False, O(L^2)); the default keeps a KV cache and feeds one row per step
+        through the decode-shape kernels -- same state machine, same outputs."""
+        if use_cache is None or use_cache:
+            return self._greedy_decode_cached(inputs_embeds, start_image_token_id, end_image_token_id, eos_token_id,
+                                              max_new_tokens, output_image)
         in_image_mode = False
         generated, image_embeds = [], []
         total_image_tokens = 0
@@ -374,6 +378,81 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         output = [torch.tensor(generated, dtype=torch.int32, device=inputs_embeds.device)]
         return (output, emb) if output_image else output
 
+    # ------------------------------------------------------------------ cached decode (row N1)
+    def _decode_meta(self, L):
+        cfg = self.config
+        h, Hq, Hkv = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads
+        return h, F.LayerMeta(1, L, Hq, Hkv, h // Hq, cfg.intermediate_size, cfg.rms_norm_eps, None, None, None)
+
+    @torch.no_grad()
+    def _head_row(self, x, in_image_mode):
+        """Final norm + (image mode: vision_head -> normalize -> mm_projector) + fp32 logits of ONE hidden row
+        (reference metamorph_llama.py:363-377, 398-399).  Returns (logits [1,V] f32, row fed back in image mode, pred_z)."""
+        hid = self.model.norm(x)
+        pred_z = None
+        if in_image_mode:
+            pred_z = self.vision_head(hid)
+            if self.normalize_vision:
+                pred_z = ops.bilinear_l2norm(pred_z.view(1, 1, -1).contiguous(), 1, 1, True).view(1, -1)
+            if self.apply_softmax:
+                raise NotImplementedError("apply_softmax decode path has no HIP kernel")
+            hid = self.model.mm_projector(pred_z)
+        logits = ops.gemv(hid.contiguous(), self.lm_head.weight.data, out=torch.empty((1, self.lm_head.weight.shape[0]), device=x.device,
+                                                                                    dtype=torch.float32))
+        return logits, hid, pred_z
+
+    @torch.no_grad()
+    def _greedy_decode_cached(self, inputs_embeds, start_image_token_id, end_image_token_id, eos_token_id, max_new_tokens,
+                              output_image):
+        if inputs_embeds.shape[0] != 1:
+            raise NotImplementedError("greedy_decode handles one sequence (as the reference's loop does)")
+        if inputs_embeds.dtype != BF16:
+            raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
+        dev = inputs_embeds.device
+        L0 = inputs_embeds.shape[1]
+        num_image_tokens = self.get_model().vision_tower.image_token_len
+        h, meta = self._decode_meta(L0)
+        max_len = L0 + max_new_tokens + 2
+        cos, sin = self.model.rope_tables(max_len, dev)
+        meta.cos, meta.sin = cos, sin
+        cache = F.KVCache(len(self.model.layers), max_len, meta.Hkv * meta.d, dev)
+        x = F.decoder_prefill(inputs_embeds.reshape(L0, h).contiguous(), self.model.layers, meta, cache)[-1:].contiguous()
+        in_image_mode = False
+        generated, image_embeds = [], []
+        total_image_tokens = 0
+        total_out = 0
+        eos = set(eos_token_id)
+        while True:
+            logits, fed_back, pred_z = self._head_row(x, in_image_mode)
+            next_token = int(torch.argmax(logits[0], dim=-1))
+            if (not in_image_mode) and next_token == start_image_token_id:
+                in_image_mode = True
+                generated.append(next_token)
+                row = None
+            elif in_image_mode and total_image_tokens < num_image_tokens:
+                total_image_tokens += 1
+                image_embeds.append(pred_z)
+                row = fed_back
+                if total_image_tokens == num_image_tokens:
+                    in_image_mode = False
+            elif next_token == end_image_token_id:
+                in_image_mode = False
+                total_image_tokens = 0
+                generated.append(next_token)
+                row = None
+            else:
+                generated.append(next_token)
+                row = None
+            total_out += 1
+            if next_token in eos or total_out > max_new_tokens:
+                break
+            if row is None:
+                row = self.model.embed_tokens(torch.tensor([[next_token]], device=dev)).view(1, h)
+            x = F.decoder_decode_row(row.contiguous(), self.model.layers, meta, cache, cos, sin)
+        emb = torch.cat(image_embeds, dim=0) if image_embeds else torch.tensor([], dtype=torch.float32, device=dev)
+        output = [torch.tensor(generated, dtype=torch.int32, device=dev)]
+        return (output, emb) if output_image else output
+
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, output_image=False, use_customize_greedy=True,
                  image_embeds=None, **kwargs):
@@ -385,7 +464,8 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         else:
             inputs_embeds = self.get_model().embed_tokens(inputs)
         if not use_customize_greedy:
-            raise NotImplementedError("HF generate() needs the KV-cache decode kernels (next row N1); use the custom greedy loop")
+            raise NotImplementedError("HF GenerationMixin sampling / beam search is out of scope; the reference's own path is the "
+                                      "custom greedy loop (use_customize_greedy=True)")
         return self.greedy_decode(position_ids=position_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
                                   output_image=output_image, **kwargs)
 

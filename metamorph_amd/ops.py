@@ -134,6 +134,44 @@ def gemm_nn_supported(a, bt):
             and ((M + 255) // 256) * ((N + 255) // 256) >= 128)
 
 
+def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
+    """out[M,N] = x[M,K] . w[N,K]^T for M <= 8 rows (decode shape): streams the weight once at HBM rate."""
+    _chk_dev(x, w, out, bias, residual)
+    px, M, K, ldx = _rows2d(x)
+    pw, N, Kw, ldw = _rows2d(w)
+    assert K == Kw and x.dtype == BF16 and w.dtype == BF16
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16)
+    po, Mo, No, ldy = _rows2d(out)
+    assert (Mo, No) == (M, N)
+    flags = GEMM_OUT_F32 if out.dtype == torch.float32 else 0
+    pr, ldr = 0, 0
+    if bias is not None:
+        flags |= GEMM_BIAS
+    if gelu is not None:
+        flags |= {"erf": GEMM_GELU_ERF, "tanh": GEMM_GELU_TANH}[gelu]
+    if residual is not None:
+        pr, Mr, Nr, ldr = _rows2d(residual)
+        assert (Mr, Nr) == (M, N)
+        flags |= GEMM_RESIDUAL
+    _lib.check(_L().mm355_gemv_bf16(px, ldx, pw, ldw, po, ldy, M, N, K, _p(bias), pr, ldr, flags, _stream()), f"mm355_gemv_bf16 M={M} N={N} K={K}")
+    return out
+
+
+def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out=None):
+    """q [B, Hq*d]; caches [B, Lmax, Hkv*d]; kv_lens int32 [B] on the device (valid rows incl. the current one)."""
+    _chk_dev(q, k_cache, v_cache, kv_lens)
+    B = q.shape[0]
+    assert k_cache.dim() == 3 and k_cache.shape == v_cache.shape and k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride()
+    assert kv_lens.dtype == torch.int32 and max_kv_len <= k_cache.shape[1]
+    out = torch.empty((B, Hq * d), device=q.device, dtype=BF16) if out is None else out
+    ws = torch.empty(int(_L().mm355_attn_decode_ws_floats(B, Hq, d, max_kv_len)), device=q.device, dtype=torch.float32)
+    _lib.check(_L().mm355_attn_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0),
+                                      kv_lens.data_ptr(), max_kv_len, out.data_ptr(), out.stride(0), B, Hq, Hkv, d, scale, ws.data_ptr(),
+                                      _stream()), "mm355_attn_decode")
+    return out
+
+
 def transpose(x, out=None, ld_out=None):
     """out[c, r] = x[r, c]"""
     _chk_dev(x, out)

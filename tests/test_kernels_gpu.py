@@ -455,6 +455,48 @@ def test_swiglu_bwd_transposed_outputs(ops):
         ops.swiglu_bwd_t(rnd(100, 2 * I, seed=3).to(DEV), rnd(100, I, seed=4).to(DEV), I)
 
 
+# ------------------------------------------------------------------------------------------------ decode shape (row N1)
+
+@pytest.mark.parametrize("M", [1, 2, 3, 8])
+@pytest.mark.parametrize("NK", [(64, 512), (130, 1032), (6144, 4096), (1000, 14336)])
+def test_gemv(ops, M, NK):
+    N, K = NK
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t()
+    close(ops.gemv(x.to(DEV), w.to(DEV)), ref, 1e-2, 0.02, f"gemv {M}x{N}x{K}")
+    close(ops.gemv(x.to(DEV), w.to(DEV), bias=b.to(DEV), gelu="erf"), R.gelu_erf(ref + b.float()), 1e-2, 0.02, "gemv bias+gelu")
+    close(ops.gemv(x.to(DEV), w.to(DEV), residual=r.to(DEV)), ref + r.float(), 1e-2, 0.03, "gemv residual")
+    of = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    close(ops.gemv(x.to(DEV), w.to(DEV), out=of), ref, 1e-4, 2e-3, "gemv f32")
+    wide = rnd(N, K + 64, seed=5, scale=0.05).to(DEV)            # strided weight rows
+    close(ops.gemv(x.to(DEV), wide[:, 32:32 + K]), x.float() @ wide[:, 32:32 + K].float().cpu().t(), 1e-2, 0.02, "gemv strided")
+
+
+def test_gemv_rejects_many_rows(ops):
+    from metamorph_amd.lib import Mm355Error
+    with pytest.raises(Mm355Error):
+        ops.gemv(rnd(9, 64, seed=1).to(DEV), rnd(16, 64, seed=2).to(DEV))
+
+
+@pytest.mark.parametrize("case", [(1, 8, 2, 128, [700]), (3, 4, 4, 64, [1, 256, 300]), (2, 32, 4, 128, [513, 77]), (1, 16, 16, 72, [40])])
+def test_attn_decode(ops, case):
+    """Last-row attention against a KV cache == the oracle's attention on the same prefix, last query row."""
+    B, Hq, Hkv, d, lens = case
+    Lmax = max(lens) + 5
+    g = torch.Generator().manual_seed(7)
+    q = (torch.randn(B, Hq * d, generator=g) * 0.7).bfloat16()
+    kc = (torch.randn(B, Lmax, Hkv * d, generator=g) * 0.7).bfloat16()
+    vc = (torch.randn(B, Lmax, Hkv * d, generator=g) * 0.7).bfloat16()
+    out = ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), max(lens), Hq, Hkv, d, d ** -0.5)
+    for b in range(B):
+        n = lens[b]
+        qq = q[b].view(Hq, 1, d).float()
+        kk = kc[b, :n].view(n, Hkv, d).transpose(0, 1).float().repeat_interleave(Hq // Hkv, dim=0)      # [Hq, n, d]
+        vv = vc[b, :n].view(n, Hkv, d).transpose(0, 1).float().repeat_interleave(Hq // Hkv, dim=0)
+        ref = (torch.softmax(qq @ kk.transpose(1, 2) * d ** -0.5, dim=-1) @ vv).reshape(Hq * d)
+        close(out[b], ref, 1e-2, 1e-2, f"attn_decode {case} sample {b}")
+
+
 # ------------------------------------------------------------------------------------------------ vision
 
 def test_im2col_matches_conv(ops):

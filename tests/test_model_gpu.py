@@ -218,3 +218,67 @@ def test_stage1_freeze_policy():
             assert p.grad is not None and torch.isfinite(p.grad.float()).all() and float(p.grad.float().abs().max()) > 0, n
         else:
             assert p.grad is None, n
+
+
+# ------------------------------------------------------------------ cached decode
+def _decode_model(**kw):
+    cfg = tiny_cfg(num_key_value_heads=1, **kw)
+    sd = init_state_dict(cfg, seed=5)
+    return cfg, hip_model(cfg, sd).eval()
+
+
+def test_cached_decode_matches_full_forward():
+    """Prefill 21 rows, then feed rows 21..39 one at a time through the decode-shape kernels (GEMV + KV-cache attention):
+    every step's logits must agree with the logits of ONE full forward over all 40 rows at that position."""
+    from metamorph_amd import functional as F
+    cfg, model = _decode_model()
+    h = cfg.hidden_size
+    L, L0 = 40, 21
+    g = torch.Generator().manual_seed(3)
+    emb = (torch.randn(1, L, h, generator=g) * 0.5).bfloat16().to(DEV)
+    with torch.no_grad():
+        full = model.llm_forward(inputs_embeds=emb, return_dict=True).logits[0]            # [L, V] fp32
+        _, meta = model._decode_meta(L0)
+        cos, sin = model.model.rope_tables(L + 2, DEV)
+        meta.cos, meta.sin = cos, sin
+        cache = F.KVCache(cfg.num_hidden_layers, L + 2, meta.Hkv * meta.d, DEV)
+        x = F.decoder_prefill(emb[0, :L0].contiguous(), model.model.layers, meta, cache)[-1:].contiguous()
+        scale = float(full.abs().max())
+        for t in range(L0 - 1, L):
+            logits, _, _ = model._head_row(x, False)
+            err = float((logits[0] - full[t]).abs().max())
+            assert err <= 2e-2 * scale, f"position {t}: cached logits differ by {err} (scale {scale})"
+            assert int(logits[0].argmax()) == int(full[t].argmax()) or float(full[t].topk(2).values.diff().abs()) < 2e-2 * scale
+            if t + 1 < L:
+                x = F.decoder_decode_row(emb[0, t + 1:t + 2].contiguous(), model.model.layers, meta, cache, cos, sin)
+        assert cache.length == L
+
+
+def test_cached_image_mode_head_matches_reference_loop_step():
+    """Image mode: vision_head -> L2 norm -> mm_projector on the last row; cached head == llm_forward(decoding=True)."""
+    cfg, model = _decode_model()
+    g = torch.Generator().manual_seed(4)
+    emb = (torch.randn(1, 17, cfg.hidden_size, generator=g) * 0.5).bfloat16().to(DEV)
+    from metamorph_amd import functional as F
+    with torch.no_grad():
+        out = model.llm_forward(inputs_embeds=emb, return_dict=True, decoding=True)
+        _, meta = model._decode_meta(17)
+        cos, sin = model.model.rope_tables(32, DEV)
+        meta.cos, meta.sin = cos, sin
+        cache = F.KVCache(cfg.num_hidden_layers, 32, meta.Hkv * meta.d, DEV)
+        x = F.decoder_prefill(emb[0].contiguous(), model.model.layers, meta, cache)[-1:].contiguous()
+        logits, fed_back, pred_z = model._head_row(x, True)
+    assert rel(pred_z, out.loss) < 2e-2 and rel(fed_back, out.hidden_states[:, -1]) < 2e-2
+    assert rel(logits[0], out.logits[0, -1]) < 2e-2
+
+
+def test_greedy_decode_cached_equals_reprefill():
+    """The reference's loop (re-run the prefix every step) and the KV-cache loop walk the same state machine."""
+    cfg, model = _decode_model()
+    g = torch.Generator().manual_seed(6)
+    emb = (torch.randn(1, 12, cfg.hidden_size, generator=g) * 0.5).bfloat16().to(DEV)
+    a = model.greedy_decode(None, None, emb, max_new_tokens=8, use_cache=True)[0]
+    b = model.greedy_decode(None, None, emb, max_new_tokens=8, use_cache=False)[0]
+    assert a.shape == b.shape and a.numel() >= 1
+    same = (a == b).nonzero().numel()
+    assert same >= a.numel() - 1 and int(a[0]) == int(b[0])     # bf16 near-ties may flip a late token, never the first
