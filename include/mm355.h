@@ -158,6 +158,11 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* W, int64_t ldw, void* y, int64_t ldy,
                     int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr,
                     uint32_t flags, void* stream);
+ /* rope_kv_append: one new fused qkv row per sample [B][(Hq+2Hkv)*d]: q and k rotated at positions[b] (device), q left in
+ *         place, rotated k and v written to cache row positions[b] (graph-replayable: no host-side position). */
+int mm355_rope_kv_append(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t Hq, int64_t Hkv, int64_t d,
+                         const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* positions,
+                         mm355_bf16* k_cache, mm355_bf16* v_cache, int64_t ld_kv, int64_t batch_stride_kv, void* stream);
 int64_t mm355_attn_decode_ws_floats(int64_t B, int64_t Hq, int64_t d, int64_t max_kv_len);
 int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
                       int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,

@@ -29,10 +29,7 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
     const uint16_t* wr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wr[r] = W + (int64_t)min(n0 + r, N - 1) * ldw;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-        u32x4 wv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = *(const u32x4*)(wr[r] + k);
+    auto fma_chunk = [&](const u32x4 (&wv)[R], int k) {
         float xf[MR][8];
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
@@ -51,6 +48,22 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
         }
+    };
+    // two 512-element K chunks per trip: eight 16-B weight loads per lane in flight (a lone wave per SIMD must cover the HBM
+    // latency by itself when N is small)
+    int k = lane * 8;
+    for (; k + 512 < K; k += 1024) {
+        u32x4 w0[R], w1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w0[r] = *(const u32x4*)(wr[r] + k); w1[r] = *(const u32x4*)(wr[r] + k + 512); }
+        fma_chunk(w0, k);
+        fma_chunk(w1, k + 512);
+    }
+    for (; k < K; k += 512) {
+        u32x4 w0[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) w0[r] = *(const u32x4*)(wr[r] + k);
+        fma_chunk(w0, k);
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -76,8 +89,52 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------------ RoPE + cache append
+// One new qkv row per sample: rotate q and k at position positions[b] (HF rounding order, as rope_qk_kernel), leave q in
+// place and write the rotated k and the v row into cache row positions[b].  Positions come from DEVICE memory so that the
+// whole per-token step is replayable as a hipGraph.
+__global__ __launch_bounds__(NT) void rope_kv_append_kernel(uint16_t* __restrict__ qkv, int64_t ld, int Hq, int Hkv, int d,
+                                                            const uint16_t* __restrict__ cos_t, const uint16_t* __restrict__ sin_t,
+                                                            const int32_t* __restrict__ positions, uint16_t* __restrict__ kc,
+                                                            uint16_t* __restrict__ vc, int64_t ld_kv, int64_t bs_kv) {
+    const int b = blockIdx.y;
+    const int pos = positions[b];
+    const int half = d >> 1, vph = half >> 3;
+    const int H = Hq + Hkv;
+    uint16_t* row = qkv + (int64_t)b * ld;
+    uint16_t* krow = kc + (int64_t)b * bs_kv + (int64_t)pos * ld_kv;
+    uint16_t* vrow = vc + (int64_t)b * bs_kv + (int64_t)pos * ld_kv;
+    const int rot = H * vph, cpy = Hkv * d / 8;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < rot + cpy; i += gridDim.x * NT) {
+        if (i < rot) {
+            const int v = i % vph, hd = i / vph;
+            uint16_t* p1 = row + (int64_t)hd * d + v * 8;
+            uint16_t* p2 = p1 + half;
+            float x1[8], x2[8], c[8], sn[8], y1[8], y2[8];
+            unpack8(*(const u32x4*)p1, x1);
+            unpack8(*(const u32x4*)p2, x2);
+            unpack8(*(const u32x4*)(cos_t + (int64_t)pos * d + v * 8), c);
+            unpack8(*(const u32x4*)(sin_t + (int64_t)pos * d + v * 8), sn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                y1[e] = round_bf(x1[e] * c[e]) + round_bf(-x2[e] * sn[e]);
+                y2[e] = round_bf(x2[e] * c[e]) + round_bf(x1[e] * sn[e]);
+            }
+            const u32x4 o1 = pack8(y1), o2 = pack8(y2);
+            if (hd < Hq) { *(u32x4*)p1 = o1; *(u32x4*)p2 = o2; }
+            else {
+                uint16_t* kd = krow + (int64_t)(hd - Hq) * d + v * 8;
+                *(u32x4*)kd = o1; *(u32x4*)(kd + half) = o2;
+            }
+        } else {
+            const int j = i - rot;
+            *(u32x4*)(vrow + j * 8) = *(const u32x4*)(row + (int64_t)H * d + j * 8);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ attention, decode shape
-constexpr int CH = 256;                                      // keys per workgroup
+constexpr int CH = 256;                                      // keys per workgroup (one per thread)
 constexpr int GMAX = 8;                                      // query heads per KV head handled by one workgroup
 
 // partial record per (b, q head, split): [m, l, o[d]] floats
@@ -231,6 +288,19 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
     else if (M <= 4) GV(4);
     else GV(8);
 #undef GV
+    return mm_launch_status();
+}
+
+extern "C" int mm355_rope_kv_append(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, const mm355_bf16* cos_t,
+                                    const mm355_bf16* sin_t, const int32_t* positions, mm355_bf16* k_cache, mm355_bf16* v_cache, int64_t ld_kv,
+                                    int64_t batch_stride_kv, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!qkv || !cos_t || !sin_t || !positions || !k_cache || !v_cache || B <= 0 || Hq <= 0 || Hkv <= 0 || d <= 0 || (d & 15) || (ld & 7) ||
+        (ld_kv & 7) || (batch_stride_kv & 7) || B > 65535)
+        return MM355_EINVAL;
+    const int64_t work = (Hq + Hkv) * (d / 16) + Hkv * d / 8;
+    hipLaunchKernelGGL(rope_kv_append_kernel, dim3((unsigned)((work + NT - 1) / NT), (unsigned)B), dim3(NT), 0, (hipStream_t)stream, qkv, ld,
+                       (int)Hq, (int)Hkv, (int)d, cos_t, sin_t, positions, k_cache, v_cache, ld_kv, batch_stride_kv);
     return mm_launch_status();
 }
 

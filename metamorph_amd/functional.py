@@ -356,14 +356,24 @@ def linear(x2d, module):
 
 
 class KVCache:
-    """Post-RoPE keys and values of every decoder layer for ONE sequence: [layers, 1, max_len, Hkv*d] bf16 each."""
+    """Post-RoPE keys and values of every decoder layer for ONE sequence: [layers, 1, max_len, Hkv*d] bf16 each.  The write
+    position lives on the device as well (pos_dev / len_dev) so that a decode step is replayable as a hipGraph."""
 
-    def __init__(self, n_layers, max_len, width, device):
+    def __init__(self, n_layers, max_len, width, device, Hq=None, d=None):
         self.k = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
         self.v = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
         self.max_len = max_len
         self.length = 0
-        self.len_dev = torch.zeros(1, device=device, dtype=torch.int32)
+        self.pos_dev = torch.zeros(1, device=device, dtype=torch.int32)       # row the next token is written to
+        self.len_dev = torch.ones(1, device=device, dtype=torch.int32)        # = pos + 1: rows visible to that token
+        self.ws = None
+        if Hq is not None:
+            self.ws = torch.empty(int(ops._L().mm355_attn_decode_ws_floats(1, Hq, d, max_len)), device=device, dtype=torch.float32)
+
+    def set_length(self, n):
+        self.length = n
+        self.pos_dev.fill_(n)
+        self.len_dev.fill_(n + 1)
 
 
 def decoder_prefill(x, layers, meta, cache):
@@ -377,36 +387,79 @@ def decoder_prefill(x, layers, meta, cache):
         cache.k[i, 0, :L].copy_(qkv[:, nq:nq + nk])
         cache.v[i, 0, :L].copy_(qkv[:, nq + nk:])
         del saved
-    cache.length = L
+    cache.set_length(L)
     return x
 
 
 def decoder_decode_row(x, layers, meta, cache, cos, sin):
     """One new row against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values; the reference's own
-    greedy loop recomputes the prefix instead, metamorph_llama.py:502-597).  x [1, h] -> [1, h]; appends at cache.length."""
-    pos = cache.length
-    if pos >= cache.max_len:
+    greedy loop recomputes the prefix instead, metamorph_llama.py:502-597).  x [1, h] -> [1, h]; appends at cache.length.
+    Every position-dependent input is read from device memory (cache.pos_dev / len_dev): the launch sequence is identical
+    for every token, i.e. capturable once and replayable (DecodeStepGraph)."""
+    if cache.length >= cache.max_len:
         raise ValueError(f"KV cache full ({cache.max_len} rows)")
-    nq, nk = meta.Hq * meta.d, meta.Hkv * meta.d
-    cache.len_dev.fill_(pos + 1)
-    cpos, spos = cos[pos:pos + 1], sin[pos:pos + 1]
+    nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
         att, mlp = layer.self_attn, layer.mlp
         wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
         wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
         n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
         qkv = ops.gemv(n1, wqkv)
-        ops.rope_qk_(qkv, 1, 1, meta.Hq, meta.Hkv, meta.d, cpos, spos)
-        cache.k[i, 0, pos].copy_(qkv[0, nq:nq + nk])
-        cache.v[i, 0, pos].copy_(qkv[0, nq + nk:])
-        o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, pos + 1, meta.Hq, meta.Hkv, meta.d, meta.scale)
+        ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, cache.pos_dev, cache.k[i], cache.v[i])
+        o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, cache.max_len, meta.Hq, meta.Hkv, meta.d, meta.scale,
+                            workspace=cache.ws)
         x2 = ops.gemv(o, att.o_proj.weight, residual=x)
         n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
         gu = ops.gemv(n2, wgu)
         act = ops.swiglu_fwd(gu, meta.I)
         x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
-    cache.length = pos + 1
+    cache.pos_dev.add_(1)
+    cache.len_dev.add_(1)
+    cache.length += 1
     return x
+
+
+class DecodeStepGraph:
+    """decoder_decode_row captured ONCE as a hipGraph (~13 launches x layers per token collapse into one graph launch; the
+    per-token step is launch-bound otherwise) and replayed per token: copy the new row into `x_in`, replay, read `x_out`.
+    Falls back to eager launches if capture is not possible (MM355_DECODE_GRAPH=0 forces that)."""
+
+    def __init__(self, layers, meta, cache, cos, sin, h, device):
+        self.args = (layers, meta, cache, cos, sin)
+        self.cache = cache
+        self.x_in = torch.zeros((1, h), device=device, dtype=BF16)
+        self.x_out = None
+        self.graph = None
+        if os.environ.get("MM355_DECODE_GRAPH", "1") == "0":
+            return
+        try:
+            keep = cache.length
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up outside capture (writes a scratch row, undone below)
+                decoder_decode_row(self.x_in, *self.args)
+            torch.cuda.current_stream().wait_stream(side)
+            cache.set_length(keep)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.x_out = decoder_decode_row(self.x_in, *self.args)
+            cache.length = keep                                  # capture records, it does not run: host mirror unchanged
+            self.graph = g
+        except Exception as e:                                   # pragma: no cover - depends on the runtime
+            import warnings
+            warnings.warn(f"hipGraph capture of the decode step failed ({e!r}); using eager launches")
+            self.graph = None
+            cache.set_length(keep)
+
+    def step(self, row):
+        if self.graph is None:
+            return decoder_decode_row(row.contiguous(), *self.args)
+        if self.cache.length >= self.cache.max_len:
+            raise ValueError(f"KV cache full ({self.cache.max_len} rows)")
+        self.x_in.copy_(row.view(1, -1))
+        self.graph.replay()
+        self.cache.length += 1
+        return self.x_out
 
 
 class GeluFn(Function):

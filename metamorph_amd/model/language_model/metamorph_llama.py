@@ -415,8 +415,9 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         max_len = L0 + max_new_tokens + 2
         cos, sin = self.model.rope_tables(max_len, dev)
         meta.cos, meta.sin = cos, sin
-        cache = F.KVCache(len(self.model.layers), max_len, meta.Hkv * meta.d, dev)
+        cache = F.KVCache(len(self.model.layers), max_len, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
         x = F.decoder_prefill(inputs_embeds.reshape(L0, h).contiguous(), self.model.layers, meta, cache)[-1:].contiguous()
+        stepper = F.DecodeStepGraph(self.model.layers, meta, cache, cos, sin, h, dev)
         in_image_mode = False
         generated, image_embeds = [], []
         total_image_tokens = 0
@@ -448,7 +449,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                 break
             if row is None:
                 row = self.model.embed_tokens(torch.tensor([[next_token]], device=dev)).view(1, h)
-            x = F.decoder_decode_row(row.contiguous(), self.model.layers, meta, cache, cos, sin)
+            x = stepper.step(row)
         emb = torch.cat(image_embeds, dim=0) if image_embeds else torch.tensor([], dtype=torch.float32, device=dev)
         output = [torch.tensor(generated, dtype=torch.int32, device=dev)]
         return (output, emb) if output_image else output

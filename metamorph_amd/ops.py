@@ -158,14 +158,27 @@ def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
     return out
 
 
-def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out=None):
+def rope_kv_append_(qkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache):
+    """qkv [B, (Hq+2Hkv)*d] new rows: rotate q (in place) and k at positions[b] (int32, device); k, v -> cache row positions[b]."""
+    _chk_dev(qkv, cos, sin, positions, k_cache, v_cache)
+    assert positions.dtype == torch.int32 and k_cache.stride() == v_cache.stride() and k_cache.stride(2) == 1
+    B = qkv.shape[0]
+    _lib.check(_L().mm355_rope_kv_append(qkv.data_ptr(), qkv.stride(0), B, Hq, Hkv, d, cos.data_ptr(), sin.data_ptr(), positions.data_ptr(),
+                                         k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0), _stream()),
+               "mm355_rope_kv_append")
+    return qkv
+
+
+def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out=None, workspace=None):
     """q [B, Hq*d]; caches [B, Lmax, Hkv*d]; kv_lens int32 [B] on the device (valid rows incl. the current one)."""
     _chk_dev(q, k_cache, v_cache, kv_lens)
     B = q.shape[0]
     assert k_cache.dim() == 3 and k_cache.shape == v_cache.shape and k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride()
     assert kv_lens.dtype == torch.int32 and max_kv_len <= k_cache.shape[1]
     out = torch.empty((B, Hq * d), device=q.device, dtype=BF16) if out is None else out
-    ws = torch.empty(int(_L().mm355_attn_decode_ws_floats(B, Hq, d, max_kv_len)), device=q.device, dtype=torch.float32)
+    ws = workspace
+    if ws is None:
+        ws = torch.empty(int(_L().mm355_attn_decode_ws_floats(B, Hq, d, max_kv_len)), device=q.device, dtype=torch.float32)
     _lib.check(_L().mm355_attn_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0),
                                       kv_lens.data_ptr(), max_kv_len, out.data_ptr(), out.stride(0), B, Hq, Hkv, d, scale, ws.data_ptr(),
                                       _stream()), "mm355_attn_decode")

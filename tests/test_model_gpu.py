@@ -282,3 +282,10 @@ def test_greedy_decode_cached_equals_reprefill():
     assert a.shape == b.shape and a.numel() >= 1
     same = (a == b).nonzero().numel()
     assert same >= a.numel() - 1 and int(a[0]) == int(b[0])     # bf16 near-ties may flip a late token, never the first
+    # the hipGraph replay of the decode step and eager launches are the same kernels on the same data: identical tokens
+    os.environ["MM355_DECODE_GRAPH"] = "0"
+    try:
+        c = model.greedy_decode(None, None, emb, max_new_tokens=8, use_cache=True)[0]
+    finally:
+        del os.environ["MM355_DECODE_GRAPH"]
+    assert torch.equal(a, c)

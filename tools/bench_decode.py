@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Decode throughput of the cached greedy loop (row N1) at LLaMA-3-8B geometry: ms/token and the weight-streaming rate."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from metamorph_amd.factory import LLAMA3_8B, build_model
+
+dev = torch.device("cuda:0")
+layers = int(os.environ.get("LAYERS", 32))
+model = build_model(dict(LLAMA3_8B, num_hidden_layers=layers), dict(num_hidden_layers=1), num_image_tokens=256, max_length=4096,
+                    device=dev, init_on_device=True).eval()
+h = 4096
+L0, new = int(os.environ.get("PROMPT", 512)), int(os.environ.get("NEW", 64))
+emb = (torch.randn(1, L0, h, device=dev) * 0.02).bfloat16()
+for use_cache in (True, False):
+    n = new if use_cache else min(new, 8)
+    model.greedy_decode(None, None, emb, max_new_tokens=2, use_cache=use_cache, eos_token_id=())
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = model.greedy_decode(None, None, emb, max_new_tokens=n, use_cache=use_cache, eos_token_id=())[0]
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    wbytes = sum(p.numel() for n_, p in model.named_parameters() if "vision_tower" not in n_ and "embed_tokens" not in n_) * 2
+    print(f"use_cache={use_cache}: {out.numel()} tokens in {dt*1e3:.1f} ms = {dt/out.numel()*1e3:.2f} ms/token"
+          f" (prompt {L0}; weights {wbytes/1e9:.1f} GB -> {wbytes*out.numel()/dt/1e12:.2f} TB/s if streamed once per token)", flush=True)
