@@ -5,3 +5,7 @@ class VideoReader:  # pragma: no cover
         raise RuntimeError("decord stub: video decoding is out of scope")
 def cpu(*a, **k):  # pragma: no cover
     return None
+
+
+def gpu(*a, **k):  # import-only stub (the reference's train.py imports the name)
+    raise RuntimeError("decord stub: video decoding is not available in the oracle environment")

@@ -42,7 +42,18 @@ class FakeTokenizer:
             ids.append(SPECIALS[w] if w in SPECIALS else self._word(w))
         return ids
 
-    def __call__(self, text):
+    def __call__(self, text, return_tensors=None, padding=None, max_length=None, truncation=False):
+        if isinstance(text, (list, tuple)):                  # batch form used by the reference's text-only preprocessing
+            import torch
+            rows = []
+            for t in text:
+                ids = ([self.bos_token_id] if self.add_bos else []) + self.encode_plain(t)
+                if truncation and max_length is not None:
+                    ids = ids[:max_length]
+                rows.append(ids)
+            n = max(len(r) for r in rows)
+            rows = [r + [self.pad_token_id] * (n - len(r)) for r in rows]
+            return SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.long) if return_tensors == "pt" else rows)
         ids = self.encode_plain(text)
         if self.add_bos:
             ids = [self.bos_token_id] + ids

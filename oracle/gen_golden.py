@@ -401,6 +401,77 @@ def gen_e2e():
             save_npz(f"e2e_{kind}_T{T}_ar{int(use_ar)}_{tag}.npz", **rec)
 
 
+# ----------------------------------------------------------------------------- N2 (batch producer)
+
+N2_SOURCES = {
+    "text_1round": [[{"from": "human", "value": "what is the capital of france"}, {"from": "gpt", "value": "paris of course"}]],
+    "text_batch2": [[{"from": "human", "value": "count to three"}, {"from": "gpt", "value": "one two three"}],
+                    [{"from": "human", "value": "say hi"}, {"from": "gpt", "value": "hi there my friend how are you today"}]],
+    "image_prompt": [[{"from": "human", "value": "<image>\nwhat is shown here"}, {"from": "gpt", "value": "a small red bird"}]],
+    "image_answer_2rounds": [[{"from": "human", "value": "hello"}, {"from": "gpt", "value": "hello there"},
+                              {"from": "human", "value": "draw a cat on a mat"}, {"from": "gpt", "value": "here it is <image>"}]],
+    "two_images_mixed": [[{"from": "human", "value": "<image> make it blue"}, {"from": "gpt", "value": "<image> done"}]],
+    "starts_with_gpt": [[{"from": "gpt", "value": "ignored greeting"}, {"from": "human", "value": "tell me a joke"},
+                         {"from": "gpt", "value": "knock knock"}]],
+    "open_answer": [[{"from": "human", "value": "<image> describe"}, {"from": "gpt", "value": ""}]],
+    "three_rounds": [[{"from": "human", "value": "a"}, {"from": "gpt", "value": "b c"}, {"from": "human", "value": "d e f"},
+                      {"from": "gpt", "value": "g"}, {"from": "human", "value": "h"}, {"from": "gpt", "value": "i j k l"}]],
+}
+
+
+def gen_n2():
+    """preprocess_multimodal + preprocess_llama3 + DataCollatorForSupervisedDataset of the reference (train.py:309-332,
+    501-597, 1251-1284) on the fake tokenizer; fixtures are the conversations and the integer outputs."""
+    import copy
+    import transformers
+    import transformers.pytorch_utils
+    import transformers.trainer as tr
+    if not hasattr(tr, "ALL_LAYERNORM_LAYERS"):
+        tr.ALL_LAYERNORM_LAYERS = transformers.pytorch_utils.ALL_LAYERNORM_LAYERS
+    import metamorph.train.train as T
+    from types import SimpleNamespace
+    cases = []
+    for name, sources in N2_SOURCES.items():
+        for add_bos in (True, False):
+            for use_se in (True, False):
+                for max_len in (4096, 12):
+                    has_image = any("<image>" in m["value"] for src in sources for m in src)
+                    if not has_image and use_se:
+                        continue
+                    tok = FakeTokenizer(add_bos=add_bos, model_max_length=max_len)
+                    src = copy.deepcopy(sources)
+                    src = T.preprocess_multimodal(src, SimpleNamespace(is_multimodal=True, mm_use_im_start_end=use_se))
+                    try:
+                        out = T.preprocess_llama3(copy.deepcopy(src), tok, has_image=has_image)
+                    except Exception as e:            # e.g. stacking ragged image prompts: the reference raises
+                        cases.append(dict(name=name, sources=sources, add_bos=add_bos, mm_use_im_start_end=use_se,
+                                          model_max_length=max_len, has_image=has_image, raises=type(e).__name__))
+                        continue
+                    cases.append(dict(name=name, sources=sources, add_bos=add_bos, mm_use_im_start_end=use_se,
+                                      model_max_length=max_len, has_image=has_image,
+                                      input_ids=out["input_ids"].tolist(), labels=out["labels"].tolist()))
+    # collator: ragged instances, truncation, images as lists of tensors
+    coll = []
+    g = torch.Generator().manual_seed(0)
+    for max_len in (4096, 6):
+        tok = FakeTokenizer(model_max_length=max_len)
+        inst = []
+        for n, nimg in ((5, 1), (9, 2), (3, 0)):
+            ids = torch.randint(3, 1000, (n,), generator=g)
+            lab = ids.clone(); lab[: n // 2] = -100
+            d = dict(input_ids=ids, labels=lab, image=[torch.full((3, 2, 2), float(10 * len(inst) + k)) for k in range(nimg)])
+            inst.append(d)
+        out = T.DataCollatorForSupervisedDataset(tokenizer=tok)(inst)
+        coll.append(dict(model_max_length=max_len, pad_token_id=tok.pad_token_id,
+                         instances=[dict(input_ids=d["input_ids"].tolist(), labels=d["labels"].tolist(),
+                                         image=[im.tolist() for im in d["image"]]) for d in inst],
+                         out=dict(input_ids=out["input_ids"].tolist(), labels=out["labels"].tolist(),
+                                  attention_mask=out["attention_mask"].tolist(), images=out["images"].tolist())))
+    with open(os.path.join(OUT, "n2_batch_producer.json"), "w") as f:
+        json.dump(dict(preprocess=cases, collate=coll), f, indent=0)
+    print(f"  wrote n2_batch_producer.json ({len(cases)} preprocess cases, {len(coll)} collate cases)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

@@ -254,3 +254,41 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
         if "vision_tower" not in k:
             assert torch.equal(v, sd2[k]), k
     assert m2.config.num_image_tokens == 4 and m2.config.model_type == "metamorph_llama"
+
+
+# ------------------------------------------------------------------ row N2: batch producer vs the reference's own outputs
+def _n2():
+    with open(os.path.join(GOLDEN, "n2_batch_producer.json")) as f:
+        return json.load(f)
+
+
+def test_preprocess_llama3_matches_reference():
+    """preprocess_multimodal + preprocess_llama3 (llama3 template, label masking incl. the mismatch rule) are integer-exact
+    against tests/golden/n2_batch_producer.json, recorded from the reference with the fake tokenizer."""
+    import copy
+    from types import SimpleNamespace
+    from metamorph_amd.data import preprocess, preprocess_multimodal
+    from oracle.fake_tokenizer import FakeTokenizer
+    cases = _n2()["preprocess"]
+    assert len(cases) >= 40
+    for c in cases:
+        tok = FakeTokenizer(add_bos=c["add_bos"], model_max_length=c["model_max_length"])
+        src = preprocess_multimodal(copy.deepcopy(c["sources"]), SimpleNamespace(is_multimodal=True, mm_use_im_start_end=c["mm_use_im_start_end"]))
+        out = preprocess(src, tok, has_image=c["has_image"])
+        tag = (c["name"], c["add_bos"], c["mm_use_im_start_end"], c["model_max_length"])
+        assert out["input_ids"].tolist() == c["input_ids"], tag
+        assert out["labels"].tolist() == c["labels"], tag
+        assert out["input_ids"].dtype == torch.long and out["labels"].dtype == torch.long
+
+
+def test_collator_matches_reference():
+    from metamorph_amd.data import DataCollatorForSupervisedDataset
+    from oracle.fake_tokenizer import FakeTokenizer
+    for c in _n2()["collate"]:
+        tok = FakeTokenizer(model_max_length=c["model_max_length"])
+        inst = [dict(input_ids=torch.tensor(d["input_ids"]), labels=torch.tensor(d["labels"]), image=[torch.tensor(im) for im in d["image"]])
+                for d in c["instances"]]
+        out = DataCollatorForSupervisedDataset(tokenizer=tok)(inst)
+        assert out["input_ids"].tolist() == c["out"]["input_ids"] and out["labels"].tolist() == c["out"]["labels"]
+        assert out["attention_mask"].tolist() == c["out"]["attention_mask"] and out["attention_mask"].dtype == torch.bool
+        assert out["images"].tolist() == c["out"]["images"]
