@@ -9,6 +9,7 @@
 // Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
 #include "attn2.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace attn3 {
 using namespace attn2;
@@ -144,16 +145,18 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
 
         f32x4 st[RQ][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
             }
-        }
         const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
@@ -382,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
 // query tiles of every query head of its GQA group, whose Q / dO rows and lse / delta arrive by LDS-DMA into a two-deep ring;
 // the group sum happens in the accumulators (no partials, no atomics)
 // ================================================================================================
+template <int ABL>
 __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
-    constexpr int KS = 4, NF = 8, QT = 64;
+    constexpr int KS = 4, NF = 8, QT = 64;   // ABL != 0: timing-only ablations (wrong results), see mm355_attn3_dkdv_launch
     constexpr int STAT = 512;                                // lse[64] | delta[64] fp32 per ring slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // Q ring [2] | dO ring [2] | stats [2]  (65 KiB)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -471,58 +475,65 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
         const int qt0 = q_start + itq * QT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 < n_tot) fetch(it + 1);
+        if (it + 1 < n_tot && (ABL != 4 || it < 1)) fetch(it + 1);
         const unsigned char* sQ = smem + (it & 1) * TILE;
         const unsigned char* sDO = smem + (2 + (it & 1)) * TILE;
         const float* sStat = (const float*)(smem + 4 * TILE + (it & 1) * STAT);
 
-        // S[i], dP[i] for the four 16-row fragments: lane holds X[q = i*16 + fq*4 + r][key = fr]
-        f32x4 s[4], dp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const bf16x8 qa = *(const bf16x8*)(sQ + i * 4096 + k_off[kk]);
-                const bf16x8 da = *(const bf16x8*)(sDO + i * 4096 + k_off[kk]);
-                s[i] = mfma16(qa, kf[kk], s[i]);
-                dp[i] = mfma16(da, vf[kk], dp[i]);
-            }
-        }
+        // Two halves of 32 query rows (= one k-slot of the second pair of products).  Source order puts the score MFMAs of
+        // half 1 between the softmax of half 0 and the dV / dK MFMAs of half 0, so that the matrix pipe has independent
+        // work while the VALU does the exponentials (the whole body is one basic block per mask variant).
         const bool need_mask = (qt0 + QT > seqlen) || (kv0 + 64 > seqlen) || (a.causal && qt0 < kv0 + 64);
-        auto softmax_bwd = [&](auto mask_c) {               // P in place of S, dS = P o (dP - delta) * scale in place of dP
+        auto body = [&](auto mask_c) {
             constexpr bool MASK = decltype(mask_c)::value;
             // visible query rows of this lane's key: [qmin, seqlen) -> tile-relative window [lo, lo + span)
             const int qmin = kg >= seqlen ? seqlen : (a.causal ? kg : 0);
             const int lo = qmin - qt0 - fq * 4;
             const unsigned span = (unsigned)(seqlen - qmin);
+            f32x4 s[4], dp[4];                               // S / dP fragments: lane holds X[q = i*16 + fq*4 + r][key = fr]
+            auto scores2 = [&](int i0) {                      // fragments i0, i0 + 1: four independent accumulator chains
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                for (int i = i0; i < i0 + 2; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int i = i0; i < i0 + 2; ++i) {
+                        const bf16x8 qa = ABL == 3 ? kf[(kk + 1) & 3] : *(const bf16x8*)(sQ + i * 4096 + k_off[kk]);
+                        const bf16x8 da = ABL == 3 ? vf[(kk + 1) & 3] : *(const bf16x8*)(sDO + i * 4096 + k_off[kk]);
+                        if (ABL != 5) { s[i] = mfma16(qa, kf[kk], s[i]); dp[i] = mfma16(da, vf[kk], dp[i]); }
+                        else { s[i][kk] += bflo((uint32_t)qa[0]); dp[i][kk] += bflo((uint32_t)da[0]); }
+                    }
+            };
+            auto soft = [&](int i) {                         // P in place of S, dS = P o (dP - delta) * scale in place of dP
                 const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
                 const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
+                    float p = ABL == 1 ? s[i][r] + l4[r] : __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
                     if (MASK) p = ((unsigned)(i * 16 + r - lo) < span) ? p : 0.f;
                     s[i][r] = p;
-                    dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;
+                    dp[i][r] = ABL == 1 ? dp[i][r] + d4[r] : p * (dp[i][r] - d4[r]) * a.scale;
                 }
-            }
+            };
+            auto grads = [&](int ks) {
+                const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
+                const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const bf16x8 dob8 = ABL == 2 ? kf[j & 3] : read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
+                    const bf16x8 qb8 = ABL == 2 ? vf[j & 3] : read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
+                    if (ABL != 5) { dvacc[j] = mfma16(pa, dob8, dvacc[j]); dkacc[j] = mfma16(dsa, qb8, dkacc[j]); }
+                    else { dvacc[j][0] += bflo((uint32_t)dob8[0]) + bflo((uint32_t)pa[0]); dkacc[j][0] += bflo((uint32_t)qb8[0]) + bflo((uint32_t)dsa[0]); }
+                }
+            };
+            scores2(0);
+            soft(0); soft(1);
+            scores2(2);
+            grads(0);
+            soft(2); soft(3);
+            grads(1);
         };
-        if (need_mask) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
-            const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const bf16x8 dob8 = read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
-                const bf16x8 qb8 = read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
-                dvacc[j] = mfma16(pa, dob8, dvacc[j]);
-                dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
-            }
-        }
+        if (need_mask) body(std::true_type{}); else body(std::false_type{});
     }
     __syncthreads();
     store_rows(dkacc, false, false);
@@ -547,17 +558,32 @@ int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
     return mm_launch_status();
 }
 
-int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
+template <int ABL>
+static int dkdv_launch_t(const attn2::Args& a, hipStream_t s) {
     constexpr int LDS = 4 * attn3::TILE + 2 * 512;           // 65 KiB > the default cap: raise it once
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MM355_ELAUNCH;
         attr_done = true;
     }
     const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hkv * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL(attn3::dkdv_kernel, grid, dim3(256), LDS, s, a);
+    hipLaunchKernelGGL(attn3::dkdv_kernel<ABL>, grid, dim3(256), LDS, s, a);
     return mm_launch_status();
+}
+
+int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
+    // MM355_ATTN_ABL=1..5: TIMING-ONLY ablations of the dK/dV kernel (results are wrong): 1 no exponentials, 2 no transpose
+    // reads, 3 no row reads, 4 no LDS-DMA after the second tile, 5 no MFMA
+    static const int abl = [] { const char* e = std::getenv("MM355_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    switch (abl) {
+        case 1: return dkdv_launch_t<1>(a, s);
+        case 2: return dkdv_launch_t<2>(a, s);
+        case 3: return dkdv_launch_t<3>(a, s);
+        case 4: return dkdv_launch_t<4>(a, s);
+        case 5: return dkdv_launch_t<5>(a, s);
+        default: return dkdv_launch_t<0>(a, s);
+    }
 }

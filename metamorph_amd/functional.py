@@ -559,7 +559,7 @@ class LinearCrossEntropyFn(Function):
     def forward(ctx, hidden, weight, head_module, plan_dev, n_valid):
         dev = hidden.device
         V, h = weight.shape
-        Vp = (V + 63) // 64 * 64
+        Vp = (V + 127) // 128 * 128                        # whole pairs of 64-wide K tiles for the dX GEMM (ping-pong kernel)
         rows = plan_dev["ce_rows"]                          # int32 [n_valid]
         tgt = plan_dev["ce_targets"]                        # int32 [n_valid]
         need_dh = hidden.requires_grad
