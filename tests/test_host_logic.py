@@ -292,3 +292,33 @@ def test_collator_matches_reference():
         assert out["input_ids"].tolist() == c["out"]["input_ids"] and out["labels"].tolist() == c["out"]["labels"]
         assert out["attention_mask"].tolist() == c["out"]["attention_mask"] and out["attention_mask"].dtype == torch.bool
         assert out["images"].tolist() == c["out"]["images"]
+
+
+# ------------------------------------------------------------------ row N3: checkpoint layouts of the reference's orchestration
+def test_adapter_checkpoint_layout(tmp_path):
+    """Stage-1 adapter files land where the reference's trainer puts them (train.py:186-209, metamorph_trainer.py:273-292)
+    and carry the parameters selected by name."""
+    from metamorph_amd.checkpoint import safe_save_model, save_mm_adapter, save_trainer_adapter_checkpoint
+    from metamorph_amd.factory import build_model
+    llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+               vocab_size=300, rms_norm_eps=1e-5, rope_theta=500000.0)
+    m = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
+    sd = dict(m.named_parameters())
+    p1 = save_mm_adapter(m, str(tmp_path / "run" / "checkpoint-30"))
+    assert p1 == str(tmp_path / "run" / "mm_projector" / "checkpoint-30.bin") and os.path.exists(p1)
+    assert os.path.exists(tmp_path / "run" / "checkpoint-30" / "config.json")
+    w = torch.load(p1)
+    assert set(w) == {k for k in sd if "mm_projector" in k} and len(w) == 4
+    assert all(torch.equal(w[k], sd[k].detach()) for k in w)
+    p2 = save_mm_adapter(m, str(tmp_path / "final"), use_im_start_end=True)
+    assert p2 == str(tmp_path / "final" / "mm_projector.bin")
+    assert "model.embed_tokens.weight" in torch.load(p2)
+    p3 = save_trainer_adapter_checkpoint(m, str(tmp_path / "run"), 77)
+    assert p3 == str(tmp_path / "run" / "checkpoint-77" / "mm_projector.bin") and os.path.exists(p3)
+    assert safe_save_model(m, str(tmp_path / "a"), tune_mm_mlp_adapter=True) == str(tmp_path / "a" / "mm_projector.bin")
+    safe_save_model(m, str(tmp_path / "full"))
+    assert os.path.exists(tmp_path / "full" / "config.json") and any(f.startswith("model") for f in os.listdir(tmp_path / "full"))
+    # the file is what initialize_vision_modules(pretrain_mm_mlp_adapter=...) consumes
+    m2 = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
+    m2.get_model().mm_projector.load_state_dict({k.split("mm_projector.")[1]: v for k, v in torch.load(p1).items()})
+    assert all(torch.equal(a, b) for a, b in zip(m.get_model().mm_projector.state_dict().values(), m2.get_model().mm_projector.state_dict().values()))

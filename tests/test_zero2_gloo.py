@@ -138,3 +138,70 @@ def test_single_process_world1(tmp_path):
     opt2 = Zero2AdamW(_make_params(torch.float32), lr=1e-2, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.master, opt.master) and opt2._step == 1
+
+
+# ------------------------------------------------------------------ row N3: world-size independent optimizer checkpoints
+class _Holder(torch.nn.Module):
+    def __init__(self, params):
+        super().__init__()
+        self.ps = torch.nn.ParameterList(params)
+
+
+def _ckpt_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metamorph_amd.checkpoint import consolidate_optimizer_state
+        from metamorph_amd.zero2 import Zero2AdamW
+        params = _make_params(torch.float32)
+        for p, key in zip(params, _SEGMENTS):
+            if key is not None:
+                p._mm_segment = key
+        model = _Holder(params)
+        opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, shard_update=_oracle_update, sumsq=_oracle_sumsq,
+                         clip_coef=_oracle_clip)
+        for s in (1, 2):
+            for p, g in zip(params, _grads_for(rank, s, params)):
+                p._mm_grad_buf.copy_(g); p.grad = p._mm_grad_buf
+            opt.step(); opt.zero_grad()
+        ck = consolidate_optimizer_state(opt, model)
+        if rank == 0:
+            torch.save(ck, os.path.join(tmp, "opt.pt"))
+            torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, "params2.pt"))
+        else:
+            assert ck is None
+        for p, g in zip(params, _grads_for(rank, 3, params)):
+            p._mm_grad_buf.copy_(g); p.grad = p._mm_grad_buf
+        opt.step()
+        if rank == 0:
+            torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, "params3.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_consolidated_optimizer_state_resumes_at_other_world_size(tmp_path):
+    """Two ranks (three segments) train two steps and write a consolidated optimizer checkpoint; ONE process without segments
+    loads it, applies step 3 on the summed gradient of both ranks and must land where the two ranks land."""
+    from metamorph_amd.checkpoint import load_consolidated_optimizer_state
+    from metamorph_amd.zero2 import Zero2AdamW
+    world = 2
+    mp.spawn(_ckpt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ck = torch.load(os.path.join(tmp_path, "opt.pt"))
+    assert ck["step"] == 2 and set(ck["state"]) == {f"ps.{i}" for i in range(6)}
+    assert ck["state"]["ps.0"]["exp_avg"].shape == (8, 16) and ck["state"]["ps.0"]["master"].dtype == torch.float32
+    params = _make_params(torch.float32)
+    model = _Holder(params)
+
+    def upd(p32, m, v, g, p_out, lr, b1, b2, eps, wd, step, scale_dev):      # two ranks' mean: the sum arrives, scale 1/2 folded in
+        _oracle_update(p32, m, v, g, p_out, lr, b1, b2, eps, wd, step, scale_dev)
+
+    opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, shard_update=upd, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+    load_consolidated_optimizer_state(opt, model, ck)
+    assert torch.allclose(torch.cat([p.data.reshape(-1) for p in params]), torch.load(os.path.join(tmp_path, "params2.pt")))
+    # step 3 with the MEAN gradient of the two ranks (world 1 divides by 1)
+    g0, g1 = _grads_for(0, 3, params), _grads_for(1, 3, params)
+    for p, a, b in zip(params, g0, g1):
+        p._mm_grad_buf.copy_((a + b) / 2); p.grad = p._mm_grad_buf
+    opt.step()
+    got = torch.cat([p.data.reshape(-1) for p in params])
+    torch.testing.assert_close(got, torch.load(os.path.join(tmp_path, "params3.pt")), rtol=1e-5, atol=1e-6)
