@@ -14,7 +14,8 @@
  *   - 16-byte aligned base pointers and leading dimensions that are multiples of 8 elements;
  *   - asynchronous on `stream` (a hipStream_t passed as void*);
  *   - returns 0 or a negative MM355_E* code; never throws, never exits;
- *   - re-entrant, no global mutable state.
+ *   - re-entrant; the only process-wide state is one-time kernel attribute setup (LDS size caps) and read-once tuning
+ *     environment variables (MM355_*), nothing that depends on the call sequence.
  */
 #ifndef MM355_H
 #define MM355_H
@@ -48,7 +49,8 @@ const char* mm355_strerror(int code);
  *   epilogue: v = acc; if BIAS v += bias[n]; if GELU_* v = gelu(v); if RESIDUAL v += R[m % res_mod][n];
  *             if ACCUMULATE v += C_old[m][n];  store as bf16 (or f32 with OUT_F32).
  * Requirements: K % 8 == 0, lda/ldb % 8 == 0 (ldc/ldr % 8 == 0 for bf16 vector stores, else scalar tail).
- * variant: 0 = auto; 1..n select a specific tile configuration (bench / tests).
+ * variant: 0 = auto (ping-pong 256x256 kernel, variant 11, once >= 200 tiles and K % 64 == 0; 128x128 LDS-DMA otherwise);
+ *          1..mm355_gemm_num_variants() select a specific tile configuration / schedule (bench / tests).
  * ------------------------------------------------------------------------------------------------ */
 #define MM355_GEMM_BIAS        1u
 #define MM355_GEMM_GELU_ERF    2u    /* nn.GELU() default (projector, vision_head)         */

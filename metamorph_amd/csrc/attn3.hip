@@ -72,6 +72,7 @@ MM_DEV void block_coords(int nx, int Hq, bool reverse, int& x, int& hq, int& b) 
 // ================================================================================================
 // forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
 // ================================================================================================
+template <bool PRIO>
 __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
     constexpr int KS = 4, NF = 8, RQ = 2, ROWS = 32, BQ = 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
             }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
                 }
             l_part[rq] += rs;
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 pb[RQ];
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
                 for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
             }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();                                         // ring is free: reuse it as the output staging area
 
@@ -546,7 +551,9 @@ int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
     const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL(attn3::fwd_kernel, grid, dim3(256), 0, s, a);
+    static const bool prio = [] { const char* e = std::getenv("MM355_ATTN_PRIO"); return e && e[0] == '1'; }();   // A/B knob
+    if (prio) hipLaunchKernelGGL(attn3::fwd_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn3::fwd_kernel<false>, grid, dim3(256), 0, s, a);
     return mm_launch_status();
 }
 
