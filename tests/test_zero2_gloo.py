@@ -205,3 +205,56 @@ def test_consolidated_optimizer_state_resumes_at_other_world_size(tmp_path):
     opt.step()
     got = torch.cat([p.data.reshape(-1) for p in params])
     torch.testing.assert_close(got, torch.load(os.path.join(tmp_path, "params3.pt")), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the real module tree: segments, hook wiring, overlap
+def _model_worker(rank, world, port, tmp, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metamorph_amd import functional as F
+        from metamorph_amd.factory import build_model
+        from metamorph_amd.zero2 import Zero2AdamW, tag_segments
+        torch.manual_seed(0)
+        llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=1,
+                   vocab_size=300, rms_norm_eps=1e-5, rope_theta=500000.0)
+        model = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
+        params = [p for p in model.parameters() if p.requires_grad]
+        tag_segments(model)
+        opt = Zero2AdamW(params, lr=1e-2, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip,
+                         overlap=overlap).enable_overlap()
+        layers = model.get_model().layers
+        # embeddings | layer 0 | layer 1 | layer 2 | final norm, projector, lm_head, vision head
+        assert len(opt.segs) == 5 and [sg["key"] for sg in opt.segs[1:4]] == [("layer", i) for i in range(3)]
+        for i, layer in enumerate(layers):                   # a layer's parameters are exactly its segment, fused blocks adjacent
+            assert {id(p) for p in layer.parameters()} == {id(p) for p in opt.segs[1 + i]["params"]}
+            att = layer.self_attn
+            assert att.k_proj.weight.data_ptr() == att.q_proj.weight.data_ptr() + att.q_proj.weight.numel() * 2
+        for step in (1, 2):
+            opt.arm_overlap()
+            g = torch.Generator().manual_seed(100 * step + rank)
+            # the backward pass: head / norm first, decoder layers last to first (each announces itself), embeddings last
+            order = [p for p in params if getattr(p, "_mm_segment", None) is None]
+            for p in order:
+                p._mm_grad_buf.copy_(torch.randn(p.shape, generator=g).to(p.dtype)); p.grad = p._mm_grad_buf
+            for i in reversed(range(len(layers))):
+                for p in layers[i].parameters():
+                    p._mm_grad_buf.copy_(torch.randn(p.shape, generator=g).to(p.dtype)); p.grad = p._mm_grad_buf
+                F._LAYER_GRAD_HOOK(layers[i])                # what DecoderLayerFn.backward does at its end
+                assert ((1 + i) in opt._pending) == bool(overlap)
+            opt.step()
+            opt.zero_grad()
+        torch.save(opt.flat_param.clone(), os.path.join(tmp, f"model_rank{rank}_ov{int(overlap)}.pt"))
+        F.set_layer_grad_hook(None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlap_on_the_real_module_tree(tmp_path):
+    """tag_segments + enable_overlap on the actual MetaMorph module tree (CPU parameters, gloo): one segment per decoder
+    layer, announcements start that layer's reduction, and the result is bit-identical to the non-overlapped schedule."""
+    for ov in (False, True):
+        mp.spawn(_model_worker, args=(2, _free_port(), str(tmp_path), ov), nprocs=2, join=True)
+    a0, a1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov0.pt")) for r in (0, 1))
+    b0, b1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov1.pt")) for r in (0, 1))
+    assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(a0, b0)
