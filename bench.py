@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=12, help="samples per GPU per step (each 2048 spliced tokens)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--image-tokens", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=1, help="images per sample (8 with --seq 4096 = BASELINE configs[2], a parity-test case)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
     ap.add_argument("--vit-layers", type=int, default=27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -45,26 +46,29 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(B, L, T, device, seed):
-    """[BOS,BOS, 20 text, <image_start>, <image>, <image_end>, text ...] padded so the SPLICED length is exactly L.
-    Samples 1..B-1 are image-QA (prompt-side image, labels -100 on the first 300 spliced positions); sample 0 is a
-    generation sample (answer-side image: the label at <image_start> is live) so the vision-head / cosine path runs and
-    the combined loss is finite (with no answer image the reference's loss is NaN)."""
+def make_batch(B, L, T, device, seed, frames=1):
+    """[BOS,BOS, 20 text, frames x (<image_start>, <image>, <image_end>), text ...] padded so the SPLICED length is exactly L.
+    Samples 1..B-1 are image-QA (prompt-side images, labels -100 on the prompt); sample 0 is a generation sample (its LAST
+    image is answer-side: the label at its <image_start> is live) so the vision-head / cosine path runs and the combined loss is
+    finite (with no answer image the reference's loss is NaN).  frames=8, L=4096 is BASELINE configs[2]."""
     g = torch.Generator().manual_seed(seed)
-    n_ids = L - T + 1
+    n_ids = L - frames * (T - 1)
     ids = torch.randint(0, 127999, (B, n_ids), generator=g)
     ids[:, 0] = 128000
     ids[:, 1] = 128000
-    ids[:, 22], ids[:, 23], ids[:, 24] = 128256, -200, 128257
+    img_pos = [22 + 3 * f + 1 for f in range(frames)]         # positions of the -200 markers
+    for p in img_pos:
+        ids[:, p - 1], ids[:, p], ids[:, p + 1] = 128256, -200, 128257
     labels = ids.clone()
-    spliced_pos = torch.arange(n_ids)
-    spliced_pos = torch.where(spliced_pos > 23, spliced_pos + T - 1, spliced_pos)
-    labels[:, spliced_pos < 300] = -100
-    labels[:, 23] = -100
-    labels[0, 20:] = ids[0, 20:]            # generation sample: supervise from just before <image_start>
-    labels[0, 23] = -200
+    prompt_end = img_pos[-1] + 2 + 20                         # images + 20 more prompt tokens are never supervised
+    labels[:, :prompt_end] = -100
+    for p in img_pos:
+        labels[:, p] = -100
+    last = img_pos[-1]
+    labels[0, last - 3:] = ids[0, last - 3:]                 # generation sample: supervise from just before the last <image_start>
+    labels[0, last] = -200
     mask = torch.ones(B, n_ids, dtype=torch.bool)
-    images = torch.randn(B, 3, 384, 384, generator=g)
+    images = torch.randn(B * frames, 3, 384, 384, generator=g)
     return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
 
 
@@ -201,7 +205,7 @@ def main():
     opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
-    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank)
+    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank, frames=args.frames)
     timer = GemmTimer()
     if not args.no_kernel_timing:
         timer.install()
@@ -261,7 +265,7 @@ def main():
     # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
     h, V, L = 4096, 128258, args.seq
     per_tok = 3.0 * (args.layers * (436.2076e6 + 2.0 * L * h) + 2.0 * h * V)
-    step_flops = per_tok * tokens_per_rank + args.batch * 666.5e9 * (args.vit_layers / 27.0)
+    step_flops = per_tok * tokens_per_rank + args.batch * args.frames * 666.5e9 * (args.vit_layers / 27.0)
     mfu = step_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
 
     if rank == 0:
@@ -273,7 +277,7 @@ def main():
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
                                    "bf16 full fine-tune (tower frozen), AdamW + ZeRO-2",
-                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens,
+                       "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        "parallelism": f"dp{world} zero2", "samples": f"{args.batch - 1} image-QA + 1 image-generation per GPU"},
             "loss": round(loss_val, 4), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
