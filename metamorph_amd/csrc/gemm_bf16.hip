@@ -76,12 +76,17 @@ MM_DEV void gemm_epilogue(f32x4 (&acc)[FM][FN], const GemmArgs& a, unsigned char
     const bool vec_ok = ((a.ldc & 7) == 0) && (!(fl & MM355_GEMM_RESIDUAL) || (a.ldr & 7) == 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        __syncthreads();
+        // the staging slab is private to this wave and the LDS executes one wave's instructions in order: a wave-level
+        // fence (no s_barrier) is all the write -> read -> next write hand-over needs; the caller has already made sure
+        // (block barrier) that nobody still reads the tile data this slab overlays
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int grow = m0 + wm * TM + i * 16 + row_l;
         if (grow < M) {
             const int64_t rr = (fl & MM355_GEMM_RESIDUAL) ? (a.res_mod > 0 ? (int64_t)(grow % a.res_mod) : (int64_t)grow) : 0;
