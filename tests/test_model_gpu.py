@@ -289,3 +289,37 @@ def test_greedy_decode_cached_equals_reprefill():
     finally:
         del os.environ["MM355_DECODE_GRAPH"]
     assert torch.equal(a, c)
+
+
+# ------------------------------------------------------------------ BASELINE configs[0] geometry class (TinyLlama: d = 64, GQA 8:1)
+def test_e2e_head_dim_64_gqa8_against_oracle():
+    """TinyLlama-style attention geometry (head size 64, eight query heads per KV head) goes through the generic attention
+    kernels (attn2) instead of the d = 128 LDS-DMA ones; loss and gradients against the CPU oracle on the same weights (fp32)."""
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))               # inputs only (ids / labels / images)
+    cfg = tiny_cfg(hidden_size=512, intermediate_size=768, num_attention_heads=8, num_key_value_heads=1, num_image_tokens=4)
+    seed = 11
+    model = hip_model(cfg, init_state_dict(cfg, seed=seed, dtype=torch.bfloat16))
+    model.train()
+    batch = dict(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), labels=T(g["labels"]), images=T(g["images"]))
+    out = model(input_ids=batch["input_ids"].to(DEV), attention_mask=batch["attention_mask"].to(DEV), labels=batch["labels"].to(DEV),
+                images=batch["images"].to(DEV).bfloat16())
+    sd = {k: v.bfloat16().float() for k, v in init_state_dict(cfg, seed=seed).items()}     # the same bf16-rounded weights, fp32 math
+    for k, v in sd.items():
+        v.requires_grad_("vision_tower" not in k and "vision_proj" not in k)
+    ref = oracle_forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"], return_logits=False)
+    got, want = float(out.loss.detach()), float(ref["loss"].detach())
+    print(f"\n   d=64 GQA8 loss hip={got:.5f} oracle={want:.5f}")
+    assert abs(got - want) <= 3e-3 * abs(want)
+    mask = ref["attention_mask"]
+    assert rel(out.hidden_states.float().cpu()[mask], ref["hidden_states"].detach()[mask]) <= 3e-2
+    out.loss.backward()
+    ref["loss"].backward()
+    params = dict(model.named_parameters())
+    n = 0
+    for k, v in sd.items():
+        if v.grad is None or k not in params:
+            continue
+        e = rel(params[k].grad, v.grad)
+        assert e <= 6e-2, (k, e)
+        n += 1
+    assert n >= 20
