@@ -64,9 +64,11 @@ def save_trainer_adapter_checkpoint(model, run_dir: str, global_step: int, use_i
 
 
 def safe_save_model(model, output_dir: str, tune_mm_mlp_adapter: bool = False, use_im_start_end: bool = False,
-                    is_main_process: bool = True):
+                    is_main_process: bool = True, optimizer=None):
     """Adapter-only runs write the adapter file; everything else the full HF checkpoint (rank 0 only: ZeRO-2 ranks hold
-    identical complete parameters)."""
+    identical complete parameters).  Pass the Zero2AdamW so that a pending asynchronous update is waited for first."""
+    if optimizer is not None:
+        optimizer.synchronize()
     if tune_mm_mlp_adapter:
         return save_mm_adapter(model, output_dir, use_im_start_end, is_main_process)
     if is_main_process:
@@ -81,6 +83,11 @@ def _param_names(model, opt):
 
 
 def consolidate_optimizer_state(opt, model, dst: int = 0):
+    opt.wait_all()
+    return _consolidate(opt, model, dst)
+
+
+def _consolidate(opt, model, dst):
     """All ranks call this.  Returns on rank `dst` {"step", "param_groups", "state": {name: {"master", "exp_avg", "exp_avg_sq"}}}
     with full fp32 tensors in each parameter's own shape (CPU), independent of world size and segmentation; None elsewhere."""
     names = _param_names(model, opt)

@@ -76,6 +76,22 @@ def set_layer_grad_hook(fn):
     _LAYER_GRAD_HOOK = fn
 
 
+_PARAM_READY_HOOK = None
+
+
+def set_param_ready_hook(fn):
+    """fn(key) is called before a group of trainable parameters is first read in a forward pass -- key = the decoder layer
+    module, or None for everything outside the decoder layers.  Zero2AdamW's asynchronous update makes the compute stream
+    wait there for that segment's update (and all-gather) instead of at the end of step()."""
+    global _PARAM_READY_HOOK
+    _PARAM_READY_HOOK = fn
+
+
+def params_ready(key=None):
+    if _PARAM_READY_HOOK is not None:
+        _PARAM_READY_HOOK(key)
+
+
 def grad_target(p):
     """(buffer, accumulate) for the gradient of parameter `p`."""
     if p.grad is not None:
@@ -290,6 +306,7 @@ class DecoderLayerFn(Function):
 
 
 def decoder_layer(x, layer, meta):
+    params_ready(layer)
     ws = [p for p in layer.parameters()]
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ws)):
         return DecoderLayerFn.apply(x, layer, meta, *ws)
@@ -382,6 +399,7 @@ def decoder_prefill(x, layers, meta, cache):
     nq, nk = meta.Hq * meta.d, meta.Hkv * meta.d
     L = x.shape[0]
     for i, layer in enumerate(layers):
+        params_ready(layer)
         x, saved = decoder_layer_forward(x, layer, meta)
         qkv = saved[0]
         cache.k[i, 0, :L].copy_(qkv[:, nq:nq + nk])
@@ -400,6 +418,7 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
         raise ValueError(f"KV cache full ({cache.max_len} rows)")
     nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
+        params_ready(layer)
         att, mlp = layer.self_attn, layer.mlp
         wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
         wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])

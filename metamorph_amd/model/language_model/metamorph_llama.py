@@ -232,6 +232,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
             raise NotImplementedError("output_attentions: attention probabilities are never materialised by the flash kernel")
         return_dict = True if return_dict is None else return_dict
         cfg = self.config
+        F.params_ready(None)
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         if inputs_embeds.dtype != BF16:
@@ -409,6 +410,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         if inputs_embeds.dtype != BF16:
             raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
         dev = inputs_embeds.device
+        F.params_ready(None)
         L0 = inputs_embeds.shape[1]
         num_image_tokens = self.get_model().vision_tower.image_token_len
         h, meta = self._decode_meta(L0)

@@ -120,6 +120,7 @@ class MetaMorphMetaForCausalLM(ABC):
         return self._project(image_features), image_features.detach()
 
     def _project(self, feats):
+        F.params_ready(None)                                 # first read of trainable parameters in a forward pass
         proj = self.get_model().mm_projector
         n, t, c = feats.shape
         y = proj(feats.reshape(n * t, c).to(BF16).contiguous())

@@ -74,7 +74,7 @@ class _Pending:
 
 class Zero2AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=None):
+                 process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=None, async_update=None):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("Zero2AdamW: no trainable parameters")
@@ -93,6 +93,17 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._armed = False
         self._pending = {}                 # segment index -> _Pending
         self._flatten(params)
+        # asynchronous update (opt-in, MM355_ZERO2_ASYNC=1): the per-segment AdamW kernels and all-gathers run on a side stream
+        # behind step(); the next forward pass waits per segment right before it reads that segment's parameters
+        # (functional.params_ready).  On ONE GPU it buys nothing (measured: the HBM-bound update slows the concurrent GEMMs by
+        # as much as it hides, 1014.9 vs 1012.7 ms/step); its purpose is hiding the all-gather at world > 1, which this round
+        # could not measure, hence off by default.
+        on_gpu = self.flat_param.is_cuda
+        self.async_update = on_gpu and ((os.environ.get("MM355_ZERO2_ASYNC", "0") == "1") if async_update is None else bool(async_update))
+        self._upd_stream = torch.cuda.Stream(device=self.flat_param.device) if self.async_update else None
+        self._ready = {}                   # segment index -> event recorded on the update stream
+        self._waited = set()
+        self._async_hooked = False
 
     # ------------------------------------------------------------------ layout
     def _flatten(self, params):
@@ -175,6 +186,7 @@ class Zero2AdamW(torch.optim.Optimizer):
     def arm_overlap(self):
         """Call before the backward pass whose gradients are final (the last micro-step of an accumulation window): from
         now until step(), notify_segment_ready() starts that segment's reduction right away."""
+        self.wait_all()                                      # the previous update has consumed the gradients before they are rewritten
         self._armed = self.overlap and self.world > 1
         return self
 
@@ -189,9 +201,12 @@ class Zero2AdamW(torch.optim.Optimizer):
         """Route DecoderLayerFn's "layer gradients are final" announcements to this optimizer."""
         from . import functional as F
         F.set_layer_grad_hook(lambda layer: self.notify_segment_ready(getattr(layer, "_mm_segment", None)))
+        if self.async_update:
+            self.enable_async_wait()
         return self
 
     def _reduce_grads(self):
+        self.wait_all()
         if self.world == 1:
             self._settle_grads(self.params)
             return
@@ -223,10 +238,86 @@ class Zero2AdamW(torch.optim.Optimizer):
             return [(0, self.padded, self.flat_grad, self.flat_param)]
         return [(sg["so"], sg["m"], sg["my_grad"], sg["my_param"]) for sg in self.segs]
 
+    # ------------------------------------------------------------------ asynchronous update
+    def _update_order(self):
+        """Segments outside the decoder layers first (embeddings, final norm, projector, heads: the next forward pass reads
+        them first and last), then the decoder layers in forward order."""
+        idx = list(range(len(self.segs)))
+        return [i for i in idx if self.segs[i]["key"] is None] + [i for i in idx if self.segs[i]["key"] is not None]
+
+    def _update_async(self, hyper):
+        main = torch.cuda.current_stream()
+        side = self._upd_stream
+        side.wait_stream(main)                               # gradients, norm and clip coefficient are final
+        self._ready, self._waited = {}, set()
+        nccl = self.world > 1 and dist.get_backend(self.pg) == "nccl"
+        with torch.cuda.stream(side):
+            prev = None                                      # (segment, all-gather work) one step behind the update kernels
+            for i in self._update_order():
+                sg = self.segs[i]
+                so, m, gs, ps = sg["so"], sg["m"], sg["my_grad"], sg["my_param"]   # (world 1: the slice is the whole segment)
+                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *hyper)
+                work = None
+                if self.world > 1:
+                    if not nccl:
+                        raise RuntimeError("asynchronous update needs the RCCL backend")
+                    work = dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg, async_op=True)
+                if prev is not None:
+                    self._finish_segment(*prev)
+                prev = (i, work)
+            if prev is not None:
+                self._finish_segment(*prev)
+
+    def _finish_segment(self, i, work):
+        if work is not None:
+            work.wait()                                      # the update stream waits for the all-gather of segment i
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._ready[i] = ev
+
+    def wait_segment(self, key):
+        """Make the current stream wait until the parameters of segment `key` (a `_mm_segment` key; None = every segment
+        outside the decoder layers) carry the last step()'s update.  No-op when nothing is pending."""
+        if not self._ready:
+            return
+        if key is None:
+            todo = [i for i, sg in enumerate(self.segs) if sg["key"] is None]
+        else:
+            i = self.seg_of_key.get(key)
+            todo = [] if i is None else [i]
+        cur = torch.cuda.current_stream()
+        for i in todo:
+            if i not in self._waited and i in self._ready:
+                cur.wait_event(self._ready[i])
+                self._waited.add(i)
+
+    def wait_all(self):
+        """Current stream waits for every pending segment update (call before reading parameters or optimizer state outside a
+        forward pass, and it is called before gradients are written again)."""
+        if self._ready:
+            cur = torch.cuda.current_stream()
+            for i, ev in self._ready.items():
+                if i not in self._waited:
+                    cur.wait_event(ev)
+            self._ready, self._waited = {}, set()
+
+    def enable_async_wait(self):
+        """Route the model's "about to read these parameters" announcements (functional.params_ready) to wait_segment."""
+        from . import functional as F
+        F.set_param_ready_hook(lambda layer: self.wait_segment(None if layer is None else getattr(layer, "_mm_segment", None)))
+        self._async_hooked = True
+        return self
+
     # ------------------------------------------------------------------ step
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
+
+    def synchronize(self):
+        """Host-side barrier on everything step() started."""
+        self.wait_all()
+        if self.flat_param.is_cuda:
+            torch.cuda.current_stream().synchronize()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -245,10 +336,15 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._step += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        for so, m, gs, ps in self._my_slices():
-            self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, float(g["lr"]), b1, b2,
-                               g["eps"], g["weight_decay"], self._step, self._coef)
-        self._all_gather_params()
+        hyper = (float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], self._step, self._coef)
+        if self.async_update:
+            self._update_async(hyper)
+            if not self._async_hooked:                       # nobody announces parameter reads: behave synchronously
+                self.wait_all()
+        else:
+            for so, m, gs, ps in self._my_slices():
+                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *hyper)
+            self._all_gather_params()
         self.grad_norm = self._norm_buf        # sum of squares of the summed gradient (device scalar); see grad_norm_value()
         return None
 
@@ -264,6 +360,7 @@ class Zero2AdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ checkpointing of the rank's shard
     def state_dict(self):
+        self.wait_all()
         return {"step": self._step, "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "world": self.world, "rank": self.rank, "total": self.total, "param_groups": [
                     {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}

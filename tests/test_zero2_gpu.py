@@ -110,3 +110,47 @@ def test_loss_curve_matches_oracle_training():
     assert ora_losses[-1] < ora_losses[0] - 0.3
     for s, (a, b) in enumerate(zip(hip_losses, ora_losses)):
         assert abs(a - b) <= 1.5e-2 * abs(b), f"step {s}: hip {a} vs oracle {b}"
+
+
+def test_async_update_equals_synchronous_update():
+    """The update kernels of step() run per segment on a side stream and the next forward pass waits segment by segment
+    (functional.params_ready): four training steps of the tiny model must give the same parameters with and without it."""
+    import os
+    from conftest import GOLDEN
+    from test_model_gpu import T, hip_model, tiny_cfg
+    from oracle.ref_model import init_state_dict
+    from metamorph_amd import functional as F
+    from metamorph_amd.zero2 import Zero2AdamW, tag_segments
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    args = dict(input_ids=T(g["input_ids"]).cuda(), attention_mask=T(g["attention_mask"]).cuda(), labels=T(g["labels"]).cuda(),
+                images=T(g["images"]).cuda().bfloat16())
+    results = []
+    for use_async in (False, True):
+        cfg = tiny_cfg(num_image_tokens=4)
+        model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+        model.train()
+        tag_segments(model)
+        opt = Zero2AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0, async_update=use_async)
+        opt.enable_overlap()
+        assert opt.async_update == use_async and len(opt.segs) == 2 + cfg.num_hidden_layers
+        losses = []
+        for _ in range(4):
+            opt.zero_grad()
+            out = model(**args)
+            opt.arm_overlap()
+            out.loss.backward()
+            opt.step()
+            if use_async:
+                assert opt._ready                      # updates are in flight / recorded, nothing was waited for on the host
+            losses.append(float(out.loss.detach()))
+        opt.synchronize()
+        results.append((losses, opt.flat_param.clone(), opt.master.clone()))
+        F.set_layer_grad_hook(None)
+        F.set_param_ready_hook(None)
+    # (run-to-run the loss / gradient sums use fp32 atomics, so two runs agree to rounding, not bit for bit)
+    for a, b in zip(results[0][0], results[1][0]):
+        assert abs(a - b) <= 2e-4 * abs(a), (results[0][0], results[1][0])
+    # Adam turns rounding-level gradient differences into +-lr steps on a few elements: compare the parameter vectors in norm
+    d = (results[0][2] - results[1][2]).norm() / results[0][2].norm()
+    assert float(d) <= 1e-3, float(d)
+    assert float((results[0][1].float() - results[1][1].float()).norm() / results[0][1].float().norm()) <= 2e-3
