@@ -183,9 +183,23 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # MM355_BENCH_FORCE_DIST=1 (+ MM355_ZERO2_FORCE_COLLECTIVES=1): drive the RCCL call pattern with a single rank under torchrun
+    force_dist = os.environ.get("MM355_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+        # stdout carries exactly ONE line (the JSON record): RCCL prints its NCCL_DEBUG=VERSION banner with printf when the
+        # communicator is created, so fd 1 points at stderr while that happens
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+            dist.barrier()                                       # forces communicator creation now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from metamorph_amd.factory import LLAMA3_8B, build_model
     from metamorph_amd.zero2 import Zero2AdamW, tag_segments
@@ -289,7 +303,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -85,6 +85,9 @@ class Zero2AdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
         self.max_grad_norm = max_grad_norm
+        # collectives are skipped at world size 1 unless MM355_ZERO2_FORCE_COLLECTIVES=1 (exercises the RCCL call pattern --
+        # in-place reduce-scatter / all-gather, async handles, side streams -- on a single-GPU box)
+        self._coll = self.distributed and (self.world > 1 or os.environ.get("MM355_ZERO2_FORCE_COLLECTIVES") == "1")
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq
         self._clip_coef = clip_coef or _hip_clip_coef
@@ -187,7 +190,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         """Call before the backward pass whose gradients are final (the last micro-step of an accumulation window): from
         now until step(), notify_segment_ready() starts that segment's reduction right away."""
         self.wait_all()                                      # the previous update has consumed the gradients before they are rewritten
-        self._armed = self.overlap and self.world > 1
+        self._armed = self.overlap and self._coll
         return self
 
     def notify_segment_ready(self, key):
@@ -207,7 +210,7 @@ class Zero2AdamW(torch.optim.Optimizer):
 
     def _reduce_grads(self):
         self.wait_all()
-        if self.world == 1:
+        if not self._coll:
             self._settle_grads(self.params)
             return
         for i in range(len(self.segs)):
@@ -219,7 +222,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._armed = False
 
     def _all_gather_params(self):
-        if self.world == 1:
+        if not self._coll:
             return
         if dist.get_backend(self.pg) == "nccl":
             works = [dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg, async_op=True) for sg in self.segs]
@@ -250,7 +253,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         side = self._upd_stream
         side.wait_stream(main)                               # gradients, norm and clip coefficient are final
         self._ready, self._waited = {}, set()
-        nccl = self.world > 1 and dist.get_backend(self.pg) == "nccl"
+        nccl = self._coll and dist.get_backend(self.pg) == "nccl"
         with torch.cuda.stream(side):
             prev = None                                      # (segment, all-gather work) one step behind the update kernels
             for i in self._update_order():
@@ -258,7 +261,7 @@ class Zero2AdamW(torch.optim.Optimizer):
                 so, m, gs, ps = sg["so"], sg["m"], sg["my_grad"], sg["my_param"]   # (world 1: the slice is the whole segment)
                 self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *hyper)
                 work = None
-                if self.world > 1:
+                if self._coll:
                     if not nccl:
                         raise RuntimeError("asynchronous update needs the RCCL backend")
                     work = dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg, async_op=True)
@@ -329,7 +332,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._norm_buf.zero_()
         for _, _, g, _ in self._my_slices():
             self._sumsq(g, self._norm_buf)
-        if self.world > 1:
+        if self._coll:
             dist.all_reduce(self._norm_buf, op=dist.ReduceOp.SUM, group=self.pg)
         # coef = min(1, max_norm / (||mean grad|| + 1e-6)) * (1/world), computed on the device (no host sync)
         self._clip_coef_scaled(inv_world)

@@ -154,3 +154,55 @@ def test_async_update_equals_synchronous_update():
     d = (results[0][2] - results[1][2]).norm() / results[0][2].norm()
     assert float(d) <= 1e-3, float(d)
     assert float((results[0][1].float() - results[1][1].float()).norm() / results[0][1].float().norm()) <= 2e-3
+
+
+def test_rccl_call_pattern_single_rank():
+    """The collective call pattern of the multi-GPU path -- in-place reduce-scatter per segment launched asynchronously from
+    DecoderLayerFn.backward, fp32 norm all-reduce, per-segment all-gather (synchronous and on the side stream) -- driven through
+    real RCCL with a one-rank process group (MM355_ZERO2_FORCE_COLLECTIVES=1): same losses as the collective-free run."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from conftest import GOLDEN
+    from test_model_gpu import T, hip_model, tiny_cfg
+    from oracle.ref_model import init_state_dict
+    from metamorph_amd import functional as F
+    from metamorph_amd.zero2 import Zero2AdamW, tag_segments
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    args = dict(input_ids=T(g["input_ids"]).cuda(), attention_mask=T(g["attention_mask"]).cuda(), labels=T(g["labels"]).cuda(),
+                images=T(g["images"]).cuda().bfloat16())
+
+    def train(async_update):
+        cfg = tiny_cfg(num_image_tokens=4)
+        model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+        model.train()
+        tag_segments(model)
+        opt = Zero2AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0, async_update=async_update)
+        opt.enable_overlap()
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            out = model(**args)
+            opt.arm_overlap()
+            out.loss.backward()
+            opt.step()
+            losses.append(float(out.loss.detach()))
+        opt.synchronize()
+        F.set_layer_grad_hook(None)
+        F.set_param_ready_hook(None)
+        return losses, opt
+
+    base, opt0 = train(False)
+    assert not opt0._coll
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MM355_ZERO2_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for async_update in (False, True):
+            losses, opt = train(async_update)
+            assert opt._coll and opt.world == 1
+            for a, b in zip(losses, base):
+                assert abs(a - b) <= 2e-4 * abs(b), (async_update, losses, base)
+    finally:
+        dist.destroy_process_group()
+        del os.environ["MM355_ZERO2_FORCE_COLLECTIVES"]
