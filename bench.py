@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=12, help="samples per GPU per step (each 2048 spliced tokens)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--image-tokens", type=int, default=256)
+    ap.add_argument("--all-generation", action="store_true", help="every sample is a generation sample (BASELINE configs[3], a parity-test case)")
     ap.add_argument("--frames", type=int, default=1, help="images per sample (8 with --seq 4096 = BASELINE configs[2], a parity-test case)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
     ap.add_argument("--vit-layers", type=int, default=27)
@@ -46,7 +47,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(B, L, T, device, seed, frames=1):
+def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
     """[BOS,BOS, 20 text, frames x (<image_start>, <image>, <image_end>), text ...] padded so the SPLICED length is exactly L.
     Samples 1..B-1 are image-QA (prompt-side images, labels -100 on the prompt); sample 0 is a generation sample (its LAST
     image is answer-side: the label at its <image_start> is live) so the vision-head / cosine path runs and the combined loss is
@@ -65,8 +66,9 @@ def make_batch(B, L, T, device, seed, frames=1):
     for p in img_pos:
         labels[:, p] = -100
     last = img_pos[-1]
-    labels[0, last - 3:] = ids[0, last - 3:]                 # generation sample: supervise from just before the last <image_start>
-    labels[0, last] = -200
+    gen = slice(0, B) if all_generation else slice(0, 1)     # BASELINE configs[3]: every sample regresses its answer image
+    labels[gen, last - 3:] = ids[gen, last - 3:]             # generation sample: supervise from just before the last <image_start>
+    labels[gen, last] = -200
     mask = torch.ones(B, n_ids, dtype=torch.bool)
     images = torch.randn(B * frames, 3, 384, 384, generator=g)
     return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
@@ -219,7 +221,7 @@ def main():
     opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
-    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank, frames=args.frames)
+    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank, frames=args.frames, all_generation=args.all_generation)
     timer = GemmTimer()
     if not args.no_kernel_timing:
         timer.install()
@@ -293,7 +295,7 @@ def main():
                                    "bf16 full fine-tune (tower frozen), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
-                       "parallelism": f"dp{world} zero2", "samples": f"{args.batch - 1} image-QA + 1 image-generation per GPU"},
+                       "parallelism": f"dp{world} zero2", "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
             "loss": round(loss_val, 4), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
