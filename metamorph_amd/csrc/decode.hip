@@ -13,14 +13,18 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------------ GEMV
-template <int MR>
+// KS = 1: a wave owns R = 4 weight rows over the whole K.  KS = 2 / 4 (small N): the 4 waves of a workgroup form 4 / KS row
+// groups x KS K-slices, partial sums meet in LDS -- 2x / 4x more waves in flight for the same N.
+template <int MR, int KS>
 __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W, int64_t ldw,
                                                   void* __restrict__ y, int64_t ldy, int M, int N, int K, const uint16_t* __restrict__ bias,
                                                   const uint16_t* __restrict__ res, int64_t ldr, uint32_t flags) {
     constexpr int R = 4;                                     // weight rows per wave
+    constexpr int RG = (NT / 64) / KS;                       // row groups per workgroup
+    __shared__ float part[NT / 64][MR * R];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * (NT / 64) + wave) * R;
-    if (n0 >= N) return;
+    const int rg = wave / KS, ks = wave % KS;
+    const int n0 = (blockIdx.x * RG + rg) * R;
     float acc[MR][R];
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -49,26 +53,54 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
                 for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
         }
     };
-    // two 512-element K chunks per trip: eight 16-B weight loads per lane in flight (a lone wave per SIMD must cover the HBM
-    // latency by itself when N is small)
-    int k = lane * 8;
-    for (; k + 512 < K; k += 1024) {
-        u32x4 w0[R], w1[R];
+    // this wave's K slice in 512-element chunks, two chunks per trip: eight 16-B weight loads per lane in flight
+    const int nch = (K + 511) / 512;
+    const int c0 = (nch * ks) / KS, c1 = (nch * (ks + 1)) / KS;
+    int c = c0;
+    if (n0 < N) {
+        for (; c + 1 < c1; c += 2) {
+            const int k = c * 512 + lane * 8;
+            u32x4 w0[R], w1[R];
+            const bool in1 = k + 512 < K;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { w0[r] = *(const u32x4*)(wr[r] + k); w1[r] = *(const u32x4*)(wr[r] + k + 512); }
-        fma_chunk(w0, k);
-        fma_chunk(w1, k + 512);
-    }
-    for (; k < K; k += 512) {
-        u32x4 w0[R];
+            for (int r = 0; r < R; ++r) { w0[r] = *(const u32x4*)(wr[r] + k); w1[r] = in1 ? *(const u32x4*)(wr[r] + k + 512) : u32x4{0u, 0u, 0u, 0u}; }
+            fma_chunk(w0, k);
+            if (in1) fma_chunk(w1, k + 512);
+        }
+        for (; c < c1; ++c) {
+            const int k = c * 512 + lane * 8;
+            if (k < K) {
+                u32x4 w0[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w0[r] = *(const u32x4*)(wr[r] + k);
-        fma_chunk(w0, k);
+                for (int r = 0; r < R; ++r) w0[r] = *(const u32x4*)(wr[r] + k);
+                fma_chunk(w0, k);
+            }
+        }
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
+    if constexpr (KS > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int r = 0; r < R; ++r) part[wave][m * R + r] = acc[m][r];
+        }
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < KS; ++q) v += part[rg * KS + q][m * R + r];
+                acc[m][r] = v;
+            }
+    }
+    if (n0 >= N) return;
     // lane (m * R + r) finishes output (m, n0 + r)
     if (lane < MR * R) {
         const int m = lane / R, r = lane % R, n = n0 + r;
@@ -280,13 +312,19 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
     if ((flags & MM355_GEMM_GELU_ERF) && (flags & MM355_GEMM_GELU_TANH)) return MM355_EINVAL;
     if (flags & MM355_GEMM_ACCUMULATE) return MM355_EUNSUPPORTED;
     if (N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
-    const unsigned grid = (unsigned)((N + 15) / 16);
     hipStream_t s = (hipStream_t)stream;
-#define GV(MR) hipLaunchKernelGGL(gemv_kernel<MR>, dim3(grid), dim3(NT), 0, s, x, ldx, W, ldw, y, ldy, (int)M, (int)N, (int)K, bias, residual, ldr, flags)
+    // few rows of a long K (down projection): split K over the waves of a workgroup; measured: K = 14336, N = 4096 28.5 -> 24.3 us,
+    // while at K = 4096 the extra LDS hand-over costs more than it buys (13.5 -> 17.7 us)
+    const int ksplit = (N <= 8192 && K >= 8192) ? 4 : 1;
+    const int rows_per_wg = 16 / ksplit;
+    const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
+#define GV2(MR, KSV) hipLaunchKernelGGL((gemv_kernel<MR, KSV>), dim3(grid), dim3(NT), 0, s, x, ldx, W, ldw, y, ldy, (int)M, (int)N, (int)K, bias, residual, ldr, flags)
+#define GV(MR) do { if (ksplit == 4) GV2(MR, 4); else if (ksplit == 2) GV2(MR, 2); else GV2(MR, 1); } while (0)
     if (M == 1) GV(1);
     else if (M == 2) GV(2);
     else if (M <= 4) GV(4);
     else GV(8);
+#undef GV2
 #undef GV
     return mm_launch_status();
 }
