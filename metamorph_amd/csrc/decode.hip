@@ -194,25 +194,49 @@ __global__ __launch_bounds__(NT) void attn_decode_split_kernel(const uint16_t* _
         sq[g][c] = bf2f(q[(int64_t)b * ld_q + (int64_t)(hk * G + g) * d + c]) * scale;
     }
     __syncthreads();
-    // ---- scores: thread = key
+    // ---- scores: lane = (key of a group of four, 16-B chunk of d); a wave walks its 64 keys four at a time, every K row is one
+    //      coalesced 256-B read, the query chunks sit in registers, the 16 chunk partials are folded with DPP row shifts
+    {
+        const int dc = lane & 15, kq = lane >> 4;
+        float qreg[G][8];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qreg[g][e] = (dc * 8 < d) ? sq[g][dc * 8 + e] : 0.f;
+        // all sixteen K rows of this lane are requested before the first one is used (independent 16-B loads in flight)
+        u32x4 kraw[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = k0 + wave * 64 + i * 4 + kq;
+            kraw[i] = (kk < kv_len && dc * 8 < d) ? *(const u32x4*)(kc + (int64_t)b * bs_kv + (int64_t)kk * ld_kv + (int64_t)hk * d + dc * 8)
+                                                  : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kl = wave * 64 + i * 4 + kq;               // key inside the chunk
+            const int kk = k0 + kl;
+            float kf[8];
+            unpack8(kraw[i], kf);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v = fmaf(kf[e], qreg[g][e], v);
+                // sum over the 16 lanes of a row: lane 15 ends up with the total
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+                if (dc == 15) sp[g][kl] = (kk < kv_len) ? v : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
     const int key = k0 + tid;
     float sc[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) sc[g] = 0.f;
-    if (key < kv_len) {
-        const uint16_t* kr = kc + (int64_t)b * bs_kv + (int64_t)key * ld_kv + (int64_t)hk * d;
-        for (int c = 0; c < d; c += 8) {
-            float kf[8];
-            unpack8(*(const u32x4*)(kr + c), kf);
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sc[g] = fmaf(kf[e], sq[g][c + e], sc[g]);
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) sc[g] = -INFINITY;
-    }
+    for (int g = 0; g < G; ++g) sc[g] = sp[g][tid];
+    __syncthreads();                                         // sp is rewritten with the probabilities below
     float mx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -238,14 +262,23 @@ __global__ __launch_bounds__(NT) void attn_decode_split_kernel(const uint16_t* _
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-    if (dc * 8 < d) {
+    {
         const int kend = min(CH, kv_len - k0);
-        for (int kk = kg; kk < kend; kk += 16) {
+        u32x4 vraw[16];                                      // sixteen independent 16-B loads in flight
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = kg + i * 16;
+            vraw[i] = (kk < kend && dc * 8 < d) ? *(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)hk * d + dc * 8)
+                                                : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = kg + i * 16;
             float vf[8];
-            unpack8(*(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)hk * d + dc * 8), vf);
+            unpack8(vraw[i], vf);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float p = sp[g][kk];
+                const float p = (kk < kend) ? sp[g][kk] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
             }
