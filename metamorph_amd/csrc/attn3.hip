@@ -72,9 +72,7 @@ MM_DEV void block_coords(int nx, int Hq, bool reverse, int& x, int& hq, int& b) 
 // ================================================================================================
 // forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
 // ================================================================================================
-template <int ABL>
 __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
-    constexpr bool PRIO = false;                             // ABL != 0: timing-only ablations (wrong results), see the launcher
     constexpr int KS = 4, NF = 8, RQ = 2, ROWS = 32, BQ = 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,22 +149,17 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bf16x8 kf = ABL == 4 ? qf[0][(kk + j) & 3] : *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-                    if (ABL != 5) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
-                    else st[rq][j][kk] += bflo((uint32_t)kf[0]);
-                }
+                for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
             }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
         const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
 #pragma unroll
-        for (int rq = 0; rq < (ABL == 2 ? 0 : RQ); ++rq) {
+        for (int rq = 0; rq < RQ; ++rq) {
             if (need_mask) {
                 const int qg = qw0 + rq * 16 + fr;
                 const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
@@ -195,13 +188,12 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = ABL == 1 ? fmaf(st[rq][j][r], sl2, -mref) : __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
                     st[rq][j][r] = p;
                     rs += p;
                 }
             l_part[rq] += rs;
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 pb[RQ];
@@ -209,15 +201,11 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args a) {
             for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const bf16x8 va = ABL == 3 ? qf[0][(kk + j) & 3] : read_nat_perm<DS>(sV, kk * 32, j, fr, fq);   // V^T[d][keys perm]
+                const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);          // V^T[d][keys perm]
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-                    if (ABL != 5) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
-                    else ot[rq][j][0] += bflo((uint32_t)va[0]) + bflo((uint32_t)pb[rq][0]);
-                }
+                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
             }
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();                                         // ring is free: reuse it as the output staging area
 
@@ -613,9 +601,8 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(Args a) {
 // query tiles of every query head of its GQA group, whose Q / dO rows and lse / delta arrive by LDS-DMA into a two-deep ring;
 // the group sum happens in the accumulators (no partials, no atomics)
 // ================================================================================================
-template <int ABL>
 __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
-    constexpr int KS = 4, NF = 8, QT = 64;   // ABL != 0: timing-only ablations (wrong results), see mm355_attn3_dkdv_launch
+    constexpr int KS = 4, NF = 8, QT = 64;
     constexpr int STAT = 512;                                // lse[64] | delta[64] fp32 per ring slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // Q ring [2] | dO ring [2] | stats [2]  (65 KiB)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -703,7 +690,7 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
         const int qt0 = q_start + itq * QT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 < n_tot && (ABL != 4 || it < 1)) fetch(it + 1);
+        if (it + 1 < n_tot) fetch(it + 1);
         const unsigned char* sQ = smem + (it & 1) * TILE;
         const unsigned char* sDO = smem + (2 + (it & 1)) * TILE;
         const float* sStat = (const float*)(smem + 4 * TILE + (it & 1) * STAT);
@@ -726,10 +713,10 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
                 for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                     for (int i = i0; i < i0 + 2; ++i) {
-                        const bf16x8 qa = ABL == 3 ? kf[(kk + 1) & 3] : *(const bf16x8*)(sQ + i * 4096 + k_off[kk]);
-                        const bf16x8 da = ABL == 3 ? vf[(kk + 1) & 3] : *(const bf16x8*)(sDO + i * 4096 + k_off[kk]);
-                        if (ABL != 5) { s[i] = mfma16(qa, kf[kk], s[i]); dp[i] = mfma16(da, vf[kk], dp[i]); }
-                        else { s[i][kk] += bflo((uint32_t)qa[0]); dp[i][kk] += bflo((uint32_t)da[0]); }
+                        const bf16x8 qa = *(const bf16x8*)(sQ + i * 4096 + k_off[kk]);
+                        const bf16x8 da = *(const bf16x8*)(sDO + i * 4096 + k_off[kk]);
+                        s[i] = mfma16(qa, kf[kk], s[i]);
+                        dp[i] = mfma16(da, vf[kk], dp[i]);
                     }
             };
             auto soft = [&](int i) {                         // P in place of S, dS = P o (dP - delta) * scale in place of dP
@@ -737,10 +724,10 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
                 const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = ABL == 1 ? s[i][r] + l4[r] : __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
                     if (MASK) p = ((unsigned)(i * 16 + r - lo) < span) ? p : 0.f;
                     s[i][r] = p;
-                    dp[i][r] = ABL == 1 ? dp[i][r] + d4[r] : p * (dp[i][r] - d4[r]) * a.scale;
+                    dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;
                 }
             };
             auto grads = [&](int ks) {
@@ -748,10 +735,10 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
                 const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const bf16x8 dob8 = ABL == 2 ? kf[j & 3] : read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
-                    const bf16x8 qb8 = ABL == 2 ? vf[j & 3] : read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
-                    if (ABL != 5) { dvacc[j] = mfma16(pa, dob8, dvacc[j]); dkacc[j] = mfma16(dsa, qb8, dkacc[j]); }
-                    else { dvacc[j][0] += bflo((uint32_t)dob8[0]) + bflo((uint32_t)pa[0]); dkacc[j][0] += bflo((uint32_t)qb8[0]) + bflo((uint32_t)dsa[0]); }
+                    const bf16x8 dob8 = read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
+                    const bf16x8 qb8 = read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
+                    dvacc[j] = mfma16(pa, dob8, dvacc[j]);
+                    dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
                 }
             };
             scores2(0);
@@ -790,17 +777,7 @@ int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
     const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);
-    // MM355_ATTN_ABL=1..5: TIMING-ONLY ablations (results are wrong): 1 no exponentials, 2 no softmax at all, 3 no transpose
-    // reads (V), 4 no row reads (K), 5 no MFMA
-    static const int abl = [] { const char* e = std::getenv("MM355_ATTN_ABL"); return e ? atoi(e) : 0; }();
-    switch (abl) {
-        case 1: hipLaunchKernelGGL(attn3::fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(attn3::fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(attn3::fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(attn3::fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
-        case 5: hipLaunchKernelGGL(attn3::fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(attn3::fwd_kernel<0>, grid, dim3(256), 0, s, a); break;
-    }
+    hipLaunchKernelGGL(attn3::fwd_kernel, grid, dim3(256), 0, s, a);
     return mm_launch_status();
 }
 
@@ -812,32 +789,17 @@ int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
     return mm_launch_status();
 }
 
-template <int ABL>
-static int dkdv_launch_t(const attn2::Args& a, hipStream_t s) {
+int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
     constexpr int LDS = 4 * attn3::TILE + 2 * 512;           // 65 KiB > the default cap: raise it once
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MM355_ELAUNCH;
         attr_done = true;
     }
     const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hkv * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL(attn3::dkdv_kernel<ABL>, grid, dim3(256), LDS, s, a);
+    hipLaunchKernelGGL(attn3::dkdv_kernel, grid, dim3(256), LDS, s, a);
     return mm_launch_status();
-}
-
-int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
-    // MM355_ATTN_ABL=1..5: TIMING-ONLY ablations of the dK/dV kernel (results are wrong): 1 no exponentials, 2 no transpose
-    // reads, 3 no row reads, 4 no LDS-DMA after the second tile, 5 no MFMA
-    static const int abl = [] { const char* e = std::getenv("MM355_ATTN_ABL"); return e ? atoi(e) : 0; }();
-    switch (abl) {
-        case 1: return dkdv_launch_t<1>(a, s);
-        case 2: return dkdv_launch_t<2>(a, s);
-        case 3: return dkdv_launch_t<3>(a, s);
-        case 4: return dkdv_launch_t<4>(a, s);
-        case 5: return dkdv_launch_t<5>(a, s);
-        default: return dkdv_launch_t<0>(a, s);
-    }
 }

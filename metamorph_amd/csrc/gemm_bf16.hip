@@ -321,7 +321,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         // four 16-MFMA units per K tile: (k-step, A half) = (0,lo) (0,hi) (1,lo) (1,hi); two rotating A register
         // sets X/Y and two B sets P/Q, each refilled from LDS one unit before it is consumed.
         bf16x8 X[HM], Y[HM], P[FN], Q[FN];
-        bool kt_live = false;                            // ablation builds only: skip LDS reads once the loop runs
         // TN layout: per-lane byte offsets of the 8-byte transposed-read granules (excluding the k-step immediate)
         int toA[TNL ? FM : 1], toB[TNL ? FN : 1];
         if constexpr (TNL) {
@@ -342,7 +341,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         };
         auto rdA = [&](bf16x8 (&af)[HM], int buf, int half, int kk) {
             const int sw = kk ? sw1 : sw0;
-            if constexpr (PIPE == 3 || PIPE == 4) { if (kt_live) return; }
             if constexpr (TNL) {
                 const unsigned char* sb = smem + buf * STAGE + kk * 32 * 512;
 #pragma unroll
@@ -355,7 +353,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         };
         auto rdB = [&](bf16x8 (&bf)[FN], int buf, int kk) {
             const int sw = kk ? sw1 : sw0;
-            if constexpr (PIPE == 3 || PIPE == 4) { if (kt_live) return; }
             if constexpr (TNL) {
                 const unsigned char* sb = smem + buf * STAGE + kk * 32 * 512;
 #pragma unroll
@@ -375,24 +372,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
                     acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[half * HM + i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        // L2 warm-up stream (PIPE == 5): one 4-byte LDS-DMA per lane into a scratch slab touches every 128-B line of
-        // a future tile (thread i -> row i of A for i < BM, row i-BM of B) two barriers before its real DMA is issued,
-        // so that the real DMA finds its lines in L2 and completes inside its one-tile window.
-        const uint16_t* tsrc = (tid < BM) ? a.A + (int64_t)min(m0 + tid, M - 1) * a.lda
-                                          : a.B + (int64_t)min(n0 + (tid - BM), N - 1) * a.ldb;
-        auto touch = [&](int kt) {
-            if constexpr (PIPE == 5) {
-                const int kc = min(kt, nk - 1) << 6;          // clamp: always exactly one touch per iteration (vmcnt bookkeeping)
-                __builtin_amdgcn_global_load_lds((gptr_t)(tsrc + kc), (lptr_t)(smem + 2 * STAGE + wave_s * 256), 4, 0, 0);
-            }
-        };
         gdma(0, 0);
         __syncthreads();
         if (nk > 1) gdma(1, 1);
-        touch(2);
         rdA(X, 0, 0, 0);
         rdB(P, 0, 0);
-        if constexpr (PIPE == 3 || PIPE == 4) { rdA(Y, 0, 1, 0); rdB(Q, 0, 1); kt_live = true; }
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             rdA(Y, cur, 1, 0);                              // unit 0: (k0, lo)
@@ -408,35 +392,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             mm(X, Q, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PIPE == 5) {
-                // counted wait: everything but the newest VMEM op (the L2 touch of tile kt+3, issued after the DMAs of
-                // tile kt+1... kt+2) must have landed; raw barrier so the compiler does not drain the touch as well
-                asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (kt + 2 < nk) gdma(kt + 2, cur);
-                touch(kt + 3);
-            } else {
-                __syncthreads();                             // tile kt+1 landed everywhere; buffer `cur` fully read
-                if constexpr (PIPE == 1 || PIPE == 3) { if (kt + 2 < nk) gdma(kt + 2, cur); }
-                if constexpr (PIPE == 6) {                   // ablation: global loads to registers only
-                    if (kt + 2 < nk) {
-                        const int k0 = (kt + 2) << 6;
-#pragma unroll
-                        for (int i = 0; i < AI; ++i) { const u32x4 t = *(const u32x4*)(srcA[i] + k0); asm volatile("" :: "v"(t)); }
-#pragma unroll
-                        for (int i = 0; i < BI; ++i) { const u32x4 t = *(const u32x4*)(srcB[i] + k0); asm volatile("" :: "v"(t)); }
-                    }
-                }
-                if constexpr (PIPE == 7) {                   // ablation: half of the DMA pieces
-                    if (kt + 2 < nk) {
-                        const int k0 = (kt + 2) << 6;
-                        unsigned char* sb = smem + cur * STAGE + wave_s * 1024;
-#pragma unroll
-                        for (int i = 0; i < AI; ++i)
-                            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sb + i * NW * 1024), 16, 0, 0);
-                    }
-                }
-            }
+            __syncthreads();                                 // tile kt+1 landed everywhere; buffer `cur` fully read
+            if (kt + 2 < nk) gdma(kt + 2, cur);
             if (kt + 1 < nk) {                                // unit 3: (k1, hi)
                 rdA(X, cur ^ 1, 0, 0);
                 rdB(P, cur ^ 1, 0);
@@ -892,7 +849,7 @@ int launch_gemm_ring(GemmArgs a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0, bool TNL = false>
 int launch_gemm(GemmArgs a, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int LDS = 2 * STAGE + (PIPE == 5 ? WM * WN * 256 : 0);
+    constexpr int LDS = 2 * STAGE;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS, PIPE, TNL>;
     static bool attr_done = false;                       // idempotent one-time attribute (benign race)
     if (!attr_done) {
@@ -997,14 +954,8 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 6: return launch_gemm<256, 256, 2, 4, true>(a, s);
         case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
-        case 9: return launch_gemm<256, 256, 2, 4, true, 5>(a, s);
         case 10: return launch_gemm_ring(a, s);
         case 11: return launch_gemm_pp(a, s);
-        case 96: return launch_gemm<256, 256, 2, 4, true, 6>(a, s);
-        case 97: return launch_gemm<256, 256, 2, 4, true, 7>(a, s);
-        case 92: return launch_gemm<256, 256, 2, 4, true, 2>(a, s);   // ablations (wrong results, timing only)
-        case 93: return launch_gemm<256, 256, 2, 4, true, 3>(a, s);
-        case 94: return launch_gemm<256, 256, 2, 4, true, 4>(a, s);
         default: return MM355_EUNSUPPORTED;
     }
 }
