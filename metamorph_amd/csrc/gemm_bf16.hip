@@ -412,7 +412,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Ring-pipelined 256x256 kernel: the K dimension is consumed in HALF tiles (BK = 32) from a ring of four 32-KiB LDS
-// slots.  Measurements (ablation variants above) showed that the cost of the staging is the BURST: when all eight waves
+// slots.  Measurements (timing-only ablation builds, since removed) suggested that the cost of the staging is the BURST: when all eight waves
 // issue their LDS-DMAs right after a barrier they queue in the texture path and no wave issues MFMAs meanwhile.  Here
 //   * each wave issues its 4 DMA pieces of half-tile s+3 two at a time IN BETWEEN its 16-MFMA units,
 //   * waits are counted (s_waitcnt vmcnt(8): the two most recent half-tiles may still be in flight), never a drain,
