@@ -105,6 +105,13 @@ int64_t mm355_rmsnorm_bwd_ws_floats(int64_t M, int64_t h);
 /* LayerNorm forward (SigLIP encoder, eps 1e-6); the tower is frozen in every shipped recipe. */
 int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y,
                         int64_t M, int64_t h, float eps, void* stream);
+/* LayerNorm backward (trainable tower; HF SiglipEncoderLayer.layer_norm1/2 under freeze_vision=False,
+ * siglip_encoder.py:138-141): dx = (dres ? dres : 0) + d/dx; dw_f32[h] += sum dy*xhat; db_f32[h] += sum dy, both summed in a
+ * fixed order from per-workgroup partial rows in `workspace` (mm355_layernorm_bwd_ws_floats(M, h) floats, 16-B aligned). */
+int64_t mm355_layernorm_bwd_ws_floats(int64_t M, int64_t h);
+int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres,
+                        mm355_bf16* dx, float* dw_f32, float* db_f32, float* workspace,
+                        int64_t M, int64_t h, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RoPE -- HF apply_rotary_pos_emb, rotate-half convention, theta from config; K9.
@@ -233,6 +240,10 @@ int mm355_im2col_patch(const void* images, int images_are_f32, int64_t N, int64_
                        mm355_bf16* out, int64_t Kp, void* stream);
 int mm355_bilinear_l2norm(const mm355_bf16* in, mm355_bf16* out, int64_t N, int64_t side_in, int64_t side_out,
                           int64_t C, int normalize, void* stream);
+/* backward of the above for a trainable tower (freeze_vision=False, siglip_encoder.py:139): d_in_f32[N][side_in^2][C] +=
+ * scatter of d/d(interpolated row) with the bilinear weights (caller zeroes d_in_f32; fp32 atomics). */
+int mm355_bilinear_l2norm_bwd(const mm355_bf16* in, const mm355_bf16* d_out, float* d_in_f32, int64_t N, int64_t side_in,
+                              int64_t side_out, int64_t C, int normalize, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cosine regression loss (metamorph_llama.py:433-435,449-455; K16).  pred_raw = vision_head output.

@@ -176,6 +176,98 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const uint16_t* __res
     }
 }
 
+// LayerNorm backward (trainable SigLIP tower).  Same walk as rmsnorm_bwd_kernel: a workgroup handles
+// `rows_per_block` rows, a thread owns fixed columns and keeps their dw / db partial sums in registers; the partial rows go to
+// the caller's workspace ([workgroup][2h]: dw | db) and are summed in a fixed order by rmsnorm_dw_reduce_kernel (no atomics).
+//   g = dy * w;  dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat));  dw += dy * xhat;  db += dy
+template <int VPT>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                           const uint16_t* __restrict__ w, const uint16_t* __restrict__ dres,
+                                                           uint16_t* __restrict__ dx, float* __restrict__ ws, int M, int h, float eps,
+                                                           int rows_per_block) {
+    __shared__ float red[NT / 64];
+    const int nv = h >> 3;
+    float wv[VPT][8], dwacc[VPT][8], dbacc[VPT][8];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[i][e] = 0.f; dbacc[i][e] = 0.f; wv[i][e] = 0.f; }
+        if (v < nv) unpack8(*(const u32x4*)(w + v * 8), wv[i]);
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int row = r0; row < r1; ++row) {
+        float xv[VPT][8], gv[VPT][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+                unpack8(*(const u32x4*)(x + (int64_t)row * h + v * 8), xv[i]);
+                unpack8(*(const u32x4*)(dy + (int64_t)row * h + v * 8), gv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += xv[i][e];
+            }
+        }
+        const float mean = block_sum<NT>(s, red) / (float)h;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[i][e] -= mean; ss += xv[i][e] * xv[i][e]; }
+            }
+        }
+        const float rstd = rsqrtf(block_sum<NT>(ss, red) / (float)h + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = xv[i][e] * rstd;
+                    xv[i][e] = xh;
+                    dwacc[i][e] += gv[i][e] * xh;
+                    dbacc[i][e] += gv[i][e];
+                    gv[i][e] *= wv[i][e];
+                    sg += gv[i][e];
+                    sgx += gv[i][e] * xh;
+                }
+            }
+        }
+        sg = block_sum<NT>(sg, red) / (float)h;
+        sgx = block_sum<NT>(sgx, red) / (float)h;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nv) {
+                float o[8];
+                if (dres) unpack8(*(const u32x4*)(dres + (int64_t)row * h + v * 8), o);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += rstd * (gv[i][e] - sg - xv[i][e] * sgx);
+                *(u32x4*)(dx + (int64_t)row * h + v * 8) = pack8(o);
+            }
+        }
+    }
+    float* wr = ws + (int64_t)blockIdx.x * 2 * h;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        if (v < nv) {
+            *(f32x4*)(wr + v * 8) = f32x4{dwacc[i][0], dwacc[i][1], dwacc[i][2], dwacc[i][3]};
+            *(f32x4*)(wr + v * 8 + 4) = f32x4{dwacc[i][4], dwacc[i][5], dwacc[i][6], dwacc[i][7]};
+            *(f32x4*)(wr + h + v * 8) = f32x4{dbacc[i][0], dbacc[i][1], dbacc[i][2], dbacc[i][3]};
+            *(f32x4*)(wr + h + v * 8 + 4) = f32x4{dbacc[i][4], dbacc[i][5], dbacc[i][6], dbacc[i][7]};
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cross entropy over rows of bf16 logits, gradient written in place.   one workgroup (512 thr) per row.
 // pass 1: online max / sum-exp;  pass 2: g = scale * (softmax - onehot)
@@ -350,6 +442,71 @@ __global__ __launch_bounds__(NT) void bilinear_l2norm_kernel(const uint16_t* __r
     }
 }
 
+// Backward of bilinear_l2norm_kernel (trainable tower): one wave per OUTPUT token recomputes the interpolated
+// row r and its norm, forms dr = (dy - y (y . dy)) / |r| (or dy when not normalising) and scatters it onto the four source
+// pixels with the bilinear weights (fp32 atomics into a caller-zeroed buffer: a source pixel feeds a handful of outputs).
+__global__ __launch_bounds__(NT) void bilinear_l2norm_bwd_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ dy,
+                                                                 float* __restrict__ din, int N, int si, int so, int C, int normalize) {
+    const int tok = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tok >= N * so * so) return;
+    const int n = tok / (so * so), oy = (tok / so) % so, ox = tok % so;
+    const int nv = C >> 3;
+    int y0, y1, x0, x1; float ly, lx;
+    if (si == so) { y0 = y1 = oy; x0 = x1 = ox; ly = lx = 0.f; }
+    else { lerp_src(oy, si, so, y0, y1, ly); lerp_src(ox, si, so, x0, x1, lx); }
+    const int64_t base = (int64_t)n * si * si * C;
+    const int64_t o00 = base + (int64_t)(y0 * si + x0) * C, o01 = base + (int64_t)(y0 * si + x1) * C;
+    const int64_t o10 = base + (int64_t)(y1 * si + x0) * C, o11 = base + (int64_t)(y1 * si + x1) * C;
+    const uint16_t* g = dy + (int64_t)tok * C;
+    auto interp = [&](int v, float* r) {
+        float a[8], bq[8], c[8], d[8];
+        unpack8(*(const u32x4*)(in + o00 + v * 8), a);
+        unpack8(*(const u32x4*)(in + o01 + v * 8), bq);
+        unpack8(*(const u32x4*)(in + o10 + v * 8), c);
+        unpack8(*(const u32x4*)(in + o11 + v * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float top = a[e] * (1.0f - lx) + bq[e] * lx;
+            const float bot = c[e] * (1.0f - lx) + d[e] * lx;
+            r[e] = round_bf(si == so ? a[e] : top * (1.0f - ly) + bot * ly);
+        }
+    };
+    float inv = 1.0f, dot = 0.f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int v = lane; v < nv; v += 64) {
+            float r[8], gy[8];
+            interp(v, r);
+            unpack8(*(const u32x4*)(g + v * 8), gy);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ss += r[e] * r[e]; dot += r[e] * gy[e]; }
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float nrm = fmaxf(round_bf(sqrtf(ss)), 1e-12f);
+        inv = 1.0f / nrm;
+        dot *= inv * inv;                                    // (y . dy) / |r|  with y = r / |r|
+    }
+    const float w00 = (1.0f - lx) * (1.0f - ly), w01 = lx * (1.0f - ly), w10 = (1.0f - lx) * ly, w11 = lx * ly;
+    for (int v = lane; v < nv; v += 64) {
+        float r[8], gy[8];
+        unpack8(*(const u32x4*)(g + v * 8), gy);
+        if (normalize) interp(v, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dr = normalize ? (gy[e] - r[e] * dot) * inv : gy[e];
+            if (si == so) atomicAdd(din + o00 + v * 8 + e, dr);
+            else {
+                atomicAdd(din + o00 + v * 8 + e, dr * w00);
+                atomicAdd(din + o01 + v * 8 + e, dr * w01);
+                atomicAdd(din + o10 + v * 8 + e, dr * w10);
+                atomicAdd(din + o11 + v * 8 + e, dr * w11);
+            }
+        }
+    }
+}
+
 template <typename F>
 int dispatch_vpt(int h, F&& f) {
     const int nv = h >> 3;
@@ -372,12 +529,12 @@ extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355
 }
 
 // dw[c] += sum_g ws[g][c]: 64 columns per workgroup, four row lanes, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int G, int h) {
+__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int G, int h, int ld) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     float acc = 0.f;
     if (c < h)
-        for (int g = rl; g < G; g += 4) acc += ws[(int64_t)g * h + c];
+        for (int g = rl; g < G; g += 4) acc += ws[(int64_t)g * ld + c];
     part[rl][threadIdx.x & 63] = acc;
     __syncthreads();
     if (rl == 0 && c < h) dw[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
@@ -409,7 +566,7 @@ extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, cons
     });
     if (rc != MM355_OK || !two_stage) return rc;
     hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, (hipStream_t)stream, workspace, dw_f32,
-                       (int)grid, (int)h);
+                       (int)grid, (int)h, (int)h);
     return mm_launch_status();
 }
 
@@ -421,6 +578,31 @@ extern "C" int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, con
         hipLaunchKernelGGL((layernorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, b, y, (int)h, eps);
         return mm_launch_status();
     });
+}
+
+extern "C" int64_t mm355_layernorm_bwd_ws_floats(int64_t M, int64_t h) {
+    if (M <= 0 || h <= 0) return 0;
+    const int rpb = rmsnorm_bwd_rows_per_block(M, true);
+    return ((M + rpb - 1) / rpb) * 2 * h;
+}
+
+extern "C" int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres, mm355_bf16* dx,
+                                   float* dw_f32, float* db_f32, float* workspace, int64_t M, int64_t h, float eps, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!dy || !x || !w || !dx || !dw_f32 || !db_f32 || !workspace || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff || !mm_aligned16(workspace))
+        return MM355_EINVAL;
+    const int rpb = rmsnorm_bwd_rows_per_block(M, true);
+    const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+    int rc = dispatch_vpt((int)h, [&](auto vpt) {
+        hipLaunchKernelGGL((layernorm_bwd_kernel<decltype(vpt)::value>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, x, w, dres, dx,
+                           workspace, (int)M, (int)h, eps, rpb);
+        return mm_launch_status();
+    });
+    if (rc != MM355_OK) return rc;
+    const dim3 rg((unsigned)((h + 63) / 64));
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, dw_f32, (int)grid, (int)h, (int)(2 * h));
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace + h, db_f32, (int)grid, (int)h, (int)(2 * h));
+    return mm_launch_status();
 }
 
 extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V, float grad_scale,
@@ -437,6 +619,17 @@ extern "C" int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* t
     if (!pred_raw || !target || !cos_sum || R <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
     const unsigned grid = (unsigned)((R + NT / 64 - 1) / (NT / 64));
     hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize, cos_sum, dpred);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_bilinear_l2norm_bwd(const mm355_bf16* in, const mm355_bf16* d_out, float* d_in_f32, int64_t N, int64_t side_in, int64_t side_out,
+                                         int64_t C, int normalize, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!in || !d_out || !d_in_f32 || N <= 0 || side_in <= 0 || side_out <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
+    const int64_t toks = N * side_out * side_out;
+    const unsigned grid = (unsigned)((toks + NT / 64 - 1) / (NT / 64));
+    hipLaunchKernelGGL(bilinear_l2norm_bwd_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, in, d_out, d_in_f32, (int)N, (int)side_in,
+                       (int)side_out, (int)C, normalize);
     return mm_launch_status();
 }
 

@@ -244,6 +244,19 @@ def layernorm_fwd(x, w, b, eps, out=None):
     return out
 
 
+def layernorm_bwd(dy, x, w, eps, dw_f32, db_f32, dres=None, dx=None):
+    """dx = (dres or 0) + d layernorm / dx; dw_f32 += sum dy*xhat, db_f32 += sum dy (deterministic two-stage sums)."""
+    _chk_dev(dy, x, w, dw_f32, db_f32)
+    assert dy.is_contiguous() and x.is_contiguous() and dw_f32.dtype == torch.float32 and db_f32.dtype == torch.float32
+    h = x.shape[-1]
+    M = x.numel() // h
+    dx = torch.empty_like(x) if dx is None else dx
+    ws = torch.empty(int(_L().mm355_layernorm_bwd_ws_floats(M, h)), dtype=torch.float32, device=x.device)
+    _lib.check(_L().mm355_layernorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), dw_f32.data_ptr(), db_f32.data_ptr(),
+                                        ws.data_ptr(), M, h, eps, _stream()), "mm355_layernorm_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------ rope / attention
 
 def rope_table(L, d, theta, device):
@@ -457,6 +470,19 @@ def bilinear_l2norm(feat, side_in, side_out, normalize):
     assert P == side_in * side_in
     out = torch.empty((N, side_out * side_out, C), device=feat.device, dtype=BF16)
     _lib.check(_L().mm355_bilinear_l2norm(feat.data_ptr(), out.data_ptr(), N, side_in, side_out, C, int(normalize), _stream()), "mm355_bilinear_l2norm")
+    return out
+
+
+def bilinear_l2norm_bwd(x, dy, side_in, side_out, normalize):
+    """Gradient of bilinear_l2norm w.r.t. x [N, side_in^2, C] (bf16) from dy [N, side_out^2, C]; returns bf16."""
+    _chk_dev(x, dy)
+    assert x.is_contiguous() and dy.is_contiguous()
+    N, _, C = x.shape
+    acc = torch.zeros(x.shape, device=x.device, dtype=torch.float32)
+    _lib.check(_L().mm355_bilinear_l2norm_bwd(x.data_ptr(), dy.data_ptr(), acc.data_ptr(), N, side_in, side_out, C, int(bool(normalize)),
+                                              _stream()), "mm355_bilinear_l2norm_bwd")
+    out = torch.empty_like(x)
+    cast_f32_to_bf16_2d(acc.view(-1, C), out.view(-1, C))
     return out
 
 

@@ -223,6 +223,23 @@ def test_layernorm_fwd(ops):
     close(y, R.layernorm(x.float(), w.float(), b.float(), 1e-6), 8e-3, 1e-2, "layernorm")
 
 
+@pytest.mark.parametrize("Mh", [(50, 1152), (9000, 1152), (37, 256)])
+def test_layernorm_bwd(ops, Mh):
+    M, h = Mh
+    x, dy, dres = rnd(M, h, seed=1), rnd(M, h, seed=2), rnd(M, h, seed=3)
+    w, b = (1 + 0.1 * rnd(h, seed=4).float()).bfloat16(), rnd(h, seed=5, scale=0.1)
+    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    R.layernorm(xf, wf, bf, 1e-6).backward(dy.float())
+    dw, db = torch.full((h,), 0.25, device=DEV), torch.full((h,), -0.5, device=DEV)      # accumulate onto what is there
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-6, dw, db, dres=dres.to(DEV))
+    close(dx, xf.grad + dres.float(), 1e-2, 2e-2, "layernorm dx")
+    close(dw - 0.25, wf.grad, 1e-3, 1e-3 * math.sqrt(M) + 1e-3, "layernorm dw")
+    close(db + 0.5, bf.grad, 1e-3, 1e-3 * math.sqrt(M) + 1e-3, "layernorm db")
+    dw2, db2 = torch.full((h,), 0.25, device=DEV), torch.full((h,), -0.5, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-6, dw2, db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                                 # fixed summation order
+
+
 # ------------------------------------------------------------------------------------------------ rope
 
 def test_rope(ops):
@@ -523,6 +540,22 @@ def test_bilinear_l2norm(ops, sides):
     y = R.bilinear_reduce(f, so * so)
     close(ops.bilinear_l2norm(f.to(DEV), si, so, False), y, 8e-3, 8e-3, "bilinear")
     close(ops.bilinear_l2norm(f.to(DEV), si, so, True), R.l2_normalize(y), 1e-2, 1e-3, "bilinear+l2")
+
+
+@pytest.mark.parametrize("sides", [(27, 16), (4, 2), (6, 6)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_bilinear_l2norm_bwd(ops, sides, normalize):
+    """Backward of the 729 -> T token reduction + L2 norm (trainable tower) against autograd through the oracle ops."""
+    si, so = sides
+    N, C = 2, 1152 if si == 27 else 64
+    x, dy = rnd(N, si * si, C, seed=1), rnd(N, so * so, C, seed=2)
+    xf = x.float().requires_grad_(True)
+    y = R.bilinear_reduce(xf, so * so) if si != so else xf
+    if normalize:
+        y = R.l2_normalize(y)
+    y.backward(dy.float())
+    got = ops.bilinear_l2norm_bwd(x.to(DEV), dy.to(DEV), si, so, normalize)
+    close(got, xf.grad, 2e-2, 2e-2 * float(xf.grad.abs().max()), f"bilinear_l2norm bwd {sides} normalize={normalize}")
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
