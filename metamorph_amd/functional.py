@@ -365,6 +365,169 @@ class LinearFn(Function):
         return dx, None, None, None
 
 
+def _param_grad_f32(p, s_f32):
+    """p.grad (+)= s_f32 (an fp32 reduction result such as a bias / norm-weight gradient), into the parameter's gradient buffer."""
+    buf, acc = grad_target(p)
+    ops.axpy_(buf.view(-1), s_f32.view(-1), None, 1.0, acc)
+    commit_grad(p, buf)
+
+
+def _linear_grads(mod, dy2d, x2d):
+    """Weight and bias gradients of y = x W^T + b from dy (may be a strided column block) and the saved input."""
+    if mod.weight.requires_grad:
+        buf, acc = grad_target(mod.weight)
+        weight_grad_gemm(dy2d, x2d, buf, acc)
+        commit_grad(mod.weight, buf)
+    if mod.bias is not None and mod.bias.requires_grad:
+        s = torch.zeros(mod.bias.shape[0], device=dy2d.device, dtype=torch.float32)
+        ops.colsum_f32(dy2d, s)
+        _param_grad_f32(mod.bias, s)
+
+
+# ------------------------------------------------------------------------------------------------
+# SigLIP encoder with a backward pass (SURVEY row N4: freeze_vision=False, reference siglip_encoder.py:138-141 running HF
+# SiglipEncoderLayer under grad).  Coarse nodes like DecoderLayerFn: forward keeps (x, qkv, o, lse, x2, fc1 pre-activation),
+# backward recomputes the two LayerNorms and the GELU, parameter gradients go straight to their gradient buffers.
+# ------------------------------------------------------------------------------------------------
+
+class SiglipGeo:
+    def __init__(self, N, P, heads, d, eps):
+        self.N, self.P, self.heads, self.d, self.eps = N, P, heads, d, eps
+        self.scale = d ** -0.5
+
+
+def _siglip_qkv(h1, att, hv):
+    qkv = torch.empty((h1.shape[0], 3 * hv), device=h1.device, dtype=BF16)
+    for i, proj in enumerate((att.q_proj, att.k_proj, att.v_proj)):     # HF stores k, v, q, out separately (with biases)
+        ops.gemm(h1, proj.weight.data, out=qkv[:, i * hv:(i + 1) * hv], bias=proj.bias.data)
+    return qkv
+
+
+class SiglipLayerFn(Function):
+    @staticmethod
+    def forward(ctx, x, layer, g, *params):
+        att, mlp = layer.self_attn, layer.mlp
+        hv = x.shape[1]
+        ln1, ln2 = layer.layer_norm1, layer.layer_norm2
+        h1 = ops.layernorm_fwd(x, ln1.weight.data, ln1.bias.data, g.eps)
+        qkv = _siglip_qkv(h1, att, hv)
+        del h1
+        o, lse = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], qkv[:, 2 * hv:], g.N, g.P, g.heads, g.heads, g.d, g.scale, False, None)
+        x2 = ops.gemm(o, att.out_proj.weight.data, bias=att.out_proj.bias.data, residual=x)
+        h2 = ops.layernorm_fwd(x2, ln2.weight.data, ln2.bias.data, g.eps)
+        f_pre = ops.gemm(h2, mlp.fc1.weight.data, bias=mlp.fc1.bias.data)
+        del h2
+        f = ops.gelu_fwd(f_pre, ops.GELU_TANH)
+        y = ops.gemm(f, mlp.fc2.weight.data, bias=mlp.fc2.bias.data, residual=x2)
+        ctx.layer, ctx.g = layer, g
+        ctx.save_for_backward(x, qkv, o, lse, x2, f_pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, o, lse, x2, f_pre = ctx.saved_tensors
+        layer, g = ctx.layer, ctx.g
+        att, mlp = layer.self_attn, layer.mlp
+        ln1, ln2 = layer.layer_norm1, layer.layer_norm2
+        hv = x.shape[1]
+        dev = x.device
+        dy = dy.contiguous()
+        # ---- MLP
+        f = ops.gelu_fwd(f_pre, ops.GELU_TANH)
+        df = input_grad_gemm(dy, mlp.fc2.weight)
+        _linear_grads(mlp.fc2, dy, f)
+        del f
+        dfp = ops.gelu_bwd(f_pre, df, ops.GELU_TANH)
+        del df
+        h2 = ops.layernorm_fwd(x2, ln2.weight.data, ln2.bias.data, g.eps)
+        dh2 = input_grad_gemm(dfp, mlp.fc1.weight)
+        _linear_grads(mlp.fc1, dfp, h2)
+        del h2, dfp
+        dw, db = torch.zeros(hv, device=dev, dtype=torch.float32), torch.zeros(hv, device=dev, dtype=torch.float32)
+        dx2 = ops.layernorm_bwd(dh2, x2, ln2.weight.data, g.eps, dw, db, dres=dy)       # dy + d LayerNorm2
+        del dh2
+        if ln2.weight.requires_grad:
+            _param_grad_f32(ln2.weight, dw)
+            _param_grad_f32(ln2.bias, db)
+        # ---- attention
+        do = input_grad_gemm(dx2, att.out_proj.weight)
+        _linear_grads(att.out_proj, dx2, o)
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :hv], qkv[:, hv:2 * hv], qkv[:, 2 * hv:], o, do, lse, g.N, g.P, g.heads, g.heads, g.d, g.scale, False, None,
+                     dqkv[:, :hv], dqkv[:, hv:2 * hv], dqkv[:, 2 * hv:])
+        del do
+        h1 = ops.layernorm_fwd(x, ln1.weight.data, ln1.bias.data, g.eps)
+        dh1 = None
+        for i, proj in enumerate((att.q_proj, att.k_proj, att.v_proj)):
+            blk = dqkv[:, i * hv:(i + 1) * hv]
+            dh1 = input_grad_gemm(blk, proj.weight, residual=dh1)
+            _linear_grads(proj, blk, h1)
+        del h1, dqkv
+        dw, db = torch.zeros(hv, device=dev, dtype=torch.float32), torch.zeros(hv, device=dev, dtype=torch.float32)
+        dx = ops.layernorm_bwd(dh1, x, ln1.weight.data, g.eps, dw, db, dres=dx2)
+        if ln1.weight.requires_grad:
+            _param_grad_f32(ln1.weight, dw)
+            _param_grad_f32(ln1.bias, db)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class PatchEmbedFn(Function):
+    """Conv2d(kernel = stride = patch) + bias + position embedding as im2col + GEMM; gradients of the three parameters."""
+
+    @staticmethod
+    def forward(ctx, images, emb, *params):
+        w = emb.patch_embedding.weight
+        k = w.shape[1] * w.shape[2] * w.shape[3]
+        kp = (k + 7) // 8 * 8
+        wpe = torch.zeros((w.shape[0], kp), device=w.device, dtype=BF16)
+        wpe[:, :k].copy_(w.data.reshape(w.shape[0], k))
+        p = w.shape[2]
+        N, _, H, W = images.shape
+        P = (H // p) * (W // p)
+        cols = ops.im2col_patch(images, p, kp)
+        x = ops.gemm(cols, wpe, bias=emb.patch_embedding.bias.data, residual=emb.position_embedding.weight.data, res_row_mod=P)
+        ctx.emb, ctx.k, ctx.N, ctx.P = emb, k, N, P
+        ctx.save_for_backward(cols)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        emb, k, N, P = ctx.emb, ctx.k, ctx.N, ctx.P
+        dy = dy.contiguous()
+        w, b, pos = emb.patch_embedding.weight, emb.patch_embedding.bias, emb.position_embedding.weight
+        hv = w.shape[0]
+        if w.requires_grad:
+            dwp = torch.empty((hv, cols.shape[1]), device=dy.device, dtype=BF16)
+            weight_grad_gemm(dy, cols, dwp, False)
+            buf, acc = grad_target(w)
+            ops.axpy_(buf.view(hv, k), dwp[:, :k].contiguous(), None, 1.0, acc)
+            commit_grad(w, buf)
+        if b.requires_grad:
+            s = torch.zeros(hv, device=dy.device, dtype=torch.float32)
+            ops.colsum_f32(dy, s)
+            _param_grad_f32(b, s)
+        if pos.requires_grad:                                   # every image adds the same table: sum over the images
+            s = torch.zeros(P * hv, device=dy.device, dtype=torch.float32)
+            ops.colsum_f32(dy.view(N, P * hv), s)
+            _param_grad_f32(pos, s)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class BilinearL2NormFn(Function):
+    @staticmethod
+    def forward(ctx, x, side_in, side_out, normalize):
+        ctx.args = (side_in, side_out, normalize)
+        ctx.save_for_backward(x)
+        return ops.bilinear_l2norm(x, side_in, side_out, normalize)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        side_in, side_out, normalize = ctx.args
+        return ops.bilinear_l2norm_bwd(x, dy.contiguous(), side_in, side_out, normalize), None, None, None
+
+
 def linear(x2d, module):
     if x2d.shape[0] <= 8 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad)):
         # decode shape: a handful of rows, inference only -> stream the weight once (mm355_gemv_bf16)

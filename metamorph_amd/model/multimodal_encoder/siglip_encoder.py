@@ -196,6 +196,31 @@ class HipSiglipVisionTransformer(nn.Module):
             x = ops.gemm(f, layer.mlp.fc2.weight.data, bias=layer.mlp.fc2.bias.data, residual=x)
         return x.view(N, P, hv)
 
+    def forward_features_train(self, images, select_layer=-1):
+        """The same computation with a backward pass (freeze_vision=False; reference siglip_encoder.py:138-141): autograd nodes
+        PatchEmbedFn / SiglipLayerFn write the tower's parameter gradients straight into their gradient buffers."""
+        from ... import functional as F
+        g = self.geometry
+        if self.dtype != BF16:
+            raise TypeError("SigLIP tower: the MI355X kernels compute in bf16; call .to(torch.bfloat16)")
+        if images.dtype not in (torch.float32, BF16):
+            images = images.float()
+        images = images.contiguous()
+        N, _, H, W = images.shape
+        p, hv, heads = g["patch_size"], g["hidden_size"], g["num_attention_heads"]
+        P = (H // p) * (W // p)
+        if P != self.embeddings.position_embedding.weight.shape[0]:
+            raise NotImplementedError("position-embedding interpolation for non-native resolutions is not implemented")
+        n_layers = len(self.encoder.layers)
+        run = select_layer if select_layer >= 0 else n_layers + 1 + select_layer
+        if not 0 <= run <= n_layers:
+            raise IndexError(f"mm_vision_select_layer={select_layer} out of range for {n_layers} layers")
+        x = F.PatchEmbedFn.apply(images, self.embeddings, *self.embeddings.parameters())
+        geo = F.SiglipGeo(N, P, heads, hv // heads, g["layer_norm_eps"])
+        for layer in self.encoder.layers[:run]:
+            x = F.SiglipLayerFn.apply(x, layer, geo, *layer.parameters())
+        return x.view(N, P, hv)
+
 
 class SiglipVisionTower(nn.Module):
     def __init__(self, vision_tower_name, args, delay_load=False):
@@ -247,9 +272,11 @@ class SiglipVisionTower(nn.Module):
         return hidden_last
 
     def forward(self, images):
-        if not self.freeze_vision and torch.is_grad_enabled() and any(p.requires_grad for p in self.vision_tower.parameters()):
-            raise NotImplementedError("trainable vision tower (freeze_vision=False) is out of scope: SURVEY.md section 8f row N4")
-        feats = self.feature_select(self.vision_tower.forward_features(images, self.select_layer))
+        train = not self.freeze_vision and torch.is_grad_enabled() and any(p.requires_grad for p in self.vision_tower.parameters())
+        if train:                                                # reference: torch.set_grad_enabled(not self.freeze_vision)
+            feats = self.feature_select(self.vision_tower.forward_features_train(images, self.select_layer))
+        else:
+            feats = self.feature_select(self.vision_tower.forward_features(images, self.select_layer))
         b, num_tokens, dim = feats.shape
         side_in = int(math.isqrt(num_tokens))
         side_out = side_in
@@ -263,6 +290,9 @@ class SiglipVisionTower(nn.Module):
             raise NotImplementedError("apply_softmax=True (soft-CE variant) has no HIP kernel; recipes use normalize_vision")
         if side_out == side_in and not self.normalize_vision:
             return feats
+        if train:
+            from ... import functional as F
+            return F.BilinearL2NormFn.apply(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
         return ops.bilinear_l2norm(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
 
     @property

@@ -90,9 +90,10 @@ def siglip_hidden(sd, cfg: OracleConfig, images: torch.Tensor, prefix="model.vis
     return x
 
 
-def vision_features(sd, cfg: OracleConfig, images: torch.Tensor):
-    """SiglipVisionTower.forward (frozen): tower -> cast to images.dtype -> reduce -> normalise."""
-    with torch.no_grad():
+def vision_features(sd, cfg: OracleConfig, images: torch.Tensor, train_vision: bool = False):
+    """SiglipVisionTower.forward: tower -> cast to images.dtype -> reduce -> normalise, under
+    torch.set_grad_enabled(not freeze_vision) (reference siglip_encoder.py:138-139)."""
+    with torch.set_grad_enabled(train_vision):
         f = siglip_hidden(sd, cfg, images).to(images.dtype)
         f = ops.bilinear_reduce(f, cfg.num_image_tokens)
         if cfg.normalize_vision:
@@ -192,8 +193,8 @@ def splice(sd, cfg: OracleConfig, input_ids, labels, attention_mask, proj_feat, 
 
 # ------------------------------------------------------------------ full forward
 
-def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True):
-    feat = vision_features(sd, cfg, images)                    # [N,T,hv], no grad
+def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False):
+    feat = vision_features(sd, cfg, images, train_vision)      # [N,T,hv]; no grad unless the tower trains (row N4)
     proj = mm_projector(sd, cfg, feat)                         # [N,T,h]
     target = feat.detach().clone()
     x, lab, key_valid, img_pos, target, _pid = splice(sd, cfg, input_ids, labels, attention_mask, proj, target)

@@ -323,3 +323,51 @@ def test_e2e_head_dim_64_gqa8_against_oracle():
         assert e <= 6e-2, (k, e)
         n += 1
     assert n >= 20
+
+
+# ------------------------------------------------------------------ row N4: trainable vision tower (freeze_vision=False)
+def test_trainable_vision_tower_gradients_against_oracle():
+    """reference siglip_encoder.py:138-139 (`torch.set_grad_enabled(not self.freeze_vision)`): with the tower unfrozen the loss
+    back-propagates through mm_projector, the 729 -> T reduction + L2 norm and every SigLIP encoder layer; gradients of all tower
+    parameters (patch embedding, position embedding, LayerNorms, q/k/v/out, fc1/fc2) against autograd through the CPU oracle."""
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    seed = 21
+    model = hip_model(cfg, init_state_dict(cfg, seed=seed, dtype=torch.bfloat16))
+    model.train()
+    tower = model.get_model().vision_tower
+    tower.freeze_vision = False
+    for n, p in tower.named_parameters():
+        p.requires_grad_("post_layernorm" not in n)
+    batch = dict(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), labels=T(g["labels"]), images=T(g["images"]))
+    out = model(input_ids=batch["input_ids"].to(DEV), attention_mask=batch["attention_mask"].to(DEV), labels=batch["labels"].to(DEV),
+                images=batch["images"].to(DEV).bfloat16())
+    sd = {k: v.bfloat16().float() for k, v in init_state_dict(cfg, seed=seed).items()}
+    for k, v in sd.items():
+        v.requires_grad_("vision_proj" not in k and "post_layernorm" not in k)
+    ref = oracle_forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"], return_logits=False,
+                         train_vision=True)
+    got, want = float(out.loss.detach()), float(ref["loss"].detach())
+    assert abs(got - want) <= 3e-3 * abs(want), (got, want)
+    out.loss.backward()
+    ref["loss"].backward()
+    params = dict(model.named_parameters())
+    n_tower = 0
+    for k, v in sd.items():
+        if "vision_tower" not in k or v.grad is None:
+            continue
+        assert params[k].grad is not None, k
+        if k.endswith("k_proj.bias"):
+            # softmax is invariant to a shift of all keys along q: the exact gradient is ZERO (the oracle shows fp32 noise);
+            # ours must be bf16 noise next to the q bias gradient
+            qb = float(sd[k.replace("k_proj", "q_proj")].grad.norm())
+            assert float(v.grad.norm()) <= 1e-4 * max(qb, 1e-12) and float(params[k].grad.float().norm()) <= 5e-2 * qb, k
+        else:
+            e = rel(params[k].grad, v.grad)
+            assert e <= 8e-2, (k, e)
+        n_tower += 1
+    print(f"\\n   trainable tower: loss hip={got:.5f} oracle={want:.5f}; {n_tower} tower gradient tensors checked")
+    assert n_tower == 3 + 16 * cfg.v_layers
+    # the frozen default still refuses nothing and produces no tower gradients
+    model2 = hip_model(cfg, init_state_dict(cfg, seed=seed, dtype=torch.bfloat16))
+    assert all(not p.requires_grad for p in model2.get_model().vision_tower.parameters())
