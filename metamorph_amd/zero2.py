@@ -75,11 +75,20 @@ class _Pending:
 class Zero2AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
                  process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=None, async_update=None):
-        params = [p for p in params if p.requires_grad]
-        if not params:
+        # `params`: an iterable of tensors, or of torch-style group dicts ({"params": [...], "lr": ..., "weight_decay": ...}) --
+        # e.g. the reference's separate `vision_lr` group for the tower (metamorph_trainer.py:201-233)
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            groups = [dict(g, params=[p for p in g["params"] if p.requires_grad]) for g in params]
+            groups = [g for g in groups if g["params"]]
+        else:
+            groups = [dict(params=[p for p in params if p.requires_grad])]
+        if not groups or not groups[0]["params"]:
             raise ValueError("Zero2AdamW: no trainable parameters")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        super().__init__(params, defaults)
+        super().__init__(groups, defaults)
+        self._group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        params = [p for g in self.param_groups for p in g["params"]]
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
@@ -117,9 +126,9 @@ class Zero2AdamW(torch.optim.Optimizer):
         chunk = ALIGN * self.world
         # consecutive parameters with the same `_mm_segment` key form a segment; NO padding inside a segment (fused q/k/v and
         # gate/up stay contiguous), every segment is padded to a multiple of ALIGN * world so that all slices stay aligned
-        runs = []
+        runs = []                                            # a segment never spans two parameter groups (their lr may differ)
         for p in params:
-            key = getattr(p, "_mm_segment", None)
+            key = (getattr(p, "_mm_segment", None), self._group_of[id(p)])
             if runs and runs[-1][0] == key:
                 runs[-1][1].append(p)
             else:
@@ -133,7 +142,7 @@ class Zero2AdamW(torch.optim.Optimizer):
                 pos += p.numel()
             n = (pos - lo + chunk - 1) // chunk * chunk
             pos = lo + n
-            segs.append({"key": key, "lo": lo, "n": n, "params": ps})
+            segs.append({"key": key[0], "group": key[1], "lo": lo, "n": n, "params": ps})
         self.padded = pos
         self.shard = self.padded // self.world
         self.flat_param = torch.zeros(self.padded, device=dev, dtype=dt)
@@ -236,10 +245,16 @@ class Zero2AdamW(torch.optim.Optimizer):
                     sg["param"][r * sg["m"]:(r + 1) * sg["m"]].copy_(t)
 
     def _my_slices(self):
-        """(shard offset, length, gradient slice, parameter slice) runs of this rank; one run when the slices are adjacent."""
-        if self.world == 1:
-            return [(0, self.padded, self.flat_grad, self.flat_param)]
-        return [(sg["so"], sg["m"], sg["my_grad"], sg["my_param"]) for sg in self.segs]
+        """(shard offset, length, gradient slice, parameter slice, group) runs of this rank; one run when the slices are
+        adjacent and share their hyper-parameters."""
+        if self.world == 1 and len(self.param_groups) == 1:
+            return [(0, self.padded, self.flat_grad, self.flat_param, 0)]
+        return [(sg["so"], sg["m"], sg["my_grad"], sg["my_param"], sg["group"]) for sg in self.segs]
+
+    def _hyper(self, gi):
+        g = self.param_groups[gi]
+        b1, b2 = g["betas"]
+        return (float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], self._step, self._coef)
 
     # ------------------------------------------------------------------ asynchronous update
     def _update_order(self):
@@ -248,7 +263,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         idx = list(range(len(self.segs)))
         return [i for i in idx if self.segs[i]["key"] is None] + [i for i in idx if self.segs[i]["key"] is not None]
 
-    def _update_async(self, hyper):
+    def _update_async(self):
         main = torch.cuda.current_stream()
         side = self._upd_stream
         side.wait_stream(main)                               # gradients, norm and clip coefficient are final
@@ -259,7 +274,7 @@ class Zero2AdamW(torch.optim.Optimizer):
             for i in self._update_order():
                 sg = self.segs[i]
                 so, m, gs, ps = sg["so"], sg["m"], sg["my_grad"], sg["my_param"]   # (world 1: the slice is the whole segment)
-                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *hyper)
+                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *self._hyper(sg["group"]))
                 work = None
                 if self._coll:
                     if not nccl:
@@ -330,23 +345,20 @@ class Zero2AdamW(torch.optim.Optimizer):
         inv_world = 1.0 / self.world
         # global L2 norm of the MEAN gradient: sqrt(sum over shards) * 1/world
         self._norm_buf.zero_()
-        for _, _, g, _ in self._my_slices():
+        for _, _, g, _, _ in self._my_slices():
             self._sumsq(g, self._norm_buf)
         if self._coll:
             dist.all_reduce(self._norm_buf, op=dist.ReduceOp.SUM, group=self.pg)
         # coef = min(1, max_norm / (||mean grad|| + 1e-6)) * (1/world), computed on the device (no host sync)
         self._clip_coef_scaled(inv_world)
         self._step += 1
-        g = self.param_groups[0]
-        b1, b2 = g["betas"]
-        hyper = (float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], self._step, self._coef)
         if self.async_update:
-            self._update_async(hyper)
+            self._update_async()
             if not self._async_hooked:                       # nobody announces parameter reads: behave synchronously
                 self.wait_all()
         else:
-            for so, m, gs, ps in self._my_slices():
-                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *hyper)
+            for so, m, gs, ps, gi in self._my_slices():
+                self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *self._hyper(gi))
             self._all_gather_params()
         self.grad_norm = self._norm_buf        # sum of squares of the summed gradient (device scalar); see grad_norm_value()
         return None

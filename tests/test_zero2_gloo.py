@@ -258,3 +258,29 @@ def test_overlap_on_the_real_module_tree(tmp_path):
     a0, a1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov0.pt")) for r in (0, 1))
     b0, b1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov1.pt")) for r in (0, 1))
     assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(a0, b0)
+
+
+def test_param_groups_with_their_own_learning_rate():
+    """torch-style parameter groups (the reference's `vision_lr` group, metamorph_trainer.py:201-233): each group is updated with
+    its own lr / weight decay, a segment never spans two groups, and the result equals per-group oracle AdamW steps under one
+    global clipping coefficient."""
+    from metamorph_amd.zero2 import Zero2AdamW
+    params = _make_params(torch.float32)
+    ref = [p.detach().clone() for p in params]
+    groups = [dict(params=params[:4], lr=1e-2, weight_decay=0.1), dict(params=params[4:], lr=1e-3, weight_decay=0.0)]
+    opt = Zero2AdamW(groups, betas=(0.9, 0.95), shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+    assert len(opt.segs) == 2 and [sg["group"] for sg in opt.segs] == [0, 1]
+    m = [torch.zeros_like(p) for p in ref]
+    v = [torch.zeros_like(p) for p in ref]
+    for step in (1, 2):
+        grads = _grads_for(0, step, params)
+        for p, g in zip(params, grads):
+            p._mm_grad_buf.copy_(g); p.grad = p._mm_grad_buf
+        opt.step(); opt.zero_grad()
+        norm = float(torch.sqrt(sum((g.float() ** 2).sum() for g in grads)))
+        coef = min(1.0, 1.0 / (norm + 1e-6))
+        for i, (r, g) in enumerate(zip(ref, grads)):
+            lr, wd = (1e-2, 0.1) if i < 4 else (1e-3, 0.0)
+            R.adamw_step(r, g, m[i], v[i], step, lr, 0.9, 0.95, 1e-8, wd, grad_scale=coef)
+    for p, r in zip(params, ref):
+        torch.testing.assert_close(p.data, r, rtol=1e-5, atol=1e-6)
