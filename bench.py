@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=12, help="samples per GPU per step (each 2048 spliced tokens)")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--image-tokens", type=int, default=256)
+    ap.add_argument("--train-vision", action="store_true", help="freeze_vision=False: the SigLIP tower trains too, own lr group (SURVEY row N4)")
     ap.add_argument("--all-generation", action="store_true", help="every sample is a generation sample (BASELINE configs[3], a parity-test case)")
     ap.add_argument("--frames", type=int, default=1, help="images per sample (8 with --seq 4096 = BASELINE configs[2], a parity-test case)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
@@ -212,12 +213,20 @@ def main():
     t_build = time.time()
     model = build_model(llm, geo, num_image_tokens=args.image_tokens, max_length=4096, device=dev, init_on_device=True)
     model.train()
+    if args.train_vision:                                        # reference: freeze_vision=False + `vision_lr` parameter group
+        tower = model.get_model().vision_tower
+        tower.freeze_vision = False
+        for n, p in tower.named_parameters():
+            p.requires_grad_("post_layernorm" not in n)
     params = [p for p in model.parameters() if p.requires_grad]
     n_params = sum(p.numel() for p in params)
     if world > 1:                                                # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
     tag_segments(model)                                          # one gradient-reduction segment per decoder layer
+    if args.train_vision:
+        vis = {id(p) for p in model.get_model().vision_tower.parameters()}
+        params = [dict(params=[p for p in params if id(p) not in vis], lr=2e-5), dict(params=[p for p in params if id(p) in vis], lr=2e-6)]
     opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
@@ -281,7 +290,7 @@ def main():
     # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
     h, V, L = 4096, 128258, args.seq
     per_tok = 3.0 * (args.layers * (436.2076e6 + 2.0 * L * h) + 2.0 * h * V)
-    step_flops = per_tok * tokens_per_rank + args.batch * args.frames * 666.5e9 * (args.vit_layers / 27.0)
+    step_flops = per_tok * tokens_per_rank + args.batch * args.frames * 666.5e9 * (args.vit_layers / 27.0) * (3.0 if args.train_vision else 1.0)
     mfu = step_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
 
     if rank == 0:
@@ -292,7 +301,7 @@ def main():
             "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/pixels)",
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
-                                   "bf16 full fine-tune (tower frozen), AdamW + ZeRO-2",
+                                   "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        "parallelism": f"dp{world} zero2", "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
