@@ -95,19 +95,33 @@ class GemmTimer:
             e.record()
             M, K = a.shape
             N = kw.get("n") or b.shape[0]
-            self.records.append((s, e, 2.0 * M * N * K, (M, N, K)))
+            self.records.append((s, e, 2.0 * M * N * K, (M, N, K), 2.0 * (M * K + N * K + M * N)))
             return r
         self.ops.gemm = timed
         import metamorph_amd.functional as F
         F.ops.gemm = timed
+        orig_pair = self.ops.gemm_pair
+
+        def timed_pair(a0, b0, out0, acc0, a1, b1, out1, acc1):     # two problems, one launch: flops of both, one duration
+            if not self.enabled:
+                return orig_pair(a0, b0, out0, acc0, a1, b1, out1, acc1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_pair(a0, b0, out0, acc0, a1, b1, out1, acc1)
+            e.record()
+            (m0, k0), n0, (m1, k1), n1 = a0.shape, b0.shape[0], a1.shape, b1.shape[0]
+            self.records.append((s, e, 2.0 * (m0 * n0 * k0 + m1 * n1 * k1), ("pair", m0, n0, k0, m1, n1, k1),
+                                 2.0 * (m0 * k0 + n0 * k0 + m0 * n0 + m1 * k1 + n1 * k1 + m1 * n1)))
+            return r
+        self.ops.gemm_pair = timed_pair
 
     def summary(self):
         torch.cuda.synchronize()
-        t = sum(s.elapsed_time(e) for s, e, _, _ in self.records) * 1e-3
-        fl = sum(f for _, _, f, _ in self.records)
+        t = sum(r[0].elapsed_time(r[1]) for r in self.records) * 1e-3
+        fl = sum(r[2] for r in self.records)
         if os.environ.get("MM355_BENCH_GEMM_TABLE") == "1":   # per-shape breakdown on stderr (tuning aid)
             by = {}
-            for s, e, f, shp in self.records:
+            for s, e, f, shp, _ in self.records:
                 c = by.setdefault(shp, [0, 0.0, 0.0])
                 c[0] += 1; c[1] += s.elapsed_time(e) * 1e-3; c[2] += f
             for shp, (n, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
@@ -280,7 +294,7 @@ def main():
             for k in json.load(open(tpath))["kernels"]:
                 if k["kernel"].startswith("gemm_pp_kernel<false, false>"):
                     traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/r1_step_b12_hbm_traffic_e.json"
-        alg_bytes = sum(2.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k) in timer.records) / n_gemm
+        alg_bytes = sum(r[4] for r in timer.records) / n_gemm
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over launches",

@@ -65,6 +65,18 @@ int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64
                     uint32_t flags, int variant, void* stream);
 int mm355_gemm_num_variants(void);
 
+/* Two independent problems of the form above, C0 (+)= A0 . B0^T and C1 (+)= A1 . B1^T, in ONE launch of the 256x256 ping-pong
+ * kernel.  A launch runs in waves of 256 workgroups (one tile per CU): the LLaMA-3-8B weight gradients of qkv (384 tiles) and
+ * down_proj (896 tiles) cost 2 + 4 wave times launched separately and 5 as a pair.  The host side pairs them at the end of
+ * DecoderLayerFn.backward (reference: the two nn.Linear weight gradients autograd computes in LlamaDecoderLayer's backward,
+ * call site metamorph_llama.py:349-359).
+ * flags per problem: MM355_GEMM_ACCUMULATE, MM355_GEMM_OUT_F32.  Requirements per problem: K % 128 == 0, lda/ldb % 8 == 0,
+ * operands below 2 GiB (else MM355_EUNSUPPORTED: launch them one by one with mm355_gemm_bf16). */
+int mm355_gemm_pair_bf16(const mm355_bf16* A0, int64_t lda0, const mm355_bf16* B0, int64_t ldb0, void* C0, int64_t ldc0,
+                         int64_t M0, int64_t N0, int64_t K0, uint32_t flags0,
+                         const mm355_bf16* A1, int64_t lda1, const mm355_bf16* B1, int64_t ldb1, void* C1, int64_t ldc1,
+                         int64_t M1, int64_t N1, int64_t K1, uint32_t flags1, void* stream);
+
 /* Weight-gradient form on the operands AS THEY LIE IN MEMORY (no transposed copies):
  *   C[M,N] (+)= At[K,M]^T . Bt[K,N]      e.g. dW[out,in] = dY[tokens,out]^T . X[tokens,in]
  * MFMA fragments are gathered from contraction-major LDS tiles with ds_read_b64_tr_b16.

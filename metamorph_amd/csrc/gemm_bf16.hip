@@ -579,15 +579,15 @@ template <int N> MM_DEV void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
+// in one grid)
 template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
+MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
     constexpr int A_BYTES = BM * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int total = a.ntm * a.ntn;
-    const int bid = blockIdx.x;
     const int q8 = total >> 3, r8 = total & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -788,29 +788,64 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_pp_tile<TA, TB>(a, blockIdx.x, smem);
+}
+
+// Two independent row-major problems in ONE grid: workgroups [0, n0) work on a0, the rest on a1.  A launch is executed in
+// waves of 256 workgroups (one 256x256 tile per CU), so two launches of 384 and 896 tiles cost 2 + 4 wave times while the pair
+// costs 5 (LLaMA-3-8B weight gradients of qkv and down_proj).  Each workgroup runs exactly one of the two inlined bodies.
+__global__ __launch_bounds__(512) void gemm_pp_pair_kernel(GemmArgs a0, GemmArgs a1, int n0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < n0) gemm_pp_tile<false, false>(a0, bid, smem);
+    else gemm_pp_tile<false, false>(a1, bid - n0, smem);
+}
+
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE, bool TNL>
 int launch_gemm(GemmArgs a, hipStream_t s);
 
 // TA / TB: operand given contraction-major ([K][M] / [K][N]); eligibility of the K extent and the 31-bit byte offsets is the
 // caller's business (pp_eligible)
-template <bool TA, bool TB>
-int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
-    constexpr int LDS = 2 * (256 + 256) * 128;              // 128 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+constexpr int PP_LDS = 2 * (256 + 256) * 128;               // 128 KiB
+
+// tile grid + raster knobs of one ping-pong problem; returns its tile count (<= 0: not launchable)
+int64_t pp_prepare(GemmArgs& a) {
     a.ntm = (a.M + 255) / 256;
     a.ntn = (a.N + 255) / 256;
     static const int gm_env = [] { const char* e = std::getenv("MM355_GEMM_GM"); return e ? atoi(e) : 0; }();   // tuning knob
     static const bool epi_bar = [] { const char* e = std::getenv("MM355_GEMM_EPI_BARRIER"); return e && e[0] == '1'; }();
     if (epi_bar) a.flags |= 0x80000000u;
     a.gm = gm_env > 0 ? gm_env : 4;                         // 4 x ntn raster groups: sweep on LLaMA-3-8B shapes (2/4/8/16/32)
-    const int64_t total = (int64_t)a.ntm * a.ntn;
+    return (int64_t)a.ntm * a.ntn;
+}
+
+template <bool TA, bool TB>
+int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
-    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), dim3((unsigned)total), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), dim3((unsigned)total), dim3(512), PP_LDS, s, a);
+    return mm_launch_status();
+}
+
+int launch_gemm_pp_pair(GemmArgs a0, GemmArgs a1, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_pp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess)
+            return MM355_ELAUNCH;
+        attr_done = true;
+    }
+    const int64_t n0 = pp_prepare(a0), n1 = pp_prepare(a1);
+    if (n0 <= 0 || n1 <= 0 || n0 + n1 > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_pp_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(512), PP_LDS, s, a0, a1, (int)n0);
     return mm_launch_status();
 }
 
@@ -958,6 +993,34 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 11: return launch_gemm_pp(a, s);
         default: return MM355_EUNSUPPORTED;
     }
+}
+
+namespace {
+// one problem of mm355_gemm_pair_bf16: plain NT form, epilogue limited to ACCUMULATE / OUT_F32
+int pair_problem(GemmArgs& a, const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, uint32_t flags) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
+    if ((K & 7) || (lda & 7) || (ldb & 7) || !mm_aligned16(A) || !mm_aligned16(B) || !mm_aligned16(C)) return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    if (flags & ~(MM355_GEMM_ACCUMULATE | MM355_GEMM_OUT_F32)) return MM355_EINVAL;
+    a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.res = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = 0; a.res_mod = 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
+    return pp_eligible(a, false, false) ? MM355_OK : MM355_EUNSUPPORTED;
+}
+}  // namespace
+
+extern "C" int mm355_gemm_pair_bf16(const mm355_bf16* A0, int64_t lda0, const mm355_bf16* B0, int64_t ldb0, void* C0, int64_t ldc0,
+                                    int64_t M0, int64_t N0, int64_t K0, uint32_t flags0,
+                                    const mm355_bf16* A1, int64_t lda1, const mm355_bf16* B1, int64_t ldb1, void* C1, int64_t ldc1,
+                                    int64_t M1, int64_t N1, int64_t K1, uint32_t flags1, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    GemmArgs a0, a1;
+    int rc = pair_problem(a0, A0, lda0, B0, ldb0, C0, ldc0, M0, N0, K0, flags0);
+    if (rc != MM355_OK) return rc;
+    rc = pair_problem(a1, A1, lda1, B1, ldb1, C1, ldc1, M1, N1, K1, flags1);
+    if (rc != MM355_OK) return rc;
+    return launch_gemm_pp_pair(a0, a1, (hipStream_t)stream);
 }
 
 extern "C" int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355_bf16* Bt, int64_t ldb, void* C, int64_t ldc, int64_t M,

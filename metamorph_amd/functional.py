@@ -20,6 +20,11 @@ BF16 = torch.bfloat16
 # transposed copies).  Measured on LLaMA-3-8B shapes: TN 1.04-1.10 PFLOP/s, NN 1.25-1.30 vs 1.45-1.5 for the row-major
 # kernel -- explicit transposes + NT are still faster end to end (1.22-1.25 PFLOP/s including the copies), so it is opt-in.
 _DW_TN = os.environ.get("MM355_DW_TN", "0") == "1"
+# MM355_DW_PAIR=0: launch every weight-gradient GEMM on its own.  Default: the down_proj and qkv weight gradients of a decoder
+# layer go out as ONE launch when that saves a wave of workgroups (LLaMA-3-8B: 896 + 384 tiles = 5 waves of 256 CUs instead
+# of 4 + 2).
+_DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
+_CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
 
 
 # ------------------------------------------------------------------------------------------------
@@ -177,6 +182,22 @@ def weight_grad_gemm(dy2d, x2d, out, accumulate, dyT=None, xT=None):
              accumulate=accumulate)
 
 
+def _dw_operands(dy2d, x2d, dyT=None, xT=None):
+    """Contraction-major operands (dy^T [N, Mp], x^T [K, Mp]) of a weight-gradient GEMM in NT form."""
+    return (transpose_padded(dy2d) if dyT is None else dyT, transpose_padded(x2d) if xT is None else xT)
+
+
+def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
+    """Two weight gradients [rows, cols] over `contraction` token rows: does one paired launch of the 256x256 kernel need fewer
+    waves of workgroups than two launches?  (Both must be problems the ping-pong kernel takes on its own: >= 200 tiles.)"""
+    t0 = -(-rows0 // 256) * -(-cols0 // 256)
+    t1 = -(-rows1 // 256) * -(-cols1 // 256)
+    kp = (contraction + 7) // 8 * 8
+    if min(t0, t1) < 200 or kp % 128:
+        return False
+    return -(-(t0 + t1) // _CUS) < -(-t0 // _CUS) + -(-t1 // _CUS)
+
+
 def input_grad_gemm(dy2d, w, out=None, residual=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual); the weight is read untransposed whenever the ping-pong kernel applies"""
     if _DW_TN and ops.gemm_nn_supported(dy2d, w):
@@ -249,10 +270,17 @@ class DecoderLayerFn(Function):
             dgu, act = ops.swiglu_bwd(gu, dact, m.I, want_act=mlp.down_proj.weight.requires_grad)
             actT = dguT = None
         del dact
+        qkv_params = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
+        held = None                      # down_proj's weight-gradient problem, kept back to share a launch with qkv's
         if mlp.down_proj.weight.requires_grad:
-            buf, acc = grad_target(mlp.down_proj.weight)
-            weight_grad_gemm(dy, act, buf, acc, xT=actT)
-            commit_grad(mlp.down_proj.weight, buf)
+            wd = mlp.down_proj.weight
+            buf, acc = grad_target(wd)
+            if (_DW_PAIR and not _DW_TN and all(p.requires_grad for p in qkv_params)
+                    and _pair_saves_a_wave(wd.shape[0], wd.shape[1], sum(p.shape[0] for p in qkv_params), h, dy.shape[0])):
+                held = _dw_operands(dy, act, xT=actT) + (buf, acc)
+            else:
+                weight_grad_gemm(dy, act, buf, acc, xT=actT)
+            commit_grad(wd, buf)
         del act, actT
         wgu = fused_weight(gu_params)
         dn2 = input_grad_gemm(dgu, wgu)                                         # [M, h]
@@ -283,13 +311,22 @@ class DecoderLayerFn(Function):
                      m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:])
         del do
         ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True)
-        qkv_params = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
         wqkv = fused_weight(qkv_params)
         dn1 = input_grad_gemm(dqkv, wqkv)
         if any(p.requires_grad for p in qkv_params):
             n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps)
             fb, acc, bufs = fused_grad_target(qkv_params)
-            weight_grad_gemm(dqkv, n1, fb, bool(acc))
+            if held is not None:
+                a1, b1 = _dw_operands(dqkv, n1)
+                if ops.gemm_pair_supported(held[0], held[1], a1, b1):
+                    ops.gemm_pair(held[0], held[1], held[2], held[3], a1, b1, fb, bool(acc))
+                else:                                                          # e.g. an operand beyond 2 GiB
+                    ops.gemm(held[0], held[1], out=held[2], accumulate=held[3])
+                    ops.gemm(a1, b1, out=fb, accumulate=bool(acc))
+                held = None
+                del a1, b1
+            else:
+                weight_grad_gemm(dqkv, n1, fb, bool(acc))
             commit_fused_grad(qkv_params, fb, acc, bufs)
             del n1
         del dqkv

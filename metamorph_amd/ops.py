@@ -84,6 +84,32 @@ def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, 
     return out
 
 
+def gemm_pair_supported(a0, b0, a1, b1):
+    """Both problems fit mm355_gemm_pair_bf16 (plain NT operands, whole pairs of K tiles, 31-bit operand offsets)."""
+    return (a0.shape[1] == b0.shape[1] and a1.shape[1] == b1.shape[1]
+            and gemm_pp_operands_ok(a0.shape[1], a0, b0) and gemm_pp_operands_ok(a1.shape[1], a1, b1))
+
+
+def gemm_pair(a0, b0, out0, acc0, a1, b1, out1, acc1):
+    """out0[M0,N0] (+)= a0 . b0^T and out1[M1,N1] (+)= a1 . b1^T in ONE launch (fills the partial last wave of workgroups that
+    each problem leaves on its own).  Raises Mm355Error(-2) when a problem is not eligible: check gemm_pair_supported first."""
+    _chk_dev(a0, b0, out0, a1, b1, out1)
+    probs = []
+    for a, b, out, acc in ((a0, b0, out0, acc0), (a1, b1, out1, acc1)):
+        assert a.dtype == BF16 and b.dtype == BF16
+        pa, M, K, lda = _rows2d(a)
+        pb, N, Kb, ldb = _rows2d(b)
+        assert K == Kb, (a.shape, b.shape)
+        po, Mo, No, ldc = _rows2d(out)
+        assert (Mo, No) == (M, N), (out.shape, M, N)
+        assert out.dtype in (BF16, torch.float32)
+        flags = (GEMM_ACCUMULATE if acc else 0) | (GEMM_OUT_F32 if out.dtype == torch.float32 else 0)
+        probs += [pa, lda, pb, ldb, po, ldc, M, N, K, flags]
+    _lib.check(_L().mm355_gemm_pair_bf16(*probs, _stream()),
+               f"mm355_gemm_pair_bf16 {tuple(a0.shape)}x{tuple(b0.shape)} + {tuple(a1.shape)}x{tuple(b1.shape)}")
+    return out0, out1
+
+
 def gemm_tn(at, bt, out, accumulate=False):
     """out[M,N] (+)= at[K,M]^T . bt[K,N]   (weight-gradient form, operands untransposed).  Raises Mm355Error(-2) when K % 64."""
     _chk_dev(at, bt, out)

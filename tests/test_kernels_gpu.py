@@ -82,6 +82,43 @@ def test_gemm_pingpong_race_screen(ops, shape):
     close(ops.gemm(a.to(DEV), b.to(DEV), variant=11), a.float() @ b.float().t(), 1e-2, 0.02 * math.sqrt(K), f"gemm v11 {shape}")
 
 
+@pytest.mark.parametrize("shapes", [((512, 768, 256), (300, 520, 384)), ((256, 256, 128), (256, 256, 128)),
+                                    ((1024, 2048, 1152), (2300, 264, 128)), ((8, 8, 128), (2048, 1280, 640))])
+def test_gemm_pair_equals_two_launches(ops, shapes):
+    """mm355_gemm_pair_bf16: two problems in one grid (workgroups [0, n0) / [n0, n0 + n1)) must give exactly what the same
+    kernel gives launched per problem -- ragged edges, different K, accumulate and fp32 outputs, and a repeat (race screen)."""
+    (M0, N0, K0), (M1, N1, K1) = shapes
+    for rep in range(3):
+        a0, b0 = rnd(M0, K0, seed=30 + rep).to(DEV), rnd(N0, K0, seed=40 + rep).to(DEV)
+        a1, b1 = rnd(M1, K1, seed=50 + rep).to(DEV), rnd(N1, K1, seed=60 + rep).to(DEV)
+        assert ops.gemm_pair_supported(a0, b0, a1, b1)
+        o0 = torch.empty(M0, N0, device=DEV, dtype=torch.bfloat16)
+        o1 = torch.empty(M1, N1, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_pair(a0, b0, o0, False, a1, b1, o1, False)
+        r0, r1 = ops.gemm(a0, b0, variant=11), ops.gemm(a1, b1, variant=11)
+        assert torch.equal(o0, r0) and torch.equal(o1, r1), f"pair differs from single launches at {shapes} round {rep}"
+    close(o0, a0.float() @ b0.float().t(), 1e-2, 0.02 * math.sqrt(K0), "pair problem 0 vs fp32")
+    close(o1, a1.float() @ b1.float().t(), 1e-2, 0.02 * math.sqrt(K1), "pair problem 1 vs fp32")
+    # accumulate into bf16 (problem 0) and fp32 (problem 1) targets
+    c0 = rnd(M0, N0, seed=70).to(DEV)
+    c1 = rnd(M1, N1, seed=71).to(DEV).float()
+    e0, e1 = c0.clone(), c1.clone()
+    ops.gemm_pair(a0, b0, c0, True, a1, b1, c1, True)
+    ops.gemm(a0, b0, out=e0, accumulate=True, variant=11)
+    ops.gemm(a1, b1, out=e1, accumulate=True, variant=11)
+    assert torch.equal(c0, e0) and torch.equal(c1, e1)
+
+
+def test_gemm_pair_rejects_ineligible(ops):
+    from metamorph_amd.lib import Mm355Error
+    a, b = rnd(256, 192, seed=1).to(DEV), rnd(256, 192, seed=2).to(DEV)          # K = 192: not whole pairs of K tiles
+    a1, b1 = rnd(256, 128, seed=3).to(DEV), rnd(256, 128, seed=4).to(DEV)
+    assert not ops.gemm_pair_supported(a, b, a1, b1)
+    o, o1 = torch.empty(256, 256, device=DEV, dtype=torch.bfloat16), torch.empty(256, 256, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(Mm355Error):
+        ops.gemm_pair(a, b, o, False, a1, b1, o1, False)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11])
 def test_gemm_epilogues(ops, variant):
     M, N, K = 320, 256, 128

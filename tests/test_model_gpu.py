@@ -202,6 +202,37 @@ def test_grad_accumulation_doubles():
             assert rel(p.grad, first[n]) < 1e-2, n
 
 
+def test_paired_weight_gradient_launch_matches_separate_launches(monkeypatch):
+    """DecoderLayerFn.backward sends the down_proj and qkv weight gradients out as one launch when that saves a wave of
+    workgroups (LLaMA-3-8B); force that path on a tiny model (128 token rows) and compare every gradient with the unpaired run."""
+    import metamorph_amd.functional as F
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=11, dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 127000, (2, 64), generator=gen).to(DEV)
+    args = dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+
+    def grads(paired):
+        calls = []
+        orig = F.ops.gemm_pair
+        monkeypatch.setattr(F, "_DW_PAIR", paired)
+        monkeypatch.setattr(F, "_pair_saves_a_wave", lambda r0, c0, r1, c1, k: ((k + 7) // 8 * 8) % 128 == 0)
+        monkeypatch.setattr(F.ops, "gemm_pair", lambda *a: (calls.append(1), orig(*a))[1])
+        model = hip_model(cfg, sd)
+        model.train()
+        for _ in range(2):                                   # second pass: the accumulate flavour of both problems
+            model(**args).loss.backward()
+        monkeypatch.setattr(F.ops, "gemm_pair", orig)
+        return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}, len(calls)
+
+    ref, n_ref = grads(False)
+    got, n_got = grads(True)
+    assert n_ref == 0 and n_got == 2 * cfg.num_hidden_layers, (n_ref, n_got)
+    assert got.keys() == ref.keys()
+    for n in ref:
+        assert rel(got[n], ref[n]) < 2e-3, (n, rel(got[n], ref[n]))
+
+
 def test_stage1_freeze_policy():
     """Only mm_projector (+ embed_tokens) trainable, as in the reference's stage 1 (train.py:1515-1519)."""
     g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
