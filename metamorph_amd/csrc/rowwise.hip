@@ -528,16 +528,32 @@ extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355
     });
 }
 
-// dw[c] += sum_g ws[g][c]: 64 columns per workgroup, four row lanes, fixed summation order (deterministic)
+// dw[c] += sum_g ws[g][c]: 32 columns per workgroup as eight float4 lanes x 32 row lanes (16-B loads, G / 32 of them per
+// thread), then a fixed-order sum over the row lanes (deterministic).  h % 4 == 0, ws rows 16-B aligned.
+constexpr int DWR_COLS = 32;
 __global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int G, int h, int ld) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (c < h)
-        for (int g = rl; g < G; g += 4) acc += ws[(int64_t)g * ld + c];
-    part[rl][threadIdx.x & 63] = acc;
+    __shared__ f32x4 part[32][8];
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * DWR_COLS + cq * 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < h) {
+        const float* p = ws + c;
+        int g = rl;
+        for (; g + 32 < G; g += 64) {                         // two independent chains
+            acc0 += *(const f32x4*)(p + (int64_t)g * ld);
+            acc1 += *(const f32x4*)(p + (int64_t)(g + 32) * ld);
+        }
+        if (g < G) acc0 += *(const f32x4*)(p + (int64_t)g * ld);
+    }
+    part[rl][cq] = acc0 + acc1;
     __syncthreads();
-    if (rl == 0 && c < h) dw[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (rl == 0 && c < h) {
+        f32x4 s = part[0][cq];
+#pragma unroll
+        for (int r = 1; r < 32; ++r) s += part[r][cq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[c + e] += s[e];
+    }
 }
 
 static int rmsnorm_bwd_rows_per_block(int64_t M, bool two_stage) {
@@ -565,7 +581,7 @@ extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, cons
         return mm_launch_status();
     });
     if (rc != MM355_OK || !two_stage) return rc;
-    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, (hipStream_t)stream, workspace, dw_f32,
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((unsigned)((h + DWR_COLS - 1) / DWR_COLS)), dim3(256), 0, (hipStream_t)stream, workspace, dw_f32,
                        (int)grid, (int)h, (int)h);
     return mm_launch_status();
 }
@@ -599,7 +615,7 @@ extern "C" int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, co
         return mm_launch_status();
     });
     if (rc != MM355_OK) return rc;
-    const dim3 rg((unsigned)((h + 63) / 64));
+    const dim3 rg((unsigned)((h + DWR_COLS - 1) / DWR_COLS));
     hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, dw_f32, (int)grid, (int)h, (int)(2 * h));
     hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace + h, db_f32, (int)grid, (int)h, (int)(2 * h));
     return mm_launch_status();
