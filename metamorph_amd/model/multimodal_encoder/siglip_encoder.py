@@ -260,6 +260,9 @@ class SiglipVisionTower(nn.Module):
             self.image_processor = AutoProcessor.from_pretrained("google/siglip-so400m-patch14-384").image_processor
             self.image_processor.crop_size = {"height": 384, "width": 384}
             state_dict = {k[len("vision_model."):]: v for k, v in model.state_dict().items() if k.startswith("vision_model.")}
+        if self.image_processor is None:                             # offline: the same checkpoint's preprocessor constants
+            from ...image_processing import SiglipImageProcessor
+            self.image_processor = SiglipImageProcessor(size=384)
         if state_dict is not None:
             own = self.vision_tower.state_dict()
             self.vision_tower.load_state_dict({k: v for k, v in state_dict.items() if k in own}, strict=False)

@@ -472,6 +472,37 @@ def gen_n2():
     print(f"  wrote n2_batch_producer.json ({len(cases)} preprocess cases, {len(coll)} collate cases)")
 
 
+def gen_images():
+    """process_images / expand2square of the reference (mm_utils.py:151-188) driving transformers' own SigLIP image processor
+    (the class the reference obtains from the hub, built here from the so400m-patch14-384 preprocessor constants at a small
+    output size so that the fixture stays small): uint8 inputs -> float pixel tensors, 'pad' and default aspect modes."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from transformers import SiglipImageProcessor as HFProc
+    from metamorph.mm_utils import process_images, expand2square
+    size = 24
+    hf = HFProc(do_resize=True, size={"height": size, "width": size}, resample=3, do_rescale=True, rescale_factor=1 / 255,
+                do_normalize=True, image_mean=[0.5] * 3, image_std=[0.5] * 3)
+    hf.crop_size = {"height": size, "width": size}
+    rs = np.random.RandomState(7)
+    raw = {"wide": (rs.rand(10, 31, 3) * 255).astype(np.uint8), "tall": (rs.rand(33, 12, 3) * 255).astype(np.uint8),
+           "square": (rs.rand(24, 24, 3) * 255).astype(np.uint8), "gray": (rs.rand(17, 9) * 255).astype(np.uint8)}
+    pil = {k: Image.fromarray(v) for k, v in raw.items()}
+    out = {}
+    for k, v in raw.items():
+        out["in_" + k] = v
+    names = sorted(raw)
+    rgb = [pil[k].convert("RGB") for k in names]
+    out["pad"] = process_images(rgb, hf, SimpleNamespace(image_aspect_ratio="pad")).numpy()
+    out["plain"] = process_images([pil[k] for k in names], hf, SimpleNamespace(image_aspect_ratio=None)).numpy()
+    bg = tuple(int(x * 255) for x in hf.image_mean)
+    for k in ("wide", "tall"):
+        out["square_of_" + k] = np.asarray(expand2square(pil[k], bg))
+    out["names"] = np.array(names)
+    out["size"] = np.int64(size)
+    save_npz("n2_process_images.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

@@ -322,3 +322,45 @@ def test_adapter_checkpoint_layout(tmp_path):
     m2 = build_model(llm, dict(num_hidden_layers=1, intermediate_size=144, image_size=28), num_image_tokens=4)
     m2.get_model().mm_projector.load_state_dict({k.split("mm_projector.")[1]: v for k, v in torch.load(p1).items()})
     assert all(torch.equal(a, b) for a, b in zip(m.get_model().mm_projector.state_dict().values(), m2.get_model().mm_projector.state_dict().values()))
+
+
+# ------------------------------------------------------------------ N2: image pre-processing (caller side, CPU)
+def test_process_images_matches_reference_golden():
+    """mm_utils.process_images / expand2square + the hub-free SigLIP image processor against outputs recorded from the
+    reference's own process_images driving transformers' SiglipImageProcessor (oracle/gen_golden.py images)."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from metamorph_amd.image_processing import SiglipImageProcessor
+    from metamorph_amd.mm_utils import expand2square, process_images
+    g = np.load(os.path.join(GOLDEN, "n2_process_images.npz"))
+    names = [str(n) for n in g["names"]]
+    proc = SiglipImageProcessor(size=int(g["size"]))
+    pil = {n: Image.fromarray(g["in_" + n]) for n in names}
+    bg = tuple(int(x * 255) for x in proc.image_mean)
+    for n in ("wide", "tall"):
+        assert np.array_equal(np.asarray(expand2square(pil[n], bg)), g["square_of_" + n]), n
+    sq = expand2square(pil["square"], bg)
+    assert sq.size == pil["square"].size and np.array_equal(np.asarray(sq), g["in_square"])
+    pad = process_images([pil[n].convert("RGB") for n in names], proc, SimpleNamespace(image_aspect_ratio="pad"))
+    plain = process_images([pil[n] for n in names], proc, SimpleNamespace(image_aspect_ratio=None))
+    assert pad.dtype == torch.float32 and tuple(pad.shape) == g["pad"].shape
+    assert np.abs(pad.numpy() - g["pad"]).max() <= 1e-6
+    assert np.abs(plain.numpy() - g["plain"]).max() <= 1e-6
+    # uint8 arrays (HWC / CHW) go the same way as PIL images
+    hwc = g["in_wide"]
+    a = proc.preprocess(hwc, return_tensors="pt")["pixel_values"]
+    b = proc.preprocess(np.ascontiguousarray(hwc.transpose(2, 0, 1)), return_tensors="pt")["pixel_values"]
+    c = proc.preprocess(pil["wide"], return_tensors="pt")["pixel_values"]
+    assert torch.equal(a, c) and torch.equal(b, c)
+
+
+def test_tower_carries_an_image_processor_without_the_hub():
+    from types import SimpleNamespace
+    from metamorph_amd.model.multimodal_encoder.siglip_encoder import SiglipVisionTower
+    args = SimpleNamespace(mm_vision_geometry=dict(hidden_size=32, intermediate_size=48, num_hidden_layers=1, num_attention_heads=2,
+                                                   image_size=28, patch_size=14, layer_norm_eps=1e-6))
+    tower = SiglipVisionTower("siglip/CLIP-ViT-SO400M-14-384", args, delay_load=True)
+    assert tower.image_processor is None
+    tower.load_model(random_init=True)
+    ip = tower.image_processor
+    assert ip.crop_size == {"height": 384, "width": 384} and tuple(ip.image_mean) == (0.5, 0.5, 0.5)
