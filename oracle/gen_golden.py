@@ -503,6 +503,30 @@ def gen_images():
     save_npz("n2_process_images.npz", **out)
 
 
+def gen_conv():
+    """Prompts of the reference's conversation templates (conversation.py) for a few message lists."""
+    import metamorph.conversation as C
+    dialogs = {
+        "open_turn": [(0, "What is in the picture?"), (1, None)],
+        "image_first": [(0, "<image>\nDescribe."), (1, "A cat."), (0, "And now?"), (1, None)],
+        "closed": [(0, "Hi"), (1, "Hello there.")],
+        "tuple_message": [(0, ("Look <image> here", "IMG", "Default")), (1, None)],
+        "empty": [],
+    }
+    cases = []
+    for tname in ("llama3", "chatml_direct", "mistral_direct"):
+        for dname, turns in dialogs.items():
+            conv = C.conv_templates[tname].copy()
+            for r, m in turns:
+                conv.append_message(conv.roles[r], m)
+            cases.append(dict(template=tname, dialog=dname, turns=[[r, list(m) if isinstance(m, tuple) else m] for r, m in turns],
+                              prompt=conv.get_prompt(), roles=list(conv.roles), sep=conv.sep, system=conv.system,
+                              version=conv.version))
+    with open(os.path.join(OUT, "n2_conversation.json"), "w") as f:
+        json.dump(dict(cases=cases, default=C.default_conversation.version), f, indent=0)
+    print(f"  wrote n2_conversation.json ({len(cases)} prompts)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

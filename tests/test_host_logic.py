@@ -364,3 +364,20 @@ def test_tower_carries_an_image_processor_without_the_hub():
     tower.load_model(random_init=True)
     ip = tower.image_processor
     assert ip.crop_size == {"height": 384, "width": 384} and tuple(ip.image_mean) == (0.5, 0.5, 0.5)
+
+
+def test_conversation_templates_match_reference_prompts():
+    """conv_templates[...].copy() / append_message / get_prompt against prompts recorded from the reference's templates."""
+    from metamorph_amd import conversation as C
+    g = json.load(open(os.path.join(GOLDEN, "n2_conversation.json")))
+    assert C.default_conversation.version == g["default"]
+    for case in g["cases"]:
+        conv = C.conv_templates[case["template"]].copy()
+        assert list(conv.roles) == case["roles"] and conv.sep == case["sep"] and conv.system == case["system"]
+        assert conv.version == case["version"]
+        for r, m in case["turns"]:
+            conv.append_message(conv.roles[r], tuple(m) if isinstance(m, list) else m)
+        assert conv.get_prompt() == case["prompt"], (case["template"], case["dialog"])
+        assert C.conv_templates[case["template"]].messages == []          # copy() does not leak messages into the template
+    with pytest.raises(ValueError):
+        C.Conversation(system="", roles=("a", "b"), messages=[], sep_style=C.SeparatorStyle.TWO).get_prompt()
