@@ -163,7 +163,10 @@ class Zero2AdamW(torch.optim.Optimizer):
                       my_grad=self.flat_grad[lo:lo + m], my_param=self.flat_param[lo:lo + m])
             so += m
         self.segs = segs
-        self.seg_of_key = {sg["key"]: i for i, sg in enumerate(segs) if sg["key"] is not None}
+        self.seg_of_key = {}               # key -> segment indices (more than one when parameter groups cut through a key)
+        for i, sg in enumerate(segs):
+            if sg["key"] is not None:
+                self.seg_of_key.setdefault(sg["key"], []).append(i)
         self.master = torch.cat([sg["my_param"] for sg in segs]).float()
         self.exp_avg = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(self.shard, device=dev, dtype=torch.float32)
@@ -205,9 +208,9 @@ class Zero2AdamW(torch.optim.Optimizer):
     def notify_segment_ready(self, key):
         if not self._armed:
             return
-        i = self.seg_of_key.get(key)
-        if i is not None and i not in self._pending:
-            self._launch_reduce(i, async_op=True)
+        for i in self.seg_of_key.get(key, ()):
+            if i not in self._pending:
+                self._launch_reduce(i, async_op=True)
 
     def enable_overlap(self):
         """Route DecoderLayerFn's "layer gradients are final" announcements to this optimizer."""
@@ -301,8 +304,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         if key is None:
             todo = [i for i, sg in enumerate(self.segs) if sg["key"] is None]
         else:
-            i = self.seg_of_key.get(key)
-            todo = [] if i is None else [i]
+            todo = self.seg_of_key.get(key, ())
         cur = torch.cuda.current_stream()
         for i in todo:
             if i not in self._waited and i in self._ready:

@@ -284,3 +284,57 @@ def test_param_groups_with_their_own_learning_rate():
             R.adamw_step(r, g, m[i], v[i], step, lr, 0.9, 0.95, 1e-8, wd, grad_scale=coef)
     for p, r in zip(params, ref):
         torch.testing.assert_close(p.data, r, rtol=1e-5, atol=1e-6)
+
+
+def _group_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metamorph_amd.zero2 import Zero2AdamW
+        params = _make_params(torch.float32)
+        for p, key in zip(params, _SEGMENTS):
+            if key is not None:
+                p._mm_segment = key
+        # the group boundary cuts THROUGH "layer 0" (tensors 0,1 | 2): that key then owns two segments
+        groups = [dict(params=params[:2], lr=1e-2, weight_decay=0.1), dict(params=params[2:], lr=1e-3, weight_decay=0.0)]
+        opt = Zero2AdamW(groups, betas=(0.9, 0.95), shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip,
+                         overlap=True)
+        assert [sg["group"] for sg in opt.segs] == [0, 1, 1, 1] and opt.seg_of_key[("layer", 0)] == [0, 1]
+        for s in (1, 2):
+            opt.arm_overlap()
+            grads = _grads_for(rank, s, params)
+            for idx in (5, 4, 3, 2, 1, 0):
+                params[idx]._mm_grad_buf.copy_(grads[idx])
+                params[idx].grad = params[idx]._mm_grad_buf
+                if idx == 3:
+                    opt.notify_segment_ready(("layer", 1))
+                if idx == 0:
+                    opt.notify_segment_ready(("layer", 0))
+                    assert {0, 1} <= set(opt._pending)            # both halves of the cut layer went out
+            opt.step()
+            opt.zero_grad()
+        torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, f"grp_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_param_groups_on_two_ranks(tmp_path):
+    """Two ranks, two parameter groups whose boundary cuts through a tagged layer: every rank ends with the same parameters,
+    equal to per-group oracle AdamW steps on the MEAN gradient under one global clipping coefficient."""
+    world = 2
+    mp.spawn(_group_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"grp_rank{r}.pt")) for r in range(world)]
+    assert torch.equal(got[0], got[1])
+    params = _make_params(torch.float32)
+    ref = [p.detach().clone() for p in params]
+    m = [torch.zeros_like(p) for p in ref]
+    v = [torch.zeros_like(p) for p in ref]
+    for step in (1, 2):
+        per_rank = [_grads_for(r, step, params) for r in range(world)]
+        mean = [sum(gs) / world for gs in zip(*per_rank)]
+        norm = float(torch.sqrt(sum((g.float() ** 2).sum() for g in mean)))
+        coef = min(1.0, 1.0 / (norm + 1e-6))
+        for i, (r, g) in enumerate(zip(ref, mean)):
+            lr, wd = (1e-2, 0.1) if i < 2 else (1e-3, 0.0)
+            R.adamw_step(r, g, m[i], v[i], step, lr, 0.9, 0.95, 1e-8, wd, grad_scale=coef)
+    torch.testing.assert_close(got[0], torch.cat([r.reshape(-1) for r in ref]), rtol=1e-5, atol=1e-6)
