@@ -71,7 +71,7 @@ int mm355_gemm_num_variants(void);
  * DecoderLayerFn.backward (reference: the two nn.Linear weight gradients autograd computes in LlamaDecoderLayer's backward,
  * call site metamorph_llama.py:349-359).
  * flags per problem: MM355_GEMM_ACCUMULATE, MM355_GEMM_OUT_F32.  Requirements per problem: K % 128 == 0, lda/ldb % 8 == 0,
- * operands below 2 GiB (else MM355_EUNSUPPORTED: launch them one by one with mm355_gemm_bf16). */
+ * 256 rows x ld x 2 B below 2 GiB (else MM355_EUNSUPPORTED: launch them one by one with mm355_gemm_bf16). */
 int mm355_gemm_pair_bf16(const mm355_bf16* A0, int64_t lda0, const mm355_bf16* B0, int64_t ldb0, void* C0, int64_t ldc0,
                          int64_t M0, int64_t N0, int64_t K0, uint32_t flags0,
                          const mm355_bf16* A1, int64_t lda1, const mm355_bf16* B1, int64_t ldb1, void* C1, int64_t ldc1,

@@ -616,7 +616,7 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
 
     // ---- LDS-DMA: quarter kinds in need order 0: A rows block 0, 1: B cols block 0, 2: B cols block 1, 3: A rows block 1;
     //      16 pieces of 8 rows each, this wave moves pieces wave and wave + 8 of every quarter
-    uint32_t src[4][2];                                      // per-lane source byte offset from A / B (host: operands < 2 GiB)
+    uint32_t src[4][2];                                      // per-lane source byte offset from the buffer base
     int dst[4][2];                                           // tile-relative LDS byte offset of the piece (wave-uniform)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -628,7 +628,7 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             if (isA && !TA) {                                // [256 m][64 k] image, piece = 8 rows x 128 B
                 const int rin = lane >> 3, c = (lane & 7) ^ rin;
                 const int row = h * 128 + blk * 64 + wave_s * 8;
-                src[kd][h] = (uint32_t)((int64_t)min(m0 + row + rin, M - 1) * a.lda * 2 + c * 16);
+                src[kd][h] = (uint32_t)((int64_t)(min(m0 + row + rin, M - 1) - m0) * a.lda * 2 + c * 16);   // from row m0
                 dst[kd][h] = row * 128;
             } else if (isA && TA) {                          // four [64 k][64 m] images (128-B rows), piece = 8 k rows
                 const int krow = wave_s * 8 + (lane >> 3);
@@ -638,7 +638,7 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             } else if (!TB) {                                // [256 n][64 k] image
                 const int rin = lane >> 3, c = (lane & 7) ^ rin;
                 const int row = (q >> 2) * 64 + blk * 32 + (q & 3) * 8;
-                src[kd][h] = (uint32_t)((int64_t)min(n0 + row + rin, N - 1) * a.ldb * 2 + c * 16);
+                src[kd][h] = (uint32_t)((int64_t)(min(n0 + row + rin, N - 1) - n0) * a.ldb * 2 + c * 16);   // from row n0
                 dst[kd][h] = A_BYTES + row * 128;
             } else {                                         // eight [64 k][32 n] images (64-B rows), piece = 16 k rows
                 const int krow = (q & 3) * 16 + (lane >> 2);
@@ -648,9 +648,14 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             }
         }
     }
-    // buffer-addressed DMA (resource in SGPRs + 32-bit lane offset + scalar K offset): no 64-bit per-lane address arithmetic
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
+    // buffer-addressed DMA (resource in SGPRs + 32-bit lane offset + scalar K offset): no 64-bit per-lane address arithmetic.
+    // A row-major operand is based at the tile's first row (one scalar 64-bit multiply-add per workgroup), so the 31-bit
+    // offsets only span 256 rows + the K extent and the operand itself may be of any size; contraction-major operands are
+    // based at the matrix (their offsets run over K rows: pp_eligible keeps those below 2 GiB).
+    const uint16_t* baseA = TA ? a.A : a.A + (int64_t)m0 * a.lda;
+    const uint16_t* baseB = TB ? a.B : a.B + (int64_t)n0 * a.ldb;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, 0x7fffffff, 0x00020000);
     const int kstepA = TA ? (int)(a.lda * 128) : 128, kstepB = TB ? (int)(a.ldb * 128) : 128;   // bytes per K tile
     auto issue = [&](int kd, int tile) {                     // quarter kd of K tile `tile`
         unsigned char* sb = smem + (tile & 1) * BUF;
@@ -849,11 +854,12 @@ int launch_gemm_pp_pair(GemmArgs a0, GemmArgs a1, hipStream_t s) {
     return mm_launch_status();
 }
 
-// whole pairs of K tiles, and every source byte offset (row * ld + K extent) below 2 GiB
+// whole pairs of K tiles, and every source byte offset below 2 GiB: (K rows * ld + M) for a contraction-major operand, based
+// at the matrix; (256 rows * ld + K) for a row-major one, based at the tile's first row
 bool pp_eligible(const GemmArgs& a, bool ta, bool tb) {
     if (a.K < 128 || (a.K & 127)) return false;
-    const int64_t ea = ta ? ((int64_t)a.K * a.lda + a.M) * 2 : ((int64_t)a.M * a.lda + a.K) * 2;
-    const int64_t eb = tb ? ((int64_t)a.K * a.ldb + a.N) * 2 : ((int64_t)a.N * a.ldb + a.K) * 2;
+    const int64_t ea = ta ? ((int64_t)a.K * a.lda + a.M) * 2 : (256 * a.lda + a.K) * 2;
+    const int64_t eb = tb ? ((int64_t)a.K * a.ldb + a.N) * 2 : (256 * a.ldb + a.K) * 2;
     if (ta && (a.M < 8 || (a.M & 7))) return false;
     if (tb && (a.N < 8 || (a.N & 7))) return false;
     return ea < 0x7fffffffLL && eb < 0x7fffffffLL;

@@ -87,7 +87,7 @@ def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, 
 def gemm_pair_supported(a0, b0, a1, b1):
     """Both problems fit mm355_gemm_pair_bf16 (plain NT operands, whole pairs of K tiles, 31-bit operand offsets)."""
     return (a0.shape[1] == b0.shape[1] and a1.shape[1] == b1.shape[1]
-            and gemm_pp_operands_ok(a0.shape[1], a0, b0) and gemm_pp_operands_ok(a1.shape[1], a1, b1))
+            and gemm_pp_operands_ok(a0.shape[1], a0, b0, row_major=True) and gemm_pp_operands_ok(a1.shape[1], a1, b1, row_major=True))
 
 
 def gemm_pair(a0, b0, out0, acc0, a1, b1, out1, acc1):
@@ -127,9 +127,11 @@ def gemm_tn_supported(at, bt):
     return at.shape[0] % 64 == 0 and at.shape[1] % 8 == 0 and bt.shape[1] % 8 == 0 and at.shape[1] >= 8 and bt.shape[1] >= 8
 
 
-def gemm_pp_operands_ok(K, *mats):
-    """The ping-pong 256x256 kernel wants whole pairs of 64-wide K tiles and 31-bit byte offsets into every operand."""
-    return K >= 128 and K % 128 == 0 and all(m.shape[0] * m.stride(0) * 2 < 2 ** 31 - 2 ** 20 for m in mats)
+def gemm_pp_operands_ok(K, *mats, row_major=False):
+    """The ping-pong 256x256 kernel wants whole pairs of 64-wide K tiles and 31-bit byte offsets: over the whole matrix for
+    contraction-major operands, over one 256-row panel for row-major ones (`row_major=True`)."""
+    span = (lambda m: 256 * m.stride(0) * 2) if row_major else (lambda m: m.shape[0] * m.stride(0) * 2)
+    return K >= 128 and K % 128 == 0 and all(span(m) < 2 ** 31 - 2 ** 20 for m in mats)
 
 
 def gemm_nn(a, bt, out=None, residual=None, accumulate=False):

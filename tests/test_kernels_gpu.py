@@ -109,6 +109,25 @@ def test_gemm_pair_equals_two_launches(ops, shapes):
     assert torch.equal(c0, e0) and torch.equal(c1, e1)
 
 
+def test_gemm_pingpong_operand_beyond_2gib(ops):
+    """Row-major operands are addressed from the tile's first row, so a 2 GiB+ operand stays on the ping-pong kernel: row
+    windows at the start, in the middle and past the 2 GiB mark must equal the plain kernel run on just those rows -- as the
+    A operand (tall activations) and as the B operand."""
+    M, N, K = (1 << 20) + 300, 256, 1024                     # A: 2.0006 GiB
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    b = rnd(N, K, seed=5).to(DEV)
+    assert a.numel() * 2 > 2 ** 31
+    out = ops.gemm(a, b, variant=11)
+    for lo in (0, M // 2 - 128, M - 812):
+        ref = ops.gemm(a[lo:lo + 812], b, variant=1)
+        assert torch.equal(out[lo:lo + 812], ref), f"rows {lo}..{lo + 812}"
+    del out
+    out_t = ops.gemm(b, a, variant=11)                       # [256, M]: the big matrix as B
+    for lo in (0, M - 812):
+        ref = ops.gemm(b, a[lo:lo + 812], variant=1)
+        assert torch.equal(out_t[:, lo:lo + 812], ref), f"cols {lo}..{lo + 812}"
+
+
 def test_gemm_pair_rejects_ineligible(ops):
     from metamorph_amd.lib import Mm355Error
     a, b = rnd(256, 192, seed=1).to(DEV), rnd(256, 192, seed=2).to(DEV)          # K = 192: not whole pairs of K tiles
