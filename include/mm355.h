@@ -211,6 +211,10 @@ int mm355_scale_bf16(mm355_bf16* x, int64_t n, const float* s_dev, float s_host,
 int mm355_axpy_bf16(mm355_bf16* y, const mm355_bf16* x, int64_t n, const float* s_dev, float s_host,
                     int accumulate, void* stream);
 int mm355_axpy_f32_to_bf16(mm355_bf16* y, const float* x, int64_t n, float s_host, int accumulate, void* stream);
+/* the same with a DEVICE scalar on top (s_dev nullable): y (+)= s_dev[0] * s_host * x -- fp32-accumulated lm_head weight gradient
+ * scaled by the upstream loss gradient without a host sync (functional.LinearCrossEntropyFn) */
+int mm355_axpy_f32_to_bf16_dev(mm355_bf16* y, const float* x, int64_t n, const float* s_dev, float s_host, int accumulate,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cross entropy over a chunk of rows of bf16 logits (metamorph_llama.py:398-413; K13).
@@ -264,6 +268,26 @@ int mm355_bilinear_l2norm_bwd(const mm355_bf16* in, const mm355_bf16* d_out, flo
  * ------------------------------------------------------------------------------------------------ */
 int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
                       float* cos_sum, mm355_bf16* dpred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The other two image-AR head variants (metamorph_llama.py:437-447 soft-CE, :459 + :211-219 mean-abs) and the
+ * temperature softmax they pair with on the tower side (siglip_encoder.py:210-211) and in image-mode decoding
+ * (metamorph_llama.py:372-373).  One wave per row, C % 8 == 0.
+ *   mean_abs:  abs_sum[0] += sum |target - pred| (bf16 difference like the reference stack); caller divides by R*C.
+ *              dpred (nullable) = d mean|t - p| / d pred.     (constructor default: normalize_vision=False, apply_softmax=False)
+ *   soft_ce:   u = normalize ? F.normalize(pred_raw) : pred_raw;  q = softmax(u / temperature) (bf16);
+ *              loss_sum[0] += -sum_r sum_j target[r][j] log(q[r][j] + 1e-10); caller divides by R.
+ *              dpred (nullable) = d (loss_sum / R) / d pred_raw.
+ *   softmax_rows:     y = softmax(x / temperature) per row (fp32 inside, bf16 out).
+ *   softmax_rows_bwd: dx = y * (dy - sum_j dy_j y_j) / temperature.
+ * ------------------------------------------------------------------------------------------------ */
+int mm355_mean_abs_loss(const mm355_bf16* pred, const mm355_bf16* target, int64_t R, int64_t C, float* abs_sum,
+                        mm355_bf16* dpred, void* stream);
+int mm355_soft_ce_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
+                       float temperature, float* loss_sum, mm355_bf16* dpred, void* stream);
+int mm355_softmax_rows(const mm355_bf16* x, mm355_bf16* y, int64_t R, int64_t C, float temperature, void* stream);
+int mm355_softmax_rows_bwd(const mm355_bf16* y, const mm355_bf16* dy, mm355_bf16* dx, int64_t R, int64_t C,
+                           float temperature, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ZeRO-2 shard update (replaces DeepSpeed zero2.json + HF adamw_torch, train.py:82): AdamW on the

@@ -392,6 +392,11 @@ extern "C" int mm355_axpy_f32_to_bf16(mm355_bf16* y, const float* x, int64_t n, 
     if (!x || !y || n <= 0) return MM355_EINVAL;
     LAUNCH(axpy_kernel<float>, grid_for(n), y, x, n, (const float*)nullptr, s_host, accumulate);
 }
+extern "C" int mm355_axpy_f32_to_bf16_dev(mm355_bf16* y, const float* x, int64_t n, const float* s_dev, float s_host, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!x || !y || n <= 0) return MM355_EINVAL;
+    LAUNCH(axpy_kernel<float>, grid_for(n), y, x, n, s_dev, s_host, accumulate);
+}
 extern "C" int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int64_t ld_out, int64_t rows, int64_t cols, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || rows <= 0 || cols <= 0 || (cols & 7) || (ld_in & 3) || (ld_out & 7)) return MM355_EINVAL;

@@ -13,7 +13,7 @@ TINYLLAMA_1B = dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=
 
 
 def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tokens=256, mm_projector_type="mlp2x_gelu",
-                vision_head="mlp", normalize_vision=True, use_vision_ar=True, vision_coef=1.0, max_length=4096,
+                vision_head="mlp", normalize_vision=True, apply_softmax=False, use_vision_ar=True, vision_coef=1.0, max_length=4096,
                 padding_side="right", image_start_id=None, state_dict=None, device=None, dtype=torch.bfloat16,
                 init_on_device=False):
     llm = dict(llm)
@@ -25,6 +25,7 @@ def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tok
     cfg.image_token_reduction = "interpolation"
     cfg.freeze_vision = True
     cfg.normalize_vision = normalize_vision
+    cfg.apply_softmax = apply_softmax
     cfg.mm_vision_select_layer = -1
     cfg.mm_vision_geometry = vision_geometry
     cfg.tokenizer_model_max_length = max_length
@@ -35,7 +36,7 @@ def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tok
     ctx = torch.device(device) if (init_on_device and device is not None) else torch.device("cpu")
     with ctx:
         model = MetaMorphLlamaForCausalLM(cfg, use_vision_ar=use_vision_ar, vision_head=vision_head, vision_coef=vision_coef,
-                                          normalize_vision=normalize_vision, vision_delay_load=True)
+                                          normalize_vision=normalize_vision, apply_softmax=apply_softmax, vision_delay_load=True)
         model.get_model().vision_tower.load_model(random_init=True)
     if state_dict is not None:
         missing, unexpected = model.load_state_dict(state_dict, strict=False)

@@ -71,6 +71,19 @@ def fused_weight(params):
     return buf
 
 
+# Bumped by every optimizer step that rewrites parameters through raw pointers (Zero2AdamW / Zero3AdamW: mm355_adamw_shard and
+# in-place collectives do not touch torch's per-tensor version counters); derived operand caches key on it.
+_PARAM_GENERATION = [0]
+
+
+def bump_param_generation():
+    _PARAM_GENERATION[0] += 1
+
+
+def param_generation():
+    return _PARAM_GENERATION[0]
+
+
 _LAYER_GRAD_HOOK = None
 
 
@@ -212,10 +225,13 @@ def input_grad_gemm(dy2d, w, out=None, residual=None):
 class LayerMeta:
     """Geometry shared by all decoder layers of one forward pass."""
 
-    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens):
+    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens, recompute=False):
         self.B, self.L, self.Hq, self.Hkv, self.d, self.I, self.eps = B, L, Hq, Hkv, d, I, eps
         self.cos, self.sin, self.seqlens = cos, sin, seqlens
         self.scale = d ** -0.5
+        # gradient checkpointing (reference train.py:1443-1449 + `--gradient_checkpointing True` in every launch script): keep only
+        # the layer input, re-run the layer's forward kernels at the start of its backward
+        self.recompute = recompute
 
 
 def decoder_layer_forward(x, layer, m: LayerMeta):
@@ -244,13 +260,21 @@ class DecoderLayerFn(Function):
     def forward(ctx, x, layer, meta, *weights):
         y, saved = decoder_layer_forward(x, layer, meta)
         ctx.layer, ctx.meta = layer, meta
-        ctx.save_for_backward(x, *saved)
+        if meta.recompute:
+            del saved
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, *saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, qkv, o, lse, x2, gu = ctx.saved_tensors
         layer, m = ctx.layer, ctx.meta
+        if len(ctx.saved_tensors) == 1:                                        # checkpointed: same kernels, same inputs => same bits
+            (x,) = ctx.saved_tensors
+            _, (qkv, o, lse, x2, gu) = decoder_layer_forward(x, layer, m)
+        else:
+            x, qkv, o, lse, x2, gu = ctx.saved_tensors
         att, mlp = layer.self_attn, layer.mlp
         dy = dy.contiguous()
         h = x.shape[1]
@@ -428,9 +452,10 @@ def _linear_grads(mod, dy2d, x2d):
 # ------------------------------------------------------------------------------------------------
 
 class SiglipGeo:
-    def __init__(self, N, P, heads, d, eps):
+    def __init__(self, N, P, heads, d, eps, recompute=False):
         self.N, self.P, self.heads, self.d, self.eps = N, P, heads, d, eps
         self.scale = d ** -0.5
+        self.recompute = recompute
 
 
 def _siglip_qkv(h1, att, hv):
@@ -440,30 +465,43 @@ def _siglip_qkv(h1, att, hv):
     return qkv
 
 
+def siglip_layer_forward(x, layer, g):
+    att, mlp = layer.self_attn, layer.mlp
+    hv = x.shape[1]
+    ln1, ln2 = layer.layer_norm1, layer.layer_norm2
+    h1 = ops.layernorm_fwd(x, ln1.weight.data, ln1.bias.data, g.eps)
+    qkv = _siglip_qkv(h1, att, hv)
+    del h1
+    o, lse = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], qkv[:, 2 * hv:], g.N, g.P, g.heads, g.heads, g.d, g.scale, False, None)
+    x2 = ops.gemm(o, att.out_proj.weight.data, bias=att.out_proj.bias.data, residual=x)
+    h2 = ops.layernorm_fwd(x2, ln2.weight.data, ln2.bias.data, g.eps)
+    f_pre = ops.gemm(h2, mlp.fc1.weight.data, bias=mlp.fc1.bias.data)
+    del h2
+    f = ops.gelu_fwd(f_pre, ops.GELU_TANH)
+    y = ops.gemm(f, mlp.fc2.weight.data, bias=mlp.fc2.bias.data, residual=x2)
+    return y, (qkv, o, lse, x2, f_pre)
+
+
 class SiglipLayerFn(Function):
     @staticmethod
     def forward(ctx, x, layer, g, *params):
-        att, mlp = layer.self_attn, layer.mlp
-        hv = x.shape[1]
-        ln1, ln2 = layer.layer_norm1, layer.layer_norm2
-        h1 = ops.layernorm_fwd(x, ln1.weight.data, ln1.bias.data, g.eps)
-        qkv = _siglip_qkv(h1, att, hv)
-        del h1
-        o, lse = ops.attn_fwd(qkv[:, :hv], qkv[:, hv:2 * hv], qkv[:, 2 * hv:], g.N, g.P, g.heads, g.heads, g.d, g.scale, False, None)
-        x2 = ops.gemm(o, att.out_proj.weight.data, bias=att.out_proj.bias.data, residual=x)
-        h2 = ops.layernorm_fwd(x2, ln2.weight.data, ln2.bias.data, g.eps)
-        f_pre = ops.gemm(h2, mlp.fc1.weight.data, bias=mlp.fc1.bias.data)
-        del h2
-        f = ops.gelu_fwd(f_pre, ops.GELU_TANH)
-        y = ops.gemm(f, mlp.fc2.weight.data, bias=mlp.fc2.bias.data, residual=x2)
+        y, saved = siglip_layer_forward(x, layer, g)
         ctx.layer, ctx.g = layer, g
-        ctx.save_for_backward(x, qkv, o, lse, x2, f_pre)
+        if g.recompute:
+            del saved
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, *saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, qkv, o, lse, x2, f_pre = ctx.saved_tensors
         layer, g = ctx.layer, ctx.g
+        if len(ctx.saved_tensors) == 1:
+            (x,) = ctx.saved_tensors
+            _, (qkv, o, lse, x2, f_pre) = siglip_layer_forward(x, layer, g)
+        else:
+            x, qkv, o, lse, x2, f_pre = ctx.saved_tensors
         att, mlp = layer.self_attn, layer.mlp
         ln1, ln2 = layer.layer_norm1, layer.layer_norm2
         hv = x.shape[1]
@@ -725,8 +763,62 @@ class CosineLossFn(Function):
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        ops.scale_(dpred, g.reshape(1).float().contiguous(), 1.0)
-        return dpred, None, None
+        return _scaled_copy(dpred, g), None, None
+
+
+def _scaled_copy(saved, g):
+    """saved * g into a FRESH tensor (a second backward through the same graph must not see a pre-scaled gradient)."""
+    out = torch.empty_like(saved)
+    ops.axpy_(out, saved, g.reshape(1).float().contiguous(), 1.0, False)
+    return out
+
+
+class MeanAbsLossFn(Function):
+    """mean |target - pred|: the reference's `mse_loss_fn` (metamorph_llama.py:211-219, reached at :459 when neither
+    normalize_vision nor apply_softmax is set -- the constructor default)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        abs_sum, dpred = ops.mean_abs_loss(pred, target, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return (abs_sum * (1.0 / pred.numel())).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return _scaled_copy(dpred, g), None
+
+
+class SoftCELossFn(Function):
+    """-(target * log(softmax(u / 0.07) + 1e-10)).sum(1).mean(), u = F.normalize(pred) when normalize_vision
+    (metamorph_llama.py:434-447)."""
+
+    @staticmethod
+    def forward(ctx, pred_raw, target, normalize):
+        loss_sum, dpred = ops.soft_ce_loss(pred_raw, target, normalize, 0.07, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return (loss_sum * (1.0 / pred_raw.shape[0])).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return _scaled_copy(dpred, g), None, None
+
+
+class SoftmaxRowsFn(Function):
+    """softmax(x / 0.07) over the feature dimension (tower side, siglip_encoder.py:210-211)."""
+
+    @staticmethod
+    def forward(ctx, x2d, temperature):
+        y = ops.softmax_rows(x2d, temperature)
+        ctx.save_for_backward(y)
+        ctx.temperature = temperature
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_rows_bwd(y, dy.contiguous(), ctx.temperature), None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -762,7 +854,7 @@ class SpliceFn(Function):
 # lm_head + shifted cross entropy without materialising [M, V] logits (K13)
 # ------------------------------------------------------------------------------------------------
 
-CE_CHUNK = 4096
+CE_CHUNK = 8192
 
 
 class LinearCrossEntropyFn(Function):
@@ -790,7 +882,8 @@ class LinearCrossEntropyFn(Function):
         if need_dh:
             wt = torch.zeros((h, Vp), device=dev, dtype=BF16) if Vp != V else torch.empty((h, Vp), device=dev, dtype=BF16)
             ops.transpose(weight, out=wt[:, :V])
-        dw = torch.empty((V, h), device=dev, dtype=BF16) if need_dw else None
+        # chunks accumulate in fp32 (a bf16 running sum would lose the small chunks once n_valid >> CE_CHUNK); rounded once in backward
+        dw = torch.empty((V, h), device=dev, dtype=BF16 if n_valid <= CE_CHUNK else torch.float32) if need_dw else None
         inv = 1.0 / max(n_valid, 1)
         first = True
         for r0 in range(0, n_valid, CE_CHUNK):

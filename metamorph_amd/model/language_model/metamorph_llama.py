@@ -91,6 +91,9 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         self.norm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._init_vision(config, vision_delay_load=vision_delay_load)
         self._rope = None
+        # set by PreTrainedModel.gradient_checkpointing_enable() (HF looks for this attribute on the sub-modules): per-layer
+        # recompute in DecoderLayerFn / SiglipLayerFn instead of torch.utils.checkpoint
+        self.gradient_checkpointing = False
 
     def rope_tables(self, L, device):
         d = self.config.hidden_size // self.config.num_attention_heads
@@ -105,7 +108,8 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
 class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
     config_class = MetaMorphConfig
     base_model_prefix = "model"
-    supports_gradient_checkpointing = False     # activations are already kept at kernel-fusion granularity
+    supports_gradient_checkpointing = True      # honoured as per-layer recompute (functional.LayerMeta.recompute)
+    accepts_loss_kwargs = False                 # like the reference's forward(): no `num_items_in_batch` normalisation inside the model
     _no_split_modules = ["_DecoderLayer"]
     _keys_to_ignore_on_load_unexpected = [r"model\.vision_tower\.vision_tower\.head\..*", r".*rotary_emb\.inv_freq"]
 
@@ -117,7 +121,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         self.vocab_size = config.vocab_size
         self.lm_head = HipLinear(config.hidden_size, config.vocab_size, bias=False)
         self.normalize_vision = bool(normalize_vision) or bool(getattr(config, "normalize_vision", False))
-        self.apply_softmax = apply_softmax
+        self.apply_softmax = bool(apply_softmax)
         vision_head = getattr(config, "vision_head_type", vision_head)
         hv = getattr(config, "mm_hidden_size", 1152)          # the reference hard-codes 1152 (metamorph_llama.py:255)
         h = config.hidden_size
@@ -246,7 +250,8 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
         d = h // Hq
         cos, sin = self.model.rope_tables(L, dev)
-        meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"])
+        meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],
+                           recompute=bool(self.model.gradient_checkpointing) and self.training)
 
         x = inputs_embeds.reshape(B * L, h)
         if not x.is_contiguous():
@@ -264,7 +269,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                 if self.normalize_vision:
                     pred_z = ops.bilinear_l2norm(pred_z.view(B, 1, -1).contiguous(), 1, 1, True).view(B, -1)
                 if self.apply_softmax:
-                    raise NotImplementedError("apply_softmax decode path has no HIP kernel")
+                    pred_z = ops.softmax_rows(pred_z.contiguous(), 0.07)
                 prediction = self.model.mm_projector(pred_z)
                 hidden_states = hidden_states.clone()
                 hidden_states[:, -1, :] = prediction
@@ -286,21 +291,26 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                 if image_features is not None:
                     R = int(plan.pred_rows.shape[0])
                     tgt = image_features.reshape(-1, image_features.shape[-1])
-                    if self.apply_softmax:
-                        raise NotImplementedError("apply_softmax=True (soft-CE image loss) has no HIP kernel")
-                    if not self.normalize_vision:
-                        raise NotImplementedError("normalize_vision=False (mean-abs image loss) has no HIP kernel; "
-                                                  "every shipped recipe sets normalize_vision=True")
-                    if R == 0:
-                        # no answer-side image rows: the reference's mean over an empty tensor (NaN) -- SURVEY A9
-                        l_img = ce if tgt.shape[0] != 0 else nan
+                    cosine = self.normalize_vision and not self.apply_softmax
+                    Rt = tgt.shape[0]
+                    if R == 0 and Rt == 0 and (cosine or self.apply_softmax):
+                        l_img = nan          # mean over an empty tensor -- SURVEY A9 (understanding-only / text-only batches)
+                    elif R != Rt and cosine:
+                        l_img = ce           # F.cosine_similarity raises on the row mismatch; the reference's try/except (:451-455)
+                    elif R != Rt or R == 0:
+                        # soft-CE: broadcasting error; mean-abs (`mse_loss_fn`): a Python float has no .item() / division by len 0
+                        raise RuntimeError(f"image-AR head ({'soft-CE' if self.apply_softmax else 'mean-abs'}): {R} prediction rows vs "
+                                           f"{Rt} target rows -- the reference raises here as well (metamorph_llama.py:445,459-466)")
                     else:
                         pred_in = F.RowsGatherFn.apply(hid, pd["pred_rows"])
-                        pred = self.vision_head(pred_in)
-                        if tgt.shape[0] != R:
-                            l_img = ce                                  # the reference's try/except (:451-455)
-                        else:
-                            l_img = F.CosineLossFn.apply(pred.contiguous(), tgt.to(BF16).contiguous(), True)
+                        pred = self.vision_head(pred_in).contiguous()
+                        tgt = tgt.to(BF16).contiguous()
+                        if self.apply_softmax:                           # soft-CE against softmax(feat / 0.07) targets (:437-447)
+                            l_img = F.SoftCELossFn.apply(pred, tgt, self.normalize_vision)
+                        elif self.normalize_vision:                      # -mean cos (:449-455)
+                            l_img = F.CosineLossFn.apply(pred, tgt, True)
+                        else:                                            # mean |t - p| (`mse_loss_fn`, :459) -- the constructor default
+                            l_img = F.MeanAbsLossFn.apply(pred, tgt)
                 else:
                     l_img = ce                                          # metamorph_llama.py:461-462
                 self._loss_language_t = ce.detach()
@@ -317,8 +327,9 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
-                image_sizes=None, return_dict=None, cache_position=None, image_embeds=None, **kwargs):
-        """Reference metamorph_llama.py:603-660."""
+                image_sizes=None, return_dict=None, cache_position=None, image_embeds=None):
+        """Reference metamorph_llama.py:603-660 (same parameter list: no **kwargs, so HF Trainer keeps dividing the loss by the
+        gradient-accumulation steps exactly as it does for the reference class)."""
         image_positions = None
         target = None
         if inputs_embeds is None:
@@ -396,7 +407,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
             if self.normalize_vision:
                 pred_z = ops.bilinear_l2norm(pred_z.view(1, 1, -1).contiguous(), 1, 1, True).view(1, -1)
             if self.apply_softmax:
-                raise NotImplementedError("apply_softmax decode path has no HIP kernel")
+                pred_z = ops.softmax_rows(pred_z.contiguous(), 0.07)
             hid = self.model.mm_projector(pred_z)
         logits = ops.gemv(hid.contiguous(), self.lm_head.weight.data, out=torch.empty((1, self.lm_head.weight.shape[0]), device=x.device,
                                                                                     dtype=torch.float32))

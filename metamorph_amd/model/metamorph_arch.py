@@ -152,7 +152,8 @@ class MetaMorphMetaForCausalLM(ABC):
         msk_h = attention_mask.detach().cpu().numpy() if attention_mask is not None else None
         plan = build_splice_plan(ids_h, lab_h, msk_h, N, T, getattr(cfg, "tokenizer_model_max_length", None),
                                  getattr(cfg, "tokenizer_padding_side", "right"),
-                                 getattr(cfg, "image_start_id", DEFAULT_IMAGE_START_ID))
+                                 getattr(cfg, "image_start_id", DEFAULT_IMAGE_START_ID),
+                                 vocab_size=self.get_model().embed_tokens.weight.shape[0])
         pd = upload_plan(plan, dev)
         emb = self.get_model().embed_tokens
         proj2d = image_features.reshape(N * T, h)

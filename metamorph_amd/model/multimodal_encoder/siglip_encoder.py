@@ -123,6 +123,7 @@ class HipSiglipVisionTransformer(nn.Module):
         self.encoder = _Encoder(g)
         self.post_layernorm = HipLayerNorm(g["hidden_size"], g["layer_norm_eps"])   # kept for checkpoint round trips; unused
         self._cache = {}
+        self.gradient_checkpointing = False       # set by HF gradient_checkpointing_enable(); used when the tower trains
 
     @property
     def dtype(self):
@@ -134,7 +135,10 @@ class HipSiglipVisionTransformer(nn.Module):
 
     # -- derived, cached operands (the tower is frozen, so they are rebuilt only when storage moves) --------
     def _cached(self, key, srcs, build):
-        sig = tuple((s.data_ptr(), s._version) for s in srcs)
+        from ...functional import param_generation
+        # (pointer, torch version) catches re-loads and in-place torch updates; the generation counter catches optimizer steps that
+        # write parameters through raw pointers (a trainable tower under Zero2AdamW: eval / generation after training steps)
+        sig = (param_generation(),) + tuple((s.data_ptr(), s._version) for s in srcs)
         hit = self._cache.get(key)
         if hit is None or hit[0] != sig:
             hit = (sig, build())
@@ -216,7 +220,7 @@ class HipSiglipVisionTransformer(nn.Module):
         if not 0 <= run <= n_layers:
             raise IndexError(f"mm_vision_select_layer={select_layer} out of range for {n_layers} layers")
         x = F.PatchEmbedFn.apply(images, self.embeddings, *self.embeddings.parameters())
-        geo = F.SiglipGeo(N, P, heads, hv // heads, g["layer_norm_eps"])
+        geo = F.SiglipGeo(N, P, heads, hv // heads, g["layer_norm_eps"], recompute=bool(getattr(self, "gradient_checkpointing", False)))
         for layer in self.encoder.layers[:run]:
             x = F.SiglipLayerFn.apply(x, layer, geo, *layer.parameters())
         return x.view(N, P, hv)
@@ -289,14 +293,18 @@ class SiglipVisionTower(nn.Module):
             if self.image_token_reduction != "interpolation":
                 raise NotImplementedError("Not Implemented!")
             side_out = int(np.random.randint(1, 25)) if self.image_token_len == 0 else int(np.sqrt(self.image_token_len))
-        if self.apply_softmax:
-            raise NotImplementedError("apply_softmax=True (soft-CE variant) has no HIP kernel; recipes use normalize_vision")
-        if side_out == side_in and not self.normalize_vision:
-            return feats
-        if train:
-            from ... import functional as F
-            return F.BilinearL2NormFn.apply(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
-        return ops.bilinear_l2norm(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
+        from ... import functional as F
+        if side_out != side_in or self.normalize_vision:
+            if train:
+                feats = F.BilinearL2NormFn.apply(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
+            else:
+                feats = ops.bilinear_l2norm(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
+        if self.apply_softmax:                                   # softmax(feat / 0.07) (siglip_encoder.py:210-211)
+            n, t, c = feats.shape
+            flat = feats.reshape(n * t, c).contiguous()
+            flat = F.SoftmaxRowsFn.apply(flat, 0.07) if train else ops.softmax_rows(flat, 0.07)
+            feats = flat.view(n, t, c)
+        return feats
 
     @property
     def dtype(self):

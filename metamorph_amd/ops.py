@@ -411,8 +411,12 @@ def axpy_(y, x, s_dev=None, s_host=1.0, accumulate=True):
     _chk_dev(y, x)
     assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel() and y.dtype == BF16
     if x.dtype == torch.float32:
-        assert s_dev is None
-        _lib.check(_L().mm355_axpy_f32_to_bf16(y.data_ptr(), x.data_ptr(), y.numel(), s_host, int(accumulate), _stream()), "mm355_axpy_f32_to_bf16")
+        if s_dev is None:
+            _lib.check(_L().mm355_axpy_f32_to_bf16(y.data_ptr(), x.data_ptr(), y.numel(), s_host, int(accumulate), _stream()), "mm355_axpy_f32_to_bf16")
+        else:
+            assert s_dev.dtype == torch.float32
+            _lib.check(_L().mm355_axpy_f32_to_bf16_dev(y.data_ptr(), x.data_ptr(), y.numel(), s_dev.data_ptr(), s_host, int(accumulate), _stream()),
+                       "mm355_axpy_f32_to_bf16_dev")
     else:
         _lib.check(_L().mm355_axpy_bf16(y.data_ptr(), x.data_ptr(), y.numel(), _p(s_dev), s_host, int(accumulate), _stream()), "mm355_axpy_bf16")
     return y
@@ -436,6 +440,47 @@ def cosine_loss(pred_raw, target, normalize, want_grad=True):
     _lib.check(_L().mm355_cosine_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(normalize), cos_sum.data_ptr(), _p(dpred), _stream()),
                "mm355_cosine_loss")
     return cos_sum, dpred
+
+
+def mean_abs_loss(pred, target, want_grad=True):
+    """(sum |target - pred| as a 1-element f32 tensor, d mean|t - p| / d pred or None)  -- reference `mse_loss_fn`."""
+    _chk_dev(pred, target)
+    assert pred.is_contiguous() and target.is_contiguous() and pred.shape == target.shape and pred.dtype == BF16 and target.dtype == BF16
+    R, C = pred.shape
+    abs_sum = torch.zeros((1,), device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    _lib.check(_L().mm355_mean_abs_loss(pred.data_ptr(), target.data_ptr(), R, C, abs_sum.data_ptr(), _p(dpred), _stream()), "mm355_mean_abs_loss")
+    return abs_sum, dpred
+
+
+def soft_ce_loss(pred_raw, target, normalize, temperature=0.07, want_grad=True):
+    """(sum_r -sum_j t log(softmax(u / temperature) + 1e-10), d (that / R) / d pred_raw or None)."""
+    _chk_dev(pred_raw, target)
+    assert pred_raw.is_contiguous() and target.is_contiguous() and pred_raw.shape == target.shape
+    assert pred_raw.dtype == BF16 and target.dtype == BF16
+    R, C = pred_raw.shape
+    loss_sum = torch.zeros((1,), device=pred_raw.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred_raw) if want_grad else None
+    _lib.check(_L().mm355_soft_ce_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(bool(normalize)), float(temperature),
+                                       loss_sum.data_ptr(), _p(dpred), _stream()), "mm355_soft_ce_loss")
+    return loss_sum, dpred
+
+
+def softmax_rows(x2d, temperature=0.07):
+    _chk_dev(x2d)
+    assert x2d.is_contiguous() and x2d.dtype == BF16 and x2d.dim() == 2
+    y = torch.empty_like(x2d)
+    _lib.check(_L().mm355_softmax_rows(x2d.data_ptr(), y.data_ptr(), x2d.shape[0], x2d.shape[1], float(temperature), _stream()), "mm355_softmax_rows")
+    return y
+
+
+def softmax_rows_bwd(y2d, dy2d, temperature=0.07):
+    _chk_dev(y2d, dy2d)
+    assert y2d.is_contiguous() and dy2d.is_contiguous() and y2d.shape == dy2d.shape and y2d.dtype == BF16 and dy2d.dtype == BF16
+    dx = torch.empty_like(y2d)
+    _lib.check(_L().mm355_softmax_rows_bwd(y2d.data_ptr(), dy2d.data_ptr(), dx.data_ptr(), y2d.shape[0], y2d.shape[1], float(temperature),
+                                           _stream()), "mm355_softmax_rows_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------ splice / rows

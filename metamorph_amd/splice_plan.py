@@ -52,7 +52,7 @@ class SplicePlan:
 
 def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_per_image: int,
                       max_length: int | None, padding_side: str = "right",
-                      image_start_id: int = DEFAULT_IMAGE_START_ID) -> SplicePlan:
+                      image_start_id: int = DEFAULT_IMAGE_START_ID, vocab_size: int | None = None) -> SplicePlan:
     ids_all = np.asarray(input_ids)
     assert ids_all.ndim == 2
     B = ids_all.shape[0]
@@ -67,6 +67,13 @@ def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_p
     for b in range(B):
         ids = ids_all[b][msk_all[b]]
         lab = lab_all[b][msk_all[b]]
+        # token ids feed an embedding gather: anything outside [0, vocab) other than the <image> sentinel raises in the reference
+        # (nn.Embedding "index out of range in self", metamorph_arch.py:278,298) and must not become an out-of-bounds gather here
+        bad = (ids < 0) & (ids != IMAGE_TOKEN_INDEX)
+        if vocab_size is not None:
+            bad |= ids >= vocab_size
+        if bad.any():
+            raise IndexError(f"index out of range in self: token id {int(ids[bad][0])} of sample {b} is outside [0, {vocab_size})")
         where = np.flatnonzero(ids == IMAGE_TOKEN_INDEX)
         if where.size == 0:
             placeholder.append(img)
@@ -107,6 +114,12 @@ def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_p
         row_lab.append(np.concatenate(lab_parts))
         row_pos.append(np.concatenate(pos_parts))
 
+    # the reference indexes image_features[cur_image_idx] for EVERY sentinel and every text-only sample's dummy image
+    # (metamorph_arch.py:277,320): one image too few is an IndexError there, and must not become an out-of-bounds gather here
+    if img > num_images:
+        raise IndexError(f"index {num_images} is out of bounds for dimension 0 with size {num_images} "
+                         f"(the batch consumes {img} images -- <image> sentinels plus one dummy per text-only sample -- "
+                         f"but {num_images} were supplied; reference metamorph_arch.py:277,320)")
     if max_length is not None:
         row_src = [r[:max_length] for r in row_src]
         row_lab = [r[:max_length] for r in row_lab]

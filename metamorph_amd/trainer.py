@@ -1,0 +1,129 @@
+"""`MetaMorphTrainer`: the binding between HF `Trainer` and the MI355X hot path (reference metamorph/train/metamorph_trainer.py:138-298).
+
+The reference's trainer subclass exists to (a) build the optimizer parameter groups (`mm_projector_lr` / `vision_lr`, weight decay off
+for biases and norm weights) and (b) save only the adapter in stage 1; gradient exchange and optimizer-state sharding are delegated to
+DeepSpeed through `--deepspeed scripts/zero2.json`.  Here the same subclass name keeps (a) and (b) and replaces the DeepSpeed
+delegation with `Zero2AdamW` (metamorph_amd/zero2.py):
+
+  * `create_optimizer` builds the reference's groups and hands them to `Zero2AdamW` (flat bf16 parameter / gradient buffers, per-layer
+    reduce-scatter over RCCL started from inside the backward pass, sharded fused AdamW, all-gather);
+  * the model is NOT wrapped in DistributedDataParallel: the decoder's autograd nodes write weight gradients straight into the flat
+    gradient buffer and return None to autograd, so DDP's reducer hooks would never fire (and DDP would average the few autograd-routed
+    gradients a second time).  `Zero2AdamW` is the only gradient exchange;
+  * gradient clipping moves into the optimizer (`max_grad_norm` is the norm of the MEAN gradient over ranks, computed from the sharded
+    reduce-scattered buffer; HF's own `clip_grad_norm_` would see un-reduced local gradients);
+  * `training_step` arms the overlapped reduce-scatter on the last micro-step of an accumulation window;
+  * `gradient_checkpointing=True` (every reference launch script) maps onto per-layer recompute in `DecoderLayerFn`.
+"""
+from __future__ import annotations
+
+import torch
+from transformers import Trainer
+
+from .checkpoint import save_trainer_adapter_checkpoint
+from .zero2 import Zero2AdamW, tag_segments
+
+
+def _decay_parameter_names(model):
+    """Names that receive weight decay: everything except biases and normalisation weights (HF `get_parameter_names(model,
+    ALL_LAYERNORM_LAYERS)` minus "bias", reference metamorph_trainer.py:170-171)."""
+    import torch.nn as nn
+    from .model.modules import HipLayerNorm, HipRMSNorm
+    norm_types = (nn.LayerNorm, HipLayerNorm, HipRMSNorm)
+    skip = set()
+    for mname, mod in model.named_modules():
+        if isinstance(mod, norm_types):
+            for pname, _ in mod.named_parameters(recurse=False):
+                skip.add(f"{mname}.{pname}" if mname else pname)
+    return [n for n, _ in model.named_parameters() if n not in skip and "bias" not in n]
+
+
+def optimizer_grouped_parameters(model, weight_decay, mm_projector_lr=None, vision_lr=None):
+    """The reference's four-way split (decay x {base lr, special lr}), reference metamorph_trainer.py:172-245."""
+    decay = set(_decay_parameter_names(model))
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    special, special_lr = set(), None
+    if mm_projector_lr is not None:
+        special, special_lr = {n for n, _ in named if "mm_projector" in n}, mm_projector_lr
+    elif vision_lr is not None:
+        special, special_lr = {n for n, _ in named if "vision_tower" in n}, vision_lr
+    groups = [
+        {"params": [p for n, p in named if n in decay and n not in special], "weight_decay": weight_decay},
+        {"params": [p for n, p in named if n not in decay and n not in special], "weight_decay": 0.0},
+    ]
+    if special:
+        groups += [
+            {"params": [p for n, p in named if n in decay and n in special], "weight_decay": weight_decay, "lr": special_lr},
+            {"params": [p for n, p in named if n not in decay and n in special], "weight_decay": 0.0, "lr": special_lr},
+        ]
+    return [g for g in groups if g["params"]]
+
+
+class MetaMorphTrainer(Trainer):
+    """Drop-in for the reference's `MetaMorphTrainer`; `zero2_kwargs` are forwarded to `Zero2AdamW` (tests inject CPU shard kernels)."""
+
+    def __init__(self, *args, zero2_kwargs=None, **kwargs):
+        self._zero2_kwargs = dict(zero2_kwargs or {})
+        self._mm_max_grad_norm = None
+        super().__init__(*args, **kwargs)
+        # clipping happens inside Zero2AdamW on the reduced gradient (see the module docstring)
+        self._mm_max_grad_norm = self.args.max_grad_norm
+        self.args.max_grad_norm = 0.0
+
+    # ------------------------------------------------------------------ no DDP wrapper
+    def create_accelerator_and_postprocess(self):
+        super().create_accelerator_and_postprocess()
+        acc = self.accelerator
+        inner = acc.prepare_model
+
+        def prepare_model(model, device_placement=None, evaluation_mode=False):
+            if getattr(model, "_mm355_no_ddp", False) or hasattr(model, "get_model"):
+                # Zero2AdamW exchanges the gradients; a DDP reducer would wait for hooks that never fire
+                if model not in acc._models:
+                    acc._models.append(model)
+                return model
+            return inner(model, device_placement=device_placement, evaluation_mode=evaluation_mode)
+
+        acc.prepare_model = prepare_model
+
+    # ------------------------------------------------------------------ optimizer
+    def create_optimizer(self):
+        if self.optimizer is not None:
+            return self.optimizer
+        a = self.args
+        tag_segments(self.model)                                     # one reduce-scatter segment per decoder layer
+        groups = optimizer_grouped_parameters(self.model, a.weight_decay, getattr(a, "mm_projector_lr", None), getattr(a, "vision_lr", None))
+        max_norm = self._mm_max_grad_norm if self._mm_max_grad_norm is not None else a.max_grad_norm
+        self.optimizer = Zero2AdamW(groups, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
+                                    weight_decay=a.weight_decay, max_grad_norm=max_norm or 0.0, **self._zero2_kwargs)
+        self.optimizer.enable_overlap()
+        return self.optimizer
+
+    def _zero2(self):
+        opt = self.optimizer
+        while opt is not None and not isinstance(opt, Zero2AdamW):
+            opt = getattr(opt, "optimizer", None)                    # accelerate's AcceleratedOptimizer wrapper
+        return opt
+
+    def training_step(self, model, inputs, num_items_in_batch=None):
+        z = self._zero2()
+        if z is not None and self.accelerator.sync_gradients:
+            z.arm_overlap()                                          # last micro-step: these gradients are final
+        return super().training_step(model, inputs, num_items_in_batch)
+
+    # ------------------------------------------------------------------ stage-1 adapter checkpoints (reference :273-298)
+    def _save_checkpoint(self, model, trial, metrics=None):
+        if getattr(self.args, "tune_mm_mlp_adapter", False):
+            save_trainer_adapter_checkpoint(self.model, self._get_output_dir(trial=trial), self.state.global_step,
+                                            use_im_start_end=getattr(self.args, "use_im_start_end", False),
+                                            is_main_process=self.args.local_rank in (0, -1))
+            return
+        z = self._zero2()
+        if z is not None:
+            z.synchronize()
+        super()._save_checkpoint(model, trial)
+
+    def _save(self, output_dir=None, state_dict=None):
+        if getattr(self.args, "tune_mm_mlp_adapter", False):
+            return
+        super()._save(output_dir, state_dict)

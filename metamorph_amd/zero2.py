@@ -363,6 +363,9 @@ class Zero2AdamW(torch.optim.Optimizer):
                 self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *self._hyper(gi))
             self._all_gather_params()
         self.grad_norm = self._norm_buf        # sum of squares of the summed gradient (device scalar); see grad_norm_value()
+        if self.flat_param.is_cuda:
+            from . import functional as F
+            F.bump_param_generation()          # parameters changed behind torch's version counters: drop derived-operand caches
         return None
 
     def _clip_coef_scaled(self, inv_world):

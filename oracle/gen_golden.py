@@ -358,6 +358,15 @@ def e2e_batch(kind):
                [A, A, 23, ST, IM, EN, 128009, 128001]]
         lab = [[-100] * 4 + [ST, IM, EN, 128009],
                [-100] * 3 + [ST, IM, EN, 128009, -100]]
+    elif kind == "multi_frame":
+        # BASELINE configs[2] in miniature: several prompt-side frames per sample (interleaved "video" frames), one sample that
+        # also carries an answer-side image after three prompt frames, one with two frames and trailing text
+        ids = [[A, A, 11, ST, IM, EN, ST, IM, EN, ST, IM, EN, 12, 13, 14, 128009],
+               [A, A, ST, IM, EN, 21, ST, IM, EN, ST, IM, EN, 22, ST, IM, EN, 128009],
+               [A, A, 31, ST, IM, EN, 32, ST, IM, EN, 33, 34, 35]]
+        lab = [[-100] * 12 + [12, 13, 14, 128009],
+               [-100] * 12 + [22, ST, IM, EN, 128009],
+               [-100] * 10 + [33, 34, 35]]
     else:
         raise KeyError(kind)
     return ids, lab
@@ -370,11 +379,24 @@ def grad_summary(t):
     return torch.cat([f.norm()[None], f[idx]])
 
 
+E2E_CASES = [
+    # (kind, T, use_vision_ar, head variant): "cos" = normalize_vision (every shipped recipe); "l1" = the constructor default
+    # (mean-abs `mse_loss_fn`); "softce" = apply_softmax on normalised features; "softce_raw" = apply_softmax alone
+    ("mixed", 4, True, "cos"), ("mixed", 16, True, "cos"), ("understanding_only", 4, True, "cos"),
+    ("understanding_only", 4, False, "cos"), ("generation_only", 4, True, "cos"),
+    ("multi_frame", 4, True, "cos"),
+    ("mixed", 4, True, "l1"), ("generation_only", 4, True, "l1"),
+    ("mixed", 4, True, "softce"), ("generation_only", 4, True, "softce_raw"),
+]
+HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
+
+
 def gen_e2e():
-    rng = np.random.default_rng(41)
-    for kind, T, use_ar in (("mixed", 4, True), ("mixed", 16, True), ("understanding_only", 4, True),
-                            ("understanding_only", 4, False), ("generation_only", 4, True)):
-        cfg = tiny_cfg(num_image_tokens=T, use_vision_ar=use_ar)
+    shared = np.random.default_rng(41)               # the first five cases draw their images from ONE stream, in this order
+    for i, (kind, T, use_ar, variant) in enumerate(E2E_CASES):
+        rng = shared if i < 5 else np.random.default_rng(4100 + i)
+        nv, sm = HEAD_VARIANTS[variant]
+        cfg = tiny_cfg(num_image_tokens=T, use_vision_ar=use_ar, normalize_vision=nv, apply_softmax=sm)
         sd = init_state_dict(cfg, seed=43)
         ids, lab = e2e_batch(kind)
         pad_id = 128001
@@ -383,6 +405,7 @@ def gen_e2e():
         msk_t = ids_t.ne(pad_id)
         n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+        suffix = "" if variant == "cos" else "_" + variant
         for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             model = build_reference(cfg, sd, dt)
             for n, p in model.named_parameters():
@@ -390,6 +413,7 @@ def gen_e2e():
             out = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images.to(dt))
             rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, images=images,
                        seed=np.int64(43), rows_per_image=np.int64(T), use_vision_ar=np.int64(use_ar),
+                       normalize_vision=np.int64(nv), apply_softmax=np.int64(sm),
                        loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language),
                        loss_image_ar=np.float64(model.loss_image_ar),
                        logits_sub=out.logits[:, :, ::997], hidden=out.hidden_states)
@@ -398,7 +422,7 @@ def gen_e2e():
                 for n, p in model.named_parameters():
                     if p.grad is not None and "vision_proj" not in n:
                         rec["grad::" + n] = grad_summary(p.grad)
-            save_npz(f"e2e_{kind}_T{T}_ar{int(use_ar)}_{tag}.npz", **rec)
+            save_npz(f"e2e_{kind}_T{T}_ar{int(use_ar)}{suffix}_{tag}.npz", **rec)
 
 
 # ----------------------------------------------------------------------------- N2 (batch producer)
@@ -525,6 +549,110 @@ def gen_conv():
     with open(os.path.join(OUT, "n2_conversation.json"), "w") as f:
         json.dump(dict(cases=cases, default=C.default_conversation.version), f, indent=0)
     print(f"  wrote n2_conversation.json ({len(cases)} prompts)")
+
+
+# ----------------------------------------------------------------------------- N1: the reference's own greedy_decode loop
+
+DECODE_ACTIVE = [ST, EN, 128009, 11, 12, 13, 14, 15, 40, 41, 42, 43, 44, 45, 46, 47]
+
+
+def decode_lm_head(sd, rows):
+    """lm_head of the decode fixtures: zero everywhere except a handful of ACTIVE token rows (8 x the seeded rows), so that
+    argmax decisions have margins far above bf16 noise instead of being near-ties among 128k random logits; `rows` overrides
+    individual rows (the <image_start> / <image_end> / <eot> rows aligned with recorded hidden rows, see gen_decode)."""
+    W = torch.zeros_like(sd["lm_head.weight"])
+    W[DECODE_ACTIVE] = 8.0 * sd["lm_head.weight"][DECODE_ACTIVE]
+    for tok, vec in rows.items():
+        W[tok] = vec
+    return W
+
+
+def gen_decode():
+    """Runs the reference's `generate` -> `greedy_decode` (metamorph_llama.py:502-597, 665-717; image-mode feedback :363-377)
+    unchanged on a tiny random model and records the emitted token ids, the per-step top-2 logit margins and the predicted visual
+    embeddings (`pred_z`).  The weights are the seeded ones except for lm_head (see decode_lm_head): the rows of the tokens the
+    loop is meant to emit are solved (least norm) so that each scores 12 on the hidden row the reference itself produces at its
+    step and 0 at every other step -- the loop then walks token mode -> <image_start> -> image mode (4 continuous tokens fed back
+    through vision_head / mm_projector) -> <image_end> -> two text tokens -> <|eot_id|> with decision margins far above bf16 noise.
+    (The hidden row of step k depends only on the tokens emitted before k, never on lm_head, so the construction converges by
+    extending the correct prefix one step per pass.)"""
+    A = 128000
+    cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1)}
+    plan = [(0, ST), (5, EN), (6, 41), (7, 42), (8, 128009)]     # (loop iteration, token it must emit); iterations 1-4 = image mode
+    image_steps = [1, 2, 3, 4]
+    for ci, (name, (ids, n_img)) in enumerate(cases.items()):
+        ids_t = torch.tensor(ids)
+        seed = 61 + ci
+        cfg = tiny_cfg(num_image_tokens=4)
+        sd = init_state_dict(cfg, seed=seed)
+        images = None
+        if n_img:
+            images = torch.from_numpy(np.random.default_rng(seed).standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+
+        def run(rows, dt, max_new=12):
+            sd2 = dict(sd)
+            sd2["lm_head.weight"] = decode_lm_head(sd, rows)
+            model = build_reference(cfg, sd2, dt)
+            model.eval()
+            lm_in, logits = [], []
+            model.lm_head.register_forward_pre_hook(lambda m, a: lm_in.append(a[0][0, -1].detach().float().clone()))
+            model.lm_head.register_forward_hook(lambda m, a, o: logits.append(o[0, -1].detach().float().clone()))
+            with torch.no_grad():
+                out, emb = model.generate(inputs=ids_t, images=None if images is None else images.to(dt), output_image=True,
+                                          max_new_tokens=max_new)
+            return out[0].tolist(), emb.float(), lm_in, logits
+
+        def solve(hid):
+            """Rows for the planned tokens from the hidden rows known so far: 12 at the own step, 0 at the other known steps
+            (eos: -0.5 inside image mode, where the loop only tests for eos)."""
+            steps = sorted(hid)
+            H = torch.stack([hid[t] for t in steps]).double()                     # [n_steps, h]
+            pinv = torch.linalg.pinv(H)                                            # [h, n_steps]
+            rows = {}
+            for t, tok in plan:
+                if t not in hid:
+                    continue
+                y = torch.tensor([12.0 if u == t else (-0.5 if (tok == 128009 and u in image_steps) else 0.0) for u in steps],
+                                 dtype=torch.float64)
+                rows[tok] = (pinv @ y).float()
+            return rows
+
+        hid, rows = {}, {}
+        for _ in range(len(plan) + 1):
+            toks, emb, lm_in, logits = run(rows, torch.float32)
+            argm = [int(l.argmax()) for l in logits]
+            good = 0                                                               # iterations whose emitted prefix is as planned
+            want = dict(plan)
+            for t in range(len(lm_in)):
+                hid[t] = lm_in[t]                                                  # valid: everything before t was as planned
+                if t in want and argm[t] != want[t]:
+                    break
+                good = t + 1
+            if good >= plan[-1][0] + 1:
+                break
+            hid = {t: v for t, v in hid.items() if t <= good}
+            rows = solve(hid)
+        toks, emb, lm_in, logits = run(rows, torch.float32)
+        assert toks == [tok for _, tok in plan] and emb.shape[0] == 4 and len(logits) == plan[-1][0] + 1, (name, toks, emb.shape)
+        top2 = [l.topk(2) for l in logits]
+        margins = torch.stack([t.values[0] - t.values[1] for t in top2])
+        decision = [t for t, _ in plan]
+        assert float(margins[decision].min()) > 2.0, margins
+        for t in image_steps:          # eos must lose clearly inside image mode (128001 has an all-zero row: it ties with id 0, which
+            assert float(logits[t][128009]) < float(logits[t].max()) - 0.3        # argmax returns first, so it can never be emitted)
+        toks16, emb16, _, logits16 = run(rows, torch.bfloat16)
+        assert toks16 == toks
+        save_npz(f"n1_decode_{name}.npz", seed=np.int64(seed), input_ids=ids_t,
+                 images=images if images is not None else torch.zeros(0), active=np.array(DECODE_ACTIVE, dtype=np.int64),
+                 row_tokens=np.array(list(rows.keys()), dtype=np.int64), row_values=torch.stack(list(rows.values())),
+                 tokens=np.array(toks, dtype=np.int64), tokens_bf16=np.array(toks16, dtype=np.int64), margins=margins,
+                 decision_steps=np.array(decision, dtype=np.int64),
+                 step_argmax=np.array([int(t.indices[0]) for t in top2], dtype=np.int64),
+                 active_logits=torch.stack([l[DECODE_ACTIVE] for l in logits]),
+                 active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]),
+                 pred_z=emb, pred_z_bf16=emb16, max_new_tokens=np.int64(12))
+        print(f"    {name}: seed {seed} tokens {toks} min decision margin {float(margins[decision].min()):.3f} "
+              f"pred_z bf16-vs-f32 rel {float((emb16 - emb).norm() / emb.norm()):.3e}")
 
 
 if __name__ == "__main__":

@@ -193,7 +193,8 @@ def splice(sd, cfg: OracleConfig, input_ids, labels, attention_mask, proj_feat, 
 
 # ------------------------------------------------------------------ full forward
 
-def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False):
+def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False,
+            ce_rows_only=False):
     feat = vision_features(sd, cfg, images, train_vision)      # [N,T,hv]; no grad unless the tower trains (row N4)
     proj = mm_projector(sd, cfg, feat)                         # [N,T,h]
     target = feat.detach().clone()
@@ -202,13 +203,22 @@ def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, re
     hid = llama_decoder(sd, cfg, x, key_valid, None)
     out = {"hidden_states": hid, "labels": lab, "attention_mask": key_valid,
            "image_positions": img_pos, "target_features": target, "inputs_embeds": x}
-    logits = ops.linear(hid, sd["lm_head.weight"]).float()
-    if return_logits:
-        out["logits"] = logits
-    if lab is None:
-        out["loss"] = None
-        return out
-    ce = ops.shifted_cross_entropy(logits, lab, IGNORE_INDEX)
+    if ce_rows_only and lab is not None and not return_logits:
+        # full-size cases: logits only for the rows whose NEXT label is live -- the same mean NLL as below, without the
+        # [B, L, V] fp32 tensor the reference materialises
+        nxt = torch.full_like(lab, IGNORE_INDEX)
+        nxt[:, :-1] = lab[:, 1:]
+        keep = nxt != IGNORE_INDEX
+        lg = ops.linear(hid[keep], sd["lm_head.weight"]).float()
+        ce = (torch.logsumexp(lg, -1) - lg.gather(1, nxt[keep][:, None])[:, 0]).sum() / keep.sum()
+    else:
+        logits = ops.linear(hid, sd["lm_head.weight"]).float()
+        if return_logits:
+            out["logits"] = logits
+        if lab is None:
+            out["loss"] = None
+            return out
+        ce = ops.shifted_cross_entropy(logits, lab, IGNORE_INDEX)
     # rows of hidden[:, :-1] whose NEXT position is an answer-image row (metamorph_llama.py:386-390,425-432)
     sel = img_pos[:, 1:].bool()
     pred_in = hid[:, :-1][sel]                                  # [R,h], row-major (b,t) order
@@ -237,17 +247,99 @@ def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, re
     return out
 
 
+# ------------------------------------------------------------------ greedy decode (row N1)
+
+def greedy_decode(sd, cfg: OracleConfig, input_ids, images=None, max_new_tokens=1024, start_image_token_id=IMAGE_START_ID,
+                  end_image_token_id=128257, eos_token_id=(128001, 128009)):
+    """The reference's `generate` + `greedy_decode` loop (metamorph_llama.py:665-717, 502-597) restated: the prefix is re-run every
+    step (use_cache=False there); in image mode the last hidden row goes through vision_head -> normalise (-> softmax / 0.07) ->
+    mm_projector and is fed back as the next input row (:363-377).  Returns (token ids, pred_z [n, hv], per-step last-row logits)."""
+    with torch.no_grad():
+        if images is not None:
+            feat = vision_features(sd, cfg, images)
+            proj = mm_projector(sd, cfg, feat)
+            x, _, _, _, _, _ = splice(sd, cfg, input_ids, None, None, proj, feat)
+        else:
+            x = sd["model.embed_tokens.weight"][input_ids]
+        in_image_mode = False
+        generated, embeds, step_logits = [], [], []
+        total_image_tokens = total_out = 0
+        while True:
+            B, L, _ = x.shape
+            hid = llama_decoder(sd, cfg, x, torch.ones(B, L, dtype=torch.bool))
+            image_embed = None
+            if in_image_mode:
+                pred_z = vision_head(sd, cfg, hid[:, -1, :])
+                if cfg.normalize_vision:
+                    pred_z = ops.l2_normalize(pred_z)
+                if cfg.apply_softmax:
+                    pred_z = torch.softmax(pred_z / 0.07, dim=-1)
+                image_embed = pred_z
+                hid = hid.clone()
+                hid[:, -1, :] = mm_projector(sd, cfg, pred_z)
+            logits = ops.linear(hid[:, -1, :], sd["lm_head.weight"]).float()
+            step_logits.append(logits[0])
+            next_token = int(torch.argmax(logits, dim=-1)[0])
+            next_embed = hid[:, -1:, :]
+            tok_embed = sd["model.embed_tokens.weight"][torch.tensor([[next_token]])].to(x.dtype)
+            if (not in_image_mode) and next_token == start_image_token_id:
+                in_image_mode = True
+                generated.append(next_token)
+                x = torch.cat((x, tok_embed), dim=1)
+            elif in_image_mode and total_image_tokens < cfg.num_image_tokens:
+                total_image_tokens += 1
+                embeds.append(image_embed)
+                x = torch.cat((x, next_embed), dim=1)
+                if total_image_tokens == cfg.num_image_tokens:
+                    in_image_mode = False
+            elif next_token == end_image_token_id:
+                in_image_mode = False
+                total_image_tokens = 0
+                generated.append(next_token)
+                x = torch.cat((x, tok_embed), dim=1)
+            else:
+                x = torch.cat((x, tok_embed), dim=1)
+                generated.append(next_token)
+            total_out += 1
+            if next_token in eos_token_id or total_out > max_new_tokens:
+                break
+        pz = torch.cat(embeds, dim=0) if embeds else torch.zeros(0)
+        return generated, pz, step_logits
+
+
+def decode_fixture_state_dict(g, cfg: OracleConfig, dtype=torch.float32):
+    """Weights of a tests/golden/n1_decode_*.npz fixture: the seeded state dict with the sparse lm_head the fixture describes
+    (oracle/gen_golden.py:gen_decode -- zero rows except `active` (8 x seeded) and the solved `row_tokens` rows)."""
+    import numpy as np
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    W = torch.zeros_like(sd["lm_head.weight"])
+    act = g["active"].tolist()
+    W[act] = 8.0 * sd["lm_head.weight"][act]
+    for tok, vec in zip(g["row_tokens"].tolist(), g["row_values"]):
+        W[tok] = torch.from_numpy(np.asarray(vec))
+    sd["lm_head.weight"] = W
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
 # ------------------------------------------------------------------ synthetic weights
 
 def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: float = 0.02,
-                    with_vision=True):
+                    with_vision=True, fast_big=False):
     """Deterministic N(0, std) weights (numpy PCG64 so the stream is platform independent);
-    norm weights 1 + N(0, 0.1) so that their gradients are exercised."""
+    norm weights 1 + N(0, 0.1) so that their gradients are exercised.  fast_big=True draws tensors of more than 2^24 elements
+    from torch's multi-threaded generator instead (full-width test cases: ~1.5 G values; the device model and the oracle
+    are built from the same dict in the same process, so platform independence is not needed there)."""
     import numpy as np
     rng = np.random.default_rng(seed)
+    tg = torch.Generator().manual_seed(seed)
     sd = {}
 
     def rnd(*shape, s=std):
+        n = 1
+        for d in shape:
+            n *= d
+        if fast_big and n > (1 << 24):
+            return (torch.randn(*shape, generator=tg, dtype=torch.float32) * s).to(dtype)
         return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * s).to(dtype)
 
     def norm_w(n):

@@ -381,3 +381,22 @@ def test_conversation_templates_match_reference_prompts():
         assert C.conv_templates[case["template"]].messages == []          # copy() does not leak messages into the template
     with pytest.raises(ValueError):
         C.Conversation(system="", roles=("a", "b"), messages=[], sep_style=C.SeparatorStyle.TWO).get_prompt()
+
+
+def test_splice_plan_refuses_what_the_reference_refuses():
+    """one image too few, or a token id outside the vocabulary, is an IndexError in the reference
+    (image_features[cur_image_idx] at metamorph_arch.py:277,320; nn.Embedding at :278,298) -- never an out-of-bounds device gather."""
+    from metamorph_amd.splice_plan import build_splice_plan
+    A, ST, IM, EN = 128000, 128256, -200, 128257
+    ids = np.array([[A, 5, ST, IM, EN, 6, ST, IM, EN, 7]])
+    lab = np.array([[-100, -100, ST, IM, EN, 6, ST, IM, EN, 7]])
+    build_splice_plan(ids, lab, None, 2, 4, 64)                              # two answer images, two supplied: fine
+    with pytest.raises(IndexError):
+        build_splice_plan(ids, lab, None, 1, 4, 64)                          # ... one supplied
+    with pytest.raises(IndexError):                                          # text-only sample needs its dummy image as well
+        build_splice_plan(np.array([[A, IM, 7], [A, 8, 9]]), None, None, 1, 4, 64)
+    with pytest.raises(IndexError):
+        build_splice_plan(np.array([[A, 5, 128258]]), None, None, 1, 4, 64, vocab_size=128258)
+    with pytest.raises(IndexError):
+        build_splice_plan(np.array([[A, -7, 5]]), None, None, 1, 4, 64, vocab_size=128258)
+    build_splice_plan(np.array([[A, 5, 128257]]), None, None, 1, 4, 64, vocab_size=128258)

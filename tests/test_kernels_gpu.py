@@ -67,6 +67,27 @@ def test_gemm_plain(ops, variant, shape):
     close(out, ref, 1e-2, 0.02 * math.sqrt(K), f"gemm v{variant} {shape}")
 
 
+@pytest.mark.parametrize("variant", [0, 1, 7, 11])
+@pytest.mark.parametrize("shape", [(512, 384, 1152), (1024, 1024, 4096), (2304, 2048, 4096), (300, 200, 192), (256, 256, 8192)])
+def test_gemm_fp32_output_tight(ops, variant, shape):
+    """OUT_F32 removes the bf16 output rounding, so the kernel is compared with an fp64 product of the same bf16 operands to
+    accumulation-order accuracy: a dropped / doubled k element (|a||b| ~ 1) or a mis-ordered fragment would be 10^4 x the bound."""
+    M, N, K = shape
+    if K % 64 and variant in (7, 11):
+        pytest.skip("LDS-DMA variants need K % 64 == 0")
+    a, b = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    ref = (a.double() @ b.double().t())
+    out = ops.gemm(a.to(DEV), b.to(DEV), out_f32=True, variant=variant).double().cpu()
+    # fp32 accumulation of exact bf16 products, |a| ~ |b| ~ 1: partial sums ~ sqrt(k), error random-walks to ~ 2^-24 K / 2.4 (1e-4 at
+    # K = 4096); 4 K 2^-24 (1e-3 at K = 4096) is ~10 sigma and still 500x below one missing product
+    bound = 4 * K * 2.0 ** -24
+    bad = (out - ref).abs() > bound
+    assert not bool(bad.any()), f"gemm f32 v{variant} {shape}: {int(bad.sum())} elements beyond the fp32 accumulation bound; max err {float((out - ref).abs().max()):.3e}"
+    # the bf16 output of the same launch is that fp32 value rounded once (<= 1/2 ulp = 2^-9 relative)
+    o16 = ops.gemm(a.to(DEV), b.to(DEV), variant=variant).double().cpu()
+    assert bool(((o16 - ref).abs() <= 2.0 ** -8 * ref.abs() + bound).all()), f"gemm bf16 v{variant} {shape}: more than one rounding away"
+
+
 @pytest.mark.parametrize("shape", [(256, 256, 128), (700, 520, 256), (1024, 768, 2048), (2304, 2048, 1152), (4096, 4096, 8192)])
 def test_gemm_pingpong_race_screen(ops, shape):
     """The staggered two-group 256x256 kernel (variant 11): counted waits + barriers are the only ordering between the LDS-DMA
@@ -404,6 +425,51 @@ def test_attn_bwd(ops, case):
     close(dqkv[:, (Hq + Hkv) * d:].view(B, L, Hkv, d), vf.grad.transpose(1, 2), what=f"dv {case}", **tol)
 
 
+@pytest.mark.parametrize("L", [2048, 4096])
+def test_attn3_full_length_against_oracle_slice(ops, L):
+    """The d = 128 LDS-DMA kernels at BASELINE sequence lengths (configs[1] L = 2048, configs[2] L = 4096), LLaMA-3-8B head
+    geometry (32 query / 8 KV heads), per-sample lengths: forward output, lse and all three gradients of ONE (sample, KV group)
+    slice against the fp32 oracle (4 query heads x L x L scores on the CPU), for a full-length and a ragged sample."""
+    B, Hq, Hkv, d = 2, 32, 8, 128
+    seqlens = [L, L - 333]
+    ld = (Hq + 2 * Hkv) * d
+    qkv = rnd(B * L, ld, seed=11 + L, scale=0.7)
+    do = rnd(B * L, Hq * d, seed=12 + L, scale=0.5)
+    valid = torch.arange(L)[None] < torch.tensor(seqlens)[:, None]
+    do = (do.view(B, L, -1) * valid[:, :, None]).reshape(B * L, -1).contiguous()
+    dev = qkv.to(DEV)
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV)
+    qd, kd, vd = dev[:, :Hq * d], dev[:, Hq * d:(Hq + Hkv) * d], dev[:, (Hq + Hkv) * d:]
+    o, lse = ops.attn_fwd(qd, kd, vd, B, L, Hq, Hkv, d, d ** -0.5, True, sl)
+    dqkv = torch.full_like(dev, float("nan"))
+    ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, B, L, Hq, Hkv, d, d ** -0.5, True, sl,
+                 dqkv[:, :Hq * d], dqkv[:, Hq * d:(Hq + Hkv) * d], dqkv[:, (Hq + Hkv) * d:])
+    assert bool(torch.isfinite(dqkv.float()).all()), "every gradient element must be written"
+    rep = Hq // Hkv
+    for b, g in ((0, 5), (1, 2)):                                # (sample, KV head): query heads g*rep .. g*rep + rep - 1
+        n = seqlens[b]
+        rows = slice(b * L, b * L + L)
+        q = qkv[rows, :Hq * d].view(L, Hq, d)[:, g * rep:(g + 1) * rep].permute(1, 0, 2)[None].float().requires_grad_(True)
+        k = qkv[rows, Hq * d:(Hq + Hkv) * d].view(L, Hkv, d)[:, g:g + 1].permute(1, 0, 2)[None].float().requires_grad_(True)
+        v = qkv[rows, (Hq + Hkv) * d:].view(L, Hkv, d)[:, g:g + 1].permute(1, 0, 2)[None].float().requires_grad_(True)
+        ref = R.attention(q, k, v, valid[b:b + 1], causal=True)                          # [1, rep, L, d]
+        dos = do[rows].view(L, Hq, d)[:, g * rep:(g + 1) * rep].permute(1, 0, 2)[None].float()
+        (ref * dos).sum().backward()
+        got_o = o[rows].view(L, Hq, d)[:, g * rep:(g + 1) * rep].permute(1, 0, 2)
+        close(got_o[:, :n], ref[0, :, :n], 1e-2, 4e-3, f"attn3 fwd L={L} sample {b} group {g}")
+        assert float(got_o[:, n:].float().abs().max()) == 0 if n < L else True
+        s = torch.matmul(q[0].detach(), k[0].detach().transpose(-1, -2)) * d ** -0.5
+        s = s.masked_fill(~torch.ones(L, L, dtype=torch.bool).tril(), float("-inf")).masked_fill(~valid[b][None, None, :], float("-inf"))
+        close(lse[b, g * rep:(g + 1) * rep, :n], torch.logsumexp(s, -1)[:, :n], 1e-3, 5e-3, f"attn3 lse L={L}")
+        tol = dict(rtol=2e-2, atol=1e-2)
+        gq = dqkv[rows, :Hq * d].view(L, Hq, d)[:, g * rep:(g + 1) * rep].permute(1, 0, 2)
+        gk = dqkv[rows, Hq * d:(Hq + Hkv) * d].view(L, Hkv, d)[:, g]
+        gv = dqkv[rows, (Hq + Hkv) * d:].view(L, Hkv, d)[:, g]
+        close(gq, q.grad[0], what=f"attn3 dq L={L} sample {b} group {g}", **tol)
+        close(gk, k.grad[0, 0], what=f"attn3 dk L={L} sample {b} group {g}", **tol)
+        close(gv, v.grad[0, 0], what=f"attn3 dv L={L} sample {b} group {g}", **tol)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 
 def test_swiglu_gelu(ops):
@@ -479,6 +545,51 @@ def test_cosine_loss(ops):
         cs, dp = ops.cosine_loss(p.to(DEV), t.to(DEV), normalize)
         close(-cs[0] / Rr, loss, 1e-2, 2e-3, f"cosine loss normalize={normalize}")
         close(dp, pf.grad, 3e-2, 2e-2 * float(pf.grad.abs().max()), f"cosine grad normalize={normalize}")
+
+
+def test_mean_abs_loss(ops):
+    """The reference's `mse_loss_fn` (mean |z - h|, metamorph_llama.py:211-219): value and gradient against the oracle."""
+    Rr, C = 37, 1152
+    p, t = rnd(Rr, C, seed=3), rnd(Rr, C, seed=4)
+    t[5, :16] = p[5, :16]                                        # exact ties: sign(0) = 0 like torch.abs backward
+    pf = p.float().requires_grad_(True)
+    loss = R.mean_abs_loss(t.float(), pf)
+    loss.backward()
+    s, dp = ops.mean_abs_loss(p.to(DEV), t.to(DEV))
+    close(s[0] / (Rr * C), loss, 2e-3, 1e-5, "mean-abs loss")     # bf16 difference (reference stack) vs fp32 difference
+    close(dp, pf.grad, 1e-2, 0.0, "mean-abs grad")
+    assert float(dp[5, :16].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_soft_ce_loss(ops, normalize):
+    """apply_softmax head (metamorph_llama.py:434-447): -(t * log(softmax(u / 0.07) + 1e-10)).sum(1).mean() with soft targets."""
+    Rr, C = 19, 1152
+    scale = 1.0 if normalize else 0.03                           # raw predictions / 0.07 must not saturate the softmax
+    p = rnd(Rr, C, seed=5, scale=scale)
+    t = torch.softmax(R.l2_normalize(rnd(Rr, C, seed=6).float()) / 0.07, -1).bfloat16()
+    pf = p.float().requires_grad_(True)
+    u = R.l2_normalize(pf) if normalize else pf
+    loss = R.soft_ce_loss(t.float(), torch.softmax(u / 0.07, -1))
+    loss.backward()
+    s, dp = ops.soft_ce_loss(p.to(DEV), t.to(DEV), normalize)
+    close(s[0] / Rr, loss, 5e-3, 1e-3, f"soft-CE loss normalize={normalize}")
+    close(dp, pf.grad, 5e-2, 3e-2 * float(pf.grad.abs().max()), f"soft-CE grad normalize={normalize}")
+
+
+def test_softmax_rows(ops):
+    """softmax(x / 0.07) rows (siglip_encoder.py:210-211, metamorph_llama.py:372-373) and its backward."""
+    Rr, C = 23, 1152
+    x = R.l2_normalize(rnd(Rr, C, seed=7).float()).bfloat16()
+    xf = x.float().requires_grad_(True)
+    y = torch.softmax(xf / 0.07, -1)
+    dy = rnd(Rr, C, seed=8)
+    (y * dy.float()).sum().backward()
+    got = ops.softmax_rows(x.to(DEV), 0.07)
+    close(got, y, 2e-2, 1e-6, "softmax rows")
+    assert abs(float(got.float().sum(-1).mean()) - 1.0) < 5e-3
+    dx = ops.softmax_rows_bwd(got, dy.to(DEV), 0.07)
+    close(dx, xf.grad, 5e-2, 3e-2 * float(xf.grad.abs().max()), "softmax rows bwd")
 
 
 # ------------------------------------------------------------------------------------------------ splice

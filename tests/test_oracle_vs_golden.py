@@ -124,6 +124,11 @@ def test_a3_tower(Timg, tag):
 
 # ------------------------------------------------------------------ end to end
 
+def head_variant(g):
+    """normalize_vision / apply_softmax of an e2e fixture (A8: cosine, mean-abs and soft-CE heads)."""
+    return dict(normalize_vision=bool(int(g["normalize_vision"])), apply_softmax=bool(int(g["apply_softmax"])))
+
+
 def _grad_summary(t):
     f = t.detach().float().flatten()
     n = min(256, f.numel())
@@ -134,7 +139,7 @@ def _grad_summary(t):
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "e2e_*_f32.npz"))))
 def test_e2e_fp32(path):
     g = np.load(path)
-    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])))
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])), **head_variant(g))
     sd = init_state_dict(cfg, seed=int(g["seed"]))
     for k, v in sd.items():
         if "vision_tower" not in k:
@@ -167,7 +172,7 @@ def test_e2e_fp32(path):
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "e2e_*_bf16.npz"))))
 def test_e2e_bf16(path):
     g = np.load(path)
-    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])))
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])), **head_variant(g))
     sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16)
     with torch.no_grad():
         out = forward(sd, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]).bfloat16())
@@ -178,3 +183,20 @@ def test_e2e_bf16(path):
         # north_star tolerance: 1e-3 in bf16 (relative, on the loss)
         assert abs(float(out["loss"]) - ref_loss) < 1e-3 * max(1, abs(ref_loss)) * 3
     torch.testing.assert_close(out["hidden_states"].float(), T(g["hidden"]), rtol=5e-2, atol=5e-2)
+
+
+# ------------------------------------------------------------------ N1: the greedy decode loop
+
+@pytest.mark.parametrize("name", ["text", "image_prompt"])
+def test_n1_greedy_decode_matches_reference_loop(name):
+    from oracle.ref_model import decode_fixture_state_dict, greedy_decode
+    g = np.load(os.path.join(GOLDEN, f"n1_decode_{name}.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = decode_fixture_state_dict(g, cfg)
+    images = T(g["images"]) if g["images"].size else None
+    toks, pz, logits = greedy_decode(sd, cfg, T(g["input_ids"]), images, max_new_tokens=int(g["max_new_tokens"]))
+    assert toks == g["tokens"].tolist()
+    assert [int(l.argmax()) for l in logits] == g["step_argmax"].tolist()
+    torch.testing.assert_close(pz, T(g["pred_z"]), rtol=1e-4, atol=1e-6)
+    act = g["active"].tolist()
+    torch.testing.assert_close(torch.stack([l[act] for l in logits]), T(g["active_logits"]), rtol=1e-4, atol=2e-5)

@@ -1,0 +1,108 @@
+"""`MetaMorphTrainer` plumbing on CPU, world_size 2 over gloo: HF `Trainer` must NOT wrap the model in
+DistributedDataParallel (the decoder's autograd nodes write weight gradients straight into Zero2AdamW's flat buffer, a DDP reducer
+would wait for hooks that never fire), `arm_overlap()` must be called on the last micro-step of every accumulation window, clipping
+must happen inside the sharded optimizer, and two ranks must end up with the parameters one rank gets on the union of their batches.
+The model is a stand-in (the HIP kernels cannot run here); the shard arithmetic is injected from the oracle like in test_zero2_gloo."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from test_zero2_gloo import _free_port, _oracle_clip, _oracle_sumsq, _oracle_update
+
+
+class Toy(nn.Module):
+    """Two 'decoder layers' + a head; `get_model()` marks it as a model whose gradients Zero2AdamW exchanges."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.layers = nn.ModuleList([nn.Linear(8, 8), nn.Linear(8, 8)])
+        self.head = nn.Linear(8, 1)
+
+    def get_model(self):
+        return self
+
+    def forward(self, x=None, y=None):
+        h = x
+        for l in self.layers:
+            h = torch.tanh(l(h))
+        return {"loss": ((self.head(h)[:, 0] - y) ** 2).mean()}
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, n):
+        g = torch.Generator().manual_seed(5)
+        self.x, self.y = torch.randn(n, 8, generator=g), torch.randn(n, generator=g)
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return {"x": self.x[i], "y": self.y[i]}
+
+
+def _train(out_dir, per_device_bs, accum, steps):
+    from transformers import TrainingArguments
+    from metamorph_amd.trainer import MetaMorphTrainer
+    from metamorph_amd.zero2 import Zero2AdamW
+    armed = []
+
+    class SeqTrainer(MetaMorphTrainer):
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    orig = Zero2AdamW.arm_overlap
+    Zero2AdamW.arm_overlap = lambda self: (armed.append(1), orig(self))[1]
+    try:
+        args = TrainingArguments(output_dir=out_dir, per_device_train_batch_size=per_device_bs, gradient_accumulation_steps=accum,
+                                 max_steps=steps, learning_rate=1e-2, weight_decay=0.1, max_grad_norm=0.5, lr_scheduler_type="constant",
+                                 use_cpu=True, report_to=[], save_strategy="no", logging_steps=1, remove_unused_columns=False,
+                                 dataloader_num_workers=0, dataloader_pin_memory=False, seed=3)
+        model = Toy()
+        tr = SeqTrainer(model=model, args=args, train_dataset=_DS(64), zero2_kwargs=dict(
+            shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip))
+        tr.train()
+    finally:
+        Zero2AdamW.arm_overlap = orig
+    z = tr._zero2()
+    assert isinstance(z, Zero2AdamW) and z._step == steps and z.max_grad_norm == 0.5 and tr.args.max_grad_norm == 0.0
+    assert type(tr.model_wrapped) is Toy and type(tr.model) is Toy, type(tr.model_wrapped)        # no DDP wrapper
+    assert len(armed) == steps, (len(armed), steps)                                                # once per accumulation window
+    assert len(z.segs) >= 3                                                                        # layers tagged as segments
+    # weight decay groups: biases in the no-decay group
+    wd = {id(p): g["weight_decay"] for g in z.param_groups for p in g["params"]}
+    assert wd[id(model.head.bias)] == 0.0 and wd[id(model.head.weight)] == 0.1
+    return torch.cat([p.data.reshape(-1) for p in model.parameters()])
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      ACCELERATE_USE_CPU="true")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat = _train(os.path.join(tmp, f"r{rank}"), per_device_bs=2, accum=2, steps=3)
+        torch.save(flat, os.path.join(tmp, f"rank{rank}.pt"))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_no_ddp_equals_one_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(a, b)
+    # one rank, micro-batches of 4 = the union of what the two ranks saw per micro-step (accelerate hands batch 2k to rank 0 and
+    # 2k+1 to rank 1); mean loss over equal-sized halves == mean over the union
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    os.environ["ACCELERATE_USE_CPU"] = "true"
+    try:
+        one = _train(str(tmp_path / "one"), per_device_bs=4, accum=2, steps=3)
+    finally:
+        os.environ.pop("ACCELERATE_USE_CPU", None)
+    torch.testing.assert_close(a, one, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,112 @@
+"""HF `Trainer` drives the HIP model the way the reference's launch scripts do (boundary row (b)): `--gradient_checkpointing True`
+(scripts/*.sh), gradient accumulation, `MetaMorphTrainer.create_optimizer` -> sharded AdamW.  Needs an MI355X:  pytest -m gpu"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN  # noqa: E402
+from oracle.ref_model import init_state_dict  # noqa: E402
+from test_model_gpu import DEV, T, hip_model, tiny_cfg  # noqa: E402
+
+
+class _Rows(torch.utils.data.Dataset):
+    def __init__(self, g, reps):
+        ids, lab, msk = T(g["input_ids"]), T(g["labels"]), T(g["attention_mask"])
+        imgs = T(g["images"])
+        self.items = []
+        k = 0
+        for b in range(ids.shape[0]):
+            n = int(msk[b].sum())
+            n_img = max(1, int((ids[b, :n] == -200).sum()))          # a text-only sample carries its dummy image (train.py:1230-1240)
+            self.items.append(dict(input_ids=ids[b, :n].clone(), labels=lab[b, :n].clone(), image=[imgs[k + j].bfloat16() for j in range(n_img)]))
+            k += n_img
+        self.items = self.items * reps
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _collator():
+    from metamorph_amd.data import DataCollatorForSupervisedDataset
+    from oracle.fake_tokenizer import FakeTokenizer
+    return DataCollatorForSupervisedDataset(tokenizer=FakeTokenizer(model_max_length=64))
+
+
+def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path):
+    from transformers import TrainingArguments
+    from metamorph_amd.trainer import MetaMorphTrainer
+    from metamorph_amd.zero2 import Zero2AdamW, tag_segments
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    ds = _Rows(g, reps=2)                                            # 6 samples: 3 micro-batches of 2, accumulation 3 -> 1 optimizer step / epoch
+    collate = _collator()
+
+    class SeqTrainer(MetaMorphTrainer):                              # fixed sample order so the hand-written loop below sees the same batches
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, gradient_accumulation_steps=3, max_steps=2,
+                             learning_rate=1e-3, weight_decay=0.01, max_grad_norm=1.0, lr_scheduler_type="constant", bf16=True,
+                             gradient_checkpointing=True, report_to=[], save_strategy="no", logging_steps=1,
+                             remove_unused_columns=False, dataloader_num_workers=0, dataloader_pin_memory=False)
+    model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+    trainer = SeqTrainer(model=model, args=args, train_dataset=ds, data_collator=collate)
+    out = trainer.train()
+    z = trainer._zero2()
+    assert isinstance(z, Zero2AdamW) and z._step == 2
+    assert model.model.gradient_checkpointing and model.is_gradient_checkpointing    # HF's gradient_checkpointing_enable() was honoured
+    assert type(trainer.model_wrapped) is type(model)                                 # no DDP / DataParallel wrapper
+    assert np.isfinite(out.training_loss)
+    # the same two optimizer steps by hand (no checkpointing): recompute runs the same kernels on the same inputs => identical parameters
+    ref = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+    ref.train()
+    tag_segments(ref)
+    from metamorph_amd.trainer import optimizer_grouped_parameters
+    opt = Zero2AdamW(optimizer_grouped_parameters(ref, 0.01), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0)
+    for _ in range(2):
+        opt.zero_grad()
+        for mb in range(3):
+            batch = collate([ds[2 * mb], ds[2 * mb + 1]])
+            o = ref(input_ids=batch["input_ids"].to(DEV), attention_mask=batch["attention_mask"].to(DEV), labels=batch["labels"].to(DEV),
+                    images=batch["images"].to(DEV))
+            (o.loss / 3).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if p.requires_grad:
+            assert torch.equal(p.data, q.data), f"{n}: Trainer-driven (checkpointed) and hand-written steps differ by {float((p.data.float() - q.data.float()).abs().max())}"
+
+
+def test_gradient_checkpointing_recompute_is_bit_identical():
+    g = np.load(os.path.join(GOLDEN, "e2e_multi_frame_T4_ar1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    batch = dict(input_ids=T(g["input_ids"]).to(DEV), attention_mask=T(g["attention_mask"]).to(DEV), labels=T(g["labels"]).to(DEV),
+                 images=T(g["images"]).to(DEV).bfloat16())
+    grads = []
+    for ckpt in (False, True):
+        model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+        model.train()
+        tower = model.get_model().vision_tower                     # the trainable-tower layers recompute as well
+        tower.freeze_vision = False
+        for n, p in tower.named_parameters():
+            p.requires_grad_("post_layernorm" not in n)
+        if ckpt:
+            model.gradient_checkpointing_enable()
+        torch.cuda.reset_peak_memory_stats()
+        out = model(**batch)
+        out.loss.backward()
+        grads.append((float(out.loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 40
+    for n in grads[0][1]:
+        assert torch.equal(grads[0][1][n], grads[1][1][n]), n
+    # eval / no_grad never recomputes and a disabled flag restores the saved-activation path
+    model.gradient_checkpointing_disable()
+    assert not model.model.gradient_checkpointing
