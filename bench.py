@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=12, help="samples per GPU per step (each 2048 spliced tokens)")
+    ap.add_argument("--batch", type=int, default=16, help="samples per GPU per step (each 2048 spliced tokens); 16 = 222 GB of the 288 GB HBM")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--image-tokens", type=int, default=256)
     ap.add_argument("--train-vision", action="store_true", help="freeze_vision=False: the SigLIP tower trains too, own lr group (SURVEY row N4)")
@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=1, help="images per sample (8 with --seq 4096 = BASELINE configs[2], a parity-test case)")
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => NOT the headline config")
     ap.add_argument("--vit-layers", type=int, default=27)
+    ap.add_argument("--zero", type=int, default=2, choices=(2, 3), help="3: decoder-layer parameters sharded (Zero3AdamW, BASELINE configs[4] machinery); NOT the headline config")
+    ap.add_argument("--grad-checkpointing", action="store_true", help="per-layer recompute (reference --gradient_checkpointing True); NOT the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -129,47 +131,47 @@ class GemmTimer:
         return len(self.records), t, fl
 
 
-def cpu_baseline(args):
-    """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: LLaMA-3-8B / SO400M
-    layer geometry, 1 of 32 decoder layers, 1 of 27 tower layers, full 128258-entry lm_head, one 512-token sample
-    (256 image + 256 text rows), fp32, forward+backward with the stage-2 freeze policy; per-stage times are scaled to
-    the full depth to quote tokens/s."""
-    import numpy as np
-    from oracle.ref_model import OracleConfig, init_state_dict
-    from oracle import ref_model as RM, ref_ops as R
+def _cpu_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 32))                 # more threads than that only adds contention for this size
+    return max(1, min(avail, 64))
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: ONE sample built like the bench's
+    (one 256-token image + text, labels as in make_batch) cut to 1024 spliced tokens, LLaMA-3-8B / SO400M layer geometry with 1 of 32 decoder
+    layers and 1 of 27 tower layers actually run plus the full 128258-entry lm_head and both loss heads, fp32, forward+backward with
+    the stage-2 freeze policy; per-stage times are scaled to the full depth to quote tokens/s."""
+    from oracle.ref_model import OracleConfig, init_state_dict
+    from oracle import ref_model as RM, ref_ops as R
+    threads = _cpu_threads()
     torch.set_num_threads(threads)
     NL = 1                                           # decoder / tower layers actually run (scaled to 32 / 27 below)
-    cfg = OracleConfig(num_hidden_layers=NL, v_layers=NL, num_image_tokens=256, tokenizer_model_max_length=4096)
-    sd = init_state_dict(cfg, seed=1)
+    cfg = OracleConfig(num_hidden_layers=NL, v_layers=NL, num_image_tokens=args.image_tokens, tokenizer_model_max_length=4096)
+    sd = init_state_dict(cfg, seed=1, fast_big=True)
     for k, v in sd.items():
         if "vision_tower" not in k and "vision_proj" not in k:
             v.requires_grad_(True)
-    L = 512
-    n_ids = L - 256 + 1
-    g = torch.Generator().manual_seed(0)
-    ids = torch.randint(0, 127999, (1, n_ids), generator=g)
-    ids[0, :2] = 128000
-    ids[0, 22], ids[0, 23], ids[0, 24] = 128256, -200, 128257
-    labels = ids.clone()
-    labels[0, :20] = -100
-    images = torch.randn(1, 3, 384, 384, generator=g)
+    L = min(args.seq, 1024)                          # bounded: 256 image + 768 text rows (the workload's samples are 2048 rows)
+    ids, labels, mask, images = make_batch(1, L, args.image_tokens, "cpu", seed=0, frames=1, all_generation=True)
+    images = images.float()
     t0 = time.time()
     with torch.no_grad():
         feat = RM.vision_features(sd, cfg, images)
     t_vit = time.time() - t0
     t0 = time.time()
     proj = RM.mm_projector(sd, cfg, feat)
-    x, lab, valid, pos, tgt, _ = RM.splice(sd, cfg, ids, labels, torch.ones_like(ids, dtype=torch.bool), proj, feat)
+    x, lab, valid, pos, tgt, _ = RM.splice(sd, cfg, ids, labels, mask, proj, feat)
     hid = RM.llama_decoder(sd, cfg, x, valid)
     t_dec_f = time.time() - t0
     t0 = time.time()
-    logits = R.linear(hid, sd["lm_head.weight"]).float()
-    ce = R.shifted_cross_entropy(logits, lab)
+    nxt = torch.full_like(lab, -100)
+    nxt[:, :-1] = lab[:, 1:]
+    keep = nxt != -100
+    lg = R.linear(hid[keep], sd["lm_head.weight"]).float()
+    ce = (torch.logsumexp(lg, -1) - lg.gather(1, nxt[keep][:, None])[:, 0]).sum() / keep.sum()
     pred = R.l2_normalize(RM.vision_head(sd, cfg, hid[:, :-1][pos[:, 1:].bool()]))
     loss = ce + R.cosine_loss(tgt.reshape(-1, tgt.shape[-1]), pred)
     t_head_f = time.time() - t0
@@ -182,10 +184,80 @@ def cpu_baseline(args):
     t_head = t_head_f + t_bwd * (1 - frac_dec)
     full = t_dec * (32 / NL) + t_head + t_vit * (27 / NL)
     return {"value": round(L / full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens (256 image + 256 text), LLaMA-3-8B + SO400M layer "
-                       f"geometry with {NL}/32 decoder and {NL}/27 tower layers + full lm_head; measured {t_dec:.2f}s ({NL} dec layer) "
-                       f"{t_head:.2f}s (heads) {t_vit:.2f}s ({NL} tower layer), scaled to full depth = {full:.1f}s per {L} tokens"),
+            "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens ({args.image_tokens} image + {L - args.image_tokens} text; "
+                       f"{int(keep.sum())} CE rows, {args.image_tokens} regression rows), LLaMA-3-8B + SO400M layer geometry with {NL}/32 decoder and "
+                       f"{NL}/27 tower layers + full lm_head; measured {t_dec:.2f}s ({NL} dec layer) {t_head:.2f}s (heads) {t_vit:.2f}s "
+                       f"({NL} tower layer), scaled to full depth = {full:.1f}s per {L} tokens"),
             "measured_seconds": round(t_dec + t_head + t_vit, 2)}
+
+
+def cpu_baseline_c1(budget_s=40.0):
+    """BASELINE configs[0] / BASELINE.md section 3 as planned: TinyLlama-1.1B geometry (22 layers, h 2048, 32/4 heads, I 5632, V 32002)
+    + SigLIP-SO400M/14-384 (27 layers), 1 prompt image -> 256 tokens + 128 text ids (spliced L = 383), B = 1, stage-1 freeze policy
+    (only mm_projector + embed_tokens train, reference train.py:1515-1519), the FULL model, directly timed forward+backward on the host
+    cores: fp32 (1 warm-up + 1 timed step) and bf16 (1 step, skipped when a probe GEMM shows the host has no fast bf16 path)."""
+    from oracle.ref_model import OracleConfig, forward, init_state_dict
+    threads = _cpu_threads()
+    torch.set_num_threads(threads)
+    cfg = OracleConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=22, num_attention_heads=32, num_key_value_heads=4,
+                       vocab_size=32002, rope_theta=10000.0, num_image_tokens=256, tokenizer_model_max_length=2048, image_start_id=32000,
+                       use_vision_ar=False)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, 31999, (1, 129), generator=g)
+    ids[0, 0] = 1
+    ids[0, 21], ids[0, 22], ids[0, 23] = 32000, -200, 32001
+    labels = torch.full_like(ids, -100)
+    labels[0, -64:] = ids[0, -64:]
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    images = torch.randn(1, 3, 384, 384, generator=g)
+    out = {"workload": "BASELINE configs[0]: TinyLlama-1.1B + SigLIP-SO400M/14-384 geometry, 1 image (256 tok) + 128 text, B=1, L=383, "
+                       "stage-1 freeze (mm_projector + embed_tokens trainable), oracle/ref_model.py forward+backward, directly timed",
+           "cores": threads, "unit": "tokens/s", "kind": "port"}
+    t_all = time.time()
+    sd32 = init_state_dict(cfg, seed=2, fast_big=True)
+    for dt, tag, warm, n in ((torch.float32, "fp32", 1, 1), (torch.bfloat16, "bf16", 0, 1)):
+        if tag == "bf16":                                  # probe: one bf16 GEMM of the MLP shape; hosts without fast bf16 GEMMs skip
+            a, b = torch.randn(383, 2048).to(dt), torch.randn(5632, 2048).to(dt)
+            torch.nn.functional.linear(a, b)
+            t0 = time.time()
+            torch.nn.functional.linear(a, b)
+            probe = time.time() - t0
+            fp32_probe = out["fp32"]["step_seconds"]
+            if probe * 22 * 3 * 3 * 4 > 3 * fp32_probe or time.time() - t_all > budget_s:
+                out["bf16"] = {"skipped": f"bf16 GEMM probe {probe * 1e3:.0f} ms (383x2048x5632): a bf16 step would take several times the fp32 "
+                                          f"step ({fp32_probe:.1f}s) on this host / time budget {budget_s:.0f}s"}
+                break
+        sd = {k: v.to(dt) for k, v in sd32.items()} if dt != torch.float32 else sd32
+        for k, v in sd.items():
+            v.requires_grad_("mm_projector" in k or "embed_tokens" in k)
+        ts = []
+        for i in range(warm + n):
+            for v in sd.values():
+                v.grad = None
+            t0 = time.time()
+            r = forward(sd, cfg, ids, mask, labels, images.to(dt), return_logits=False, ce_rows_only=True)
+            r["loss"].backward()
+            if i >= warm:
+                ts.append(time.time() - t0)
+        step = sum(ts) / len(ts)
+        out[tag] = {"step_seconds": round(step, 3), "value": round(383 / step, 2), "steps_timed": n, "loss": round(float(r["loss"].detach()), 4)}
+    return out
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
 
 
 def main():
@@ -195,9 +267,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU over RCCL), exactly the command line the
+        # docstring gives; rank 0 of the child job prints the ONE JSON line on this process's stdout
+        return self_launch(args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # MM355_BENCH_FORCE_DIST=1 (+ MM355_ZERO2_FORCE_COLLECTIVES=1): drive the RCCL call pattern with a single rank under torchrun
@@ -241,7 +314,13 @@ def main():
     if args.train_vision:
         vis = {id(p) for p in model.get_model().vision_tower.parameters()}
         params = [dict(params=[p for p in params if id(p) not in vis], lr=2e-5), dict(params=[p for p in params if id(p) in vis], lr=2e-6)]
-    opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
+    if args.grad_checkpointing:
+        model.gradient_checkpointing_enable()
+    if args.zero == 3:
+        from metamorph_amd.zero3 import Zero3AdamW
+        opt = Zero3AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_hooks()
+    else:
+        opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
     ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank, frames=args.frames, all_generation=args.all_generation)
@@ -318,15 +397,17 @@ def main():
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
-                       "parallelism": f"dp{world} zero2", "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
+                       "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
             "loss": round(loss_val, 4), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }
         if roofline:
             rec["roofline"] = roofline
+        rec["rccl_ranks"] = dist.get_world_size() if (world > 1 or force_dist) else 1
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
+            rec["cpu_baseline_c1"] = cpu_baseline_c1()
         print(json.dumps(rec), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

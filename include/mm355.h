@@ -113,6 +113,12 @@ int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf1
                       const mm355_bf16* dres, mm355_bf16* dx, float* dw_f32, float* workspace,
                       int64_t M, int64_t h, float eps, void* stream);
 int64_t mm355_rmsnorm_bwd_ws_floats(int64_t M, int64_t h);
+/* the same with the weight gradient landing straight in the parameter's bf16 gradient buffer (training hot path: no fp32
+ * scratch to zero, no separate accumulate pass): w_grad[h] = (accumulate ? w_grad : 0) + sum_m dy*xhat, fixed summation order;
+ * workspace (mm355_rmsnorm_bwd_ws_floats floats) is required. */
+int mm355_rmsnorm_bwd_wgrad(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres,
+                            mm355_bf16* dx, mm355_bf16* w_grad, int accumulate, float* workspace,
+                            int64_t M, int64_t h, float eps, void* stream);
 
 /* LayerNorm forward (SigLIP encoder, eps 1e-6); the tower is frozen in every shipped recipe. */
 int mm355_layernorm_fwd(const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* b, mm355_bf16* y,
@@ -162,6 +168,9 @@ int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v
                    mm355_bf16* dq, int64_t ld_dq, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
                    int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
                    float* workspace, void* stream);
+
+/* floats of `workspace` mm355_attn_bwd needs for this geometry (ld_max = largest of ld_q / ld_k / ld_o); 0 when none is needed */
+int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, int64_t ld_max);
 
 /* f32 [rows][cols] -> bf16 column block (generic helper). */
 int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int64_t ld_out,

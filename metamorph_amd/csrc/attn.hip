@@ -87,6 +87,11 @@ extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, i
     return mm_launch_status();
 }
 
+extern "C" int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, int64_t ld_max) {
+    if (Hq == Hkv || fast128(d, ld_max)) return 0;           // no GQA, or the d == 128 kernels (group summed in registers)
+    return 2 * B * L * Hq * d;
+}
+
 extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
                               int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
                               mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,

@@ -556,6 +556,33 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __r
     }
 }
 
+// The same fixed-order sum, landing straight in a bf16 gradient buffer: grad = (accumulate ? grad : 0) + sum  (one rounding).
+__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_bf16_kernel(const float* __restrict__ ws, uint16_t* __restrict__ grad, int G, int h, int ld,
+                                                                     int accumulate) {
+    __shared__ f32x4 part[32][8];
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * DWR_COLS + cq * 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < h) {
+        const float* p = ws + c;
+        int g = rl;
+        for (; g + 32 < G; g += 64) {
+            acc0 += *(const f32x4*)(p + (int64_t)g * ld);
+            acc1 += *(const f32x4*)(p + (int64_t)(g + 32) * ld);
+        }
+        if (g < G) acc0 += *(const f32x4*)(p + (int64_t)g * ld);
+    }
+    part[rl][cq] = acc0 + acc1;
+    __syncthreads();
+    if (rl == 0 && c < h) {
+        f32x4 s = part[0][cq];
+#pragma unroll
+        for (int r = 1; r < 32; ++r) s += part[r][cq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) grad[c + e] = f2bf(s[e] + (accumulate ? bf2f(grad[c + e]) : 0.f));
+    }
+}
+
 static int rmsnorm_bwd_rows_per_block(int64_t M, bool two_stage) {
     if (two_stage) return M >= 8192 ? 32 : (M >= 1024 ? 8 : 1);
     return M >= 8192 ? 16 : (M >= 1024 ? 4 : 1);
@@ -583,6 +610,23 @@ extern "C" int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, cons
     if (rc != MM355_OK || !two_stage) return rc;
     hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((unsigned)((h + DWR_COLS - 1) / DWR_COLS)), dim3(256), 0, (hipStream_t)stream, workspace, dw_f32,
                        (int)grid, (int)h, (int)h);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_rmsnorm_bwd_wgrad(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w, const mm355_bf16* dres, mm355_bf16* dx,
+                                       mm355_bf16* w_grad, int accumulate, float* workspace, int64_t M, int64_t h, float eps, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!dy || !x || !w || !dx || !w_grad || !workspace || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff || !mm_aligned16(workspace)) return MM355_EINVAL;
+    const int rpb = rmsnorm_bwd_rows_per_block(M, true);
+    const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+    int rc = dispatch_vpt((int)h, [&](auto vpt) {
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<decltype(vpt)::value>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, x, w, dres, dx,
+                           (float*)nullptr, workspace, (int)M, (int)h, eps, rpb);
+        return mm_launch_status();
+    });
+    if (rc != MM355_OK) return rc;
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_bf16_kernel, dim3((unsigned)((h + DWR_COLS - 1) / DWR_COLS)), dim3(256), 0, (hipStream_t)stream, workspace,
+                       w_grad, (int)grid, (int)h, (int)h, accumulate);
     return mm_launch_status();
 }
 

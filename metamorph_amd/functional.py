@@ -105,9 +105,11 @@ def set_param_ready_hook(fn):
     _PARAM_READY_HOOK = fn
 
 
-def params_ready(key=None):
+def params_ready(key=None, backward=False):
+    """key = the decoder layer module about to be read (None: everything outside the decoder layers); backward=True when the
+    reader is that layer's backward pass (Zero3AdamW then also attaches the layer's gradient slot)."""
     if _PARAM_READY_HOOK is not None:
-        _PARAM_READY_HOOK(key)
+        _PARAM_READY_HOOK(key, backward)
 
 
 def grad_target(p):
@@ -173,10 +175,9 @@ def transpose_padded(x2d):
     """x [R, C] -> [C, Rp] with Rp = R rounded up to 8 and zero padding columns (a legal GEMM K dimension)."""
     R, C = x2d.shape
     Rp = (R + 7) // 8 * 8
-    if Rp == R:
-        buf = torch.empty((C, Rp), device=x2d.device, dtype=BF16)
-    else:
-        buf = torch.zeros((C, Rp), device=x2d.device, dtype=BF16)
+    buf = torch.empty((C, Rp), device=x2d.device, dtype=BF16)
+    if Rp != R:
+        buf[:, R:].zero_()                                    # only the (< 8) padding columns
     ops.transpose(x2d, out=buf[:, :R])
     return buf
 
@@ -255,6 +256,16 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     return y, (qkv, o, lse, x2, gu)
 
 
+def _rmsnorm_backward(dn, x, w, eps, dres):
+    """dres + d rmsnorm / dx; the weight gradient (if trained) lands in the parameter's gradient buffer in the same launch pair."""
+    if not w.requires_grad:
+        return ops.rmsnorm_bwd(dn, x, w, eps, dres=dres, dw_f32=None)
+    buf, acc = grad_target(w)
+    dx = ops.rmsnorm_bwd_wgrad(dn, x, w, eps, buf, acc, dres=dres)
+    commit_grad(w, buf)
+    return dx
+
+
 class DecoderLayerFn(Function):
     @staticmethod
     def forward(ctx, x, layer, meta, *weights):
@@ -270,6 +281,7 @@ class DecoderLayerFn(Function):
     @staticmethod
     def backward(ctx, dy):
         layer, m = ctx.layer, ctx.meta
+        params_ready(layer, backward=True)                                     # sharded parameters (ZeRO-3): gather before use
         if len(ctx.saved_tensors) == 1:                                        # checkpointed: same kernels, same inputs => same bits
             (x,) = ctx.saved_tensors
             _, (qkv, o, lse, x2, gu) = decoder_layer_forward(x, layer, m)
@@ -315,14 +327,8 @@ class DecoderLayerFn(Function):
             commit_fused_grad(gu_params, fb, acc, bufs)
             del n2
         del dgu, dguT
-        ln2 = layer.post_attention_layernorm.weight
-        dw2 = torch.zeros(h, device=dev, dtype=torch.float32) if ln2.requires_grad else None
-        dx2 = ops.rmsnorm_bwd(dn2, x2, ln2, m.eps, dres=dy, dw_f32=dw2)        # dy + d rmsnorm
+        dx2 = _rmsnorm_backward(dn2, x2, layer.post_attention_layernorm.weight, m.eps, dy)     # dy + d rmsnorm
         del dn2
-        if dw2 is not None:
-            buf, acc = grad_target(ln2)
-            ops.axpy_(buf, dw2, None, 1.0, acc)
-            commit_grad(ln2, buf)
 
         # ---- attention ----
         do = input_grad_gemm(dx2, att.o_proj.weight)                            # [M, Hq*d]
@@ -354,13 +360,7 @@ class DecoderLayerFn(Function):
             commit_fused_grad(qkv_params, fb, acc, bufs)
             del n1
         del dqkv
-        ln1 = layer.input_layernorm.weight
-        dw1 = torch.zeros(h, device=dev, dtype=torch.float32) if ln1.requires_grad else None
-        dx = ops.rmsnorm_bwd(dn1, x, ln1, m.eps, dres=dx2, dw_f32=dw1)
-        if dw1 is not None:
-            buf, acc = grad_target(ln1)
-            ops.axpy_(buf, dw1, None, 1.0, acc)
-            commit_grad(ln1, buf)
+        dx = _rmsnorm_backward(dn1, x, layer.input_layernorm.weight, m.eps, dx2)
         if _LAYER_GRAD_HOOK is not None:                                       # every gradient of this layer is final now
             _LAYER_GRAD_HOOK(layer)
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -880,7 +880,9 @@ class LinearCrossEntropyFn(Function):
         dhc = torch.empty_like(hc) if need_dh else None
         wt = None
         if need_dh:
-            wt = torch.zeros((h, Vp), device=dev, dtype=BF16) if Vp != V else torch.empty((h, Vp), device=dev, dtype=BF16)
+            wt = torch.empty((h, Vp), device=dev, dtype=BF16)
+            if Vp != V:
+                wt[:, V:].zero_()                             # only the padding columns (K tail of the dX GEMM)
             ops.transpose(weight, out=wt[:, :V])
         # chunks accumulate in fp32 (a bf16 running sum would lose the small chunks once n_valid >> CE_CHUNK); rounded once in backward
         dw = torch.empty((V, h), device=dev, dtype=BF16 if n_valid <= CE_CHUNK else torch.float32) if need_dw else None

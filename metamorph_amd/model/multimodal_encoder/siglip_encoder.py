@@ -138,7 +138,8 @@ class HipSiglipVisionTransformer(nn.Module):
         from ...functional import param_generation
         # (pointer, torch version) catches re-loads and in-place torch updates; the generation counter catches optimizer steps that
         # write parameters through raw pointers (a trainable tower under Zero2AdamW: eval / generation after training steps)
-        sig = (param_generation(),) + tuple((s.data_ptr(), s._version) for s in srcs)
+        gen = param_generation() if any(s.requires_grad for s in srcs) else 0      # a frozen tower is never touched by the optimizer
+        sig = (gen,) + tuple((s.data_ptr(), s._version) for s in srcs)
         hit = self._cache.get(key)
         if hit is None or hit[0] != sig:
             hit = (sig, build())
@@ -162,6 +163,26 @@ class HipSiglipVisionTransformer(nn.Module):
         bs = [a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]
         return self._cached(("qkv", j), ws + bs, lambda: (torch.cat([w.data for w in ws], 0).contiguous(),
                                                          torch.cat([b.data for b in bs], 0).contiguous()))
+
+    def _mlp_padded(self, j):
+        """fc1 / fc2 operands of layer j with the intermediate width rounded up to whole 128-wide K tiles (SO400M: 4304 -> 4352) so
+        that both GEMMs run on the LDS-DMA kernels instead of the register-staged fallback for ragged K: fc1 gains zero rows and
+        zero bias entries (tanh-GELU(0) = 0), fc2 zero columns -- the product is unchanged bit for bit (adding exact zeros)."""
+        m = self.encoder.layers[j].mlp
+        iv = m.fc1.weight.shape[0]
+        ivp = (iv + 127) // 128 * 128
+        if ivp == iv:
+            return m.fc1.weight.data, m.fc1.bias.data, m.fc2.weight.data
+
+        def build():
+            w1 = torch.zeros((ivp, m.fc1.weight.shape[1]), device=m.fc1.weight.device, dtype=BF16)
+            w1[:iv].copy_(m.fc1.weight.data)
+            b1 = torch.zeros((ivp,), device=w1.device, dtype=BF16)
+            b1[:iv].copy_(m.fc1.bias.data)
+            w2 = torch.zeros((m.fc2.weight.shape[0], ivp), device=w1.device, dtype=BF16)
+            w2[:, :iv].copy_(m.fc2.weight.data)
+            return w1, b1, w2
+        return self._cached(("mlp", j), [m.fc1.weight, m.fc1.bias, m.fc2.weight], build)
 
     @torch.no_grad()
     def forward_features(self, images, select_layer=-1):
@@ -196,8 +217,9 @@ class HipSiglipVisionTransformer(nn.Module):
             a = layer.self_attn
             x = ops.gemm(o, a.out_proj.weight.data, bias=a.out_proj.bias.data, residual=x)
             h2 = layer.layer_norm2(x)
-            f = ops.gemm(h2, layer.mlp.fc1.weight.data, bias=layer.mlp.fc1.bias.data, gelu="tanh")
-            x = ops.gemm(f, layer.mlp.fc2.weight.data, bias=layer.mlp.fc2.bias.data, residual=x)
+            w1, b1, w2 = self._mlp_padded(j)
+            f = ops.gemm(h2, w1, bias=b1, gelu="tanh")
+            x = ops.gemm(f, w2, bias=layer.mlp.fc2.bias.data, residual=x)
         return x.view(N, P, hv)
 
     def forward_features_train(self, images, select_layer=-1):

@@ -261,6 +261,19 @@ def rmsnorm_bwd(dy, x, w, eps, dres=None, dw_f32=None, dx=None, atomic=False):
     return dx
 
 
+def rmsnorm_bwd_wgrad(dy, x, w, eps, w_grad, accumulate, dres=None, dx=None):
+    """dx as rmsnorm_bwd; the weight gradient goes straight into the bf16 buffer `w_grad` ((+)= when accumulate)."""
+    _chk_dev(dy, x, w, w_grad)
+    assert dy.is_contiguous() and x.is_contiguous() and w_grad.is_contiguous() and w_grad.dtype == BF16
+    h = x.shape[-1]
+    M = x.numel() // h
+    dx = torch.empty_like(x) if dx is None else dx
+    ws = torch.empty(int(_L().mm355_rmsnorm_bwd_ws_floats(M, h)), dtype=torch.float32, device=x.device)
+    _lib.check(_L().mm355_rmsnorm_bwd_wgrad(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(dres), dx.data_ptr(), w_grad.data_ptr(), int(bool(accumulate)),
+                                            ws.data_ptr(), M, h, eps, _stream()), "mm355_rmsnorm_bwd_wgrad")
+    return dx
+
+
 def layernorm_fwd(x, w, b, eps, out=None):
     _chk_dev(x, w, b)
     assert x.is_contiguous()
@@ -330,7 +343,8 @@ def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlen
     delta = torch.empty((B, Hq, L), device=o.device, dtype=torch.float32)
     _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), B, L, Hq, d, _stream()),
                "mm355_attn_bwd_prep")
-    ws = torch.empty((2, M, Hq * d), device=o.device, dtype=torch.float32) if Hq != Hkv else None
+    n_ws = int(_L().mm355_attn_bwd_ws_floats(B, L, Hq, Hkv, d, max(ldq, ldk, d_o.stride(0))))
+    ws = torch.empty(n_ws, device=o.device, dtype=torch.float32) if n_ws else None     # generic-d GQA only; d = 128 sums in registers
     pdq, _, _, lddq = _rows2d(dq2d)
     pdk, _, _, lddk = _rows2d(dk2d)
     pdv, _, _, lddv = _rows2d(dv2d)

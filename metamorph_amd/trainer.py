@@ -22,6 +22,7 @@ from transformers import Trainer
 
 from .checkpoint import save_trainer_adapter_checkpoint
 from .zero2 import Zero2AdamW, tag_segments
+from .zero3 import Zero3AdamW
 
 
 def _decay_parameter_names(model):
@@ -62,7 +63,11 @@ def optimizer_grouped_parameters(model, weight_decay, mm_projector_lr=None, visi
 class MetaMorphTrainer(Trainer):
     """Drop-in for the reference's `MetaMorphTrainer`; `zero2_kwargs` are forwarded to `Zero2AdamW` (tests inject CPU shard kernels)."""
 
-    def __init__(self, *args, zero2_kwargs=None, **kwargs):
+    def __init__(self, *args, zero2_kwargs=None, zero_stage=2, **kwargs):
+        # zero_stage: 2 = Zero2AdamW (reference scripts/zero2.json), 3 = Zero3AdamW (scripts/zero3.json: decoder-layer parameters sharded)
+        if zero_stage not in (2, 3):
+            raise ValueError("zero_stage must be 2 or 3")
+        self._zero_stage = zero_stage
         self._zero2_kwargs = dict(zero2_kwargs or {})
         self._mm_max_grad_norm = None
         super().__init__(*args, **kwargs)
@@ -94,14 +99,15 @@ class MetaMorphTrainer(Trainer):
         tag_segments(self.model)                                     # one reduce-scatter segment per decoder layer
         groups = optimizer_grouped_parameters(self.model, a.weight_decay, getattr(a, "mm_projector_lr", None), getattr(a, "vision_lr", None))
         max_norm = self._mm_max_grad_norm if self._mm_max_grad_norm is not None else a.max_grad_norm
-        self.optimizer = Zero2AdamW(groups, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
-                                    weight_decay=a.weight_decay, max_grad_norm=max_norm or 0.0, **self._zero2_kwargs)
+        cls = Zero3AdamW if self._zero_stage == 3 else Zero2AdamW
+        self.optimizer = cls(groups, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
+                             weight_decay=a.weight_decay, max_grad_norm=max_norm or 0.0, **self._zero2_kwargs)
         self.optimizer.enable_overlap()
         return self.optimizer
 
     def _zero2(self):
         opt = self.optimizer
-        while opt is not None and not isinstance(opt, Zero2AdamW):
+        while opt is not None and not isinstance(opt, (Zero2AdamW, Zero3AdamW)):
             opt = getattr(opt, "optimizer", None)                    # accelerate's AcceleratedOptimizer wrapper
         return opt
 

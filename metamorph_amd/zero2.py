@@ -324,7 +324,7 @@ class Zero2AdamW(torch.optim.Optimizer):
     def enable_async_wait(self):
         """Route the model's "about to read these parameters" announcements (functional.params_ready) to wait_segment."""
         from . import functional as F
-        F.set_param_ready_hook(lambda layer: self.wait_segment(None if layer is None else getattr(layer, "_mm_segment", None)))
+        F.set_param_ready_hook(lambda layer, backward=False: self.wait_segment(None if layer is None else getattr(layer, "_mm_segment", None)))
         self._async_hooked = True
         return self
 

@@ -173,17 +173,26 @@ def splice(sd, cfg: OracleConfig, input_ids, labels, attention_mask, proj_feat, 
     emb = sd["model.embed_tokens.weight"]
     B, L = len(plan["src"]), len(plan["src"][0])
     h = emb.shape[1]
-    rows = []
-    zero = torch.zeros(h, dtype=proj_feat.dtype)
+    # row sources as the bookkeeping lists them: None = padding (zeros), (img, i, t) = row t of image i, int = token id.
+    # Assembled with two gathers (one autograd node each) instead of one select per row: the backward of a per-row `emb[s]` allocates
+    # a full [V, h] zero tensor PER ROW, minutes at V = 128258 -- same values, same gradients.
+    tok_pos, tok_ids, img_pos, img_rows = [], [], [], []
     for b in range(B):
-        for s in plan["src"][b]:
+        for l, s in enumerate(plan["src"][b]):
             if s is None:
-                rows.append(zero)
-            elif isinstance(s, tuple):
-                rows.append(proj_feat[s[1], s[2]])
+                continue
+            if isinstance(s, tuple):
+                img_pos.append(b * L + l)
+                img_rows.append(s[1] * T + s[2])
             else:
-                rows.append(emb[s].to(proj_feat.dtype))
-    x = torch.stack(rows).view(B, L, h)
+                tok_pos.append(b * L + l)
+                tok_ids.append(s)
+    x = torch.zeros(B * L, h, dtype=proj_feat.dtype)
+    if tok_pos:
+        x = x.index_put((torch.tensor(tok_pos),), emb[torch.tensor(tok_ids)].to(proj_feat.dtype))
+    if img_pos:
+        x = x.index_put((torch.tensor(img_pos),), proj_feat.reshape(N * T, h)[torch.tensor(img_rows)])
+    x = x.view(B, L, h)
     out_labels = torch.tensor(plan["labels"], dtype=torch.long) if plan["labels"] is not None else None
     return (x, out_labels, torch.tensor(plan["attention_mask"], dtype=torch.bool),
             torch.tensor(plan["image_positions"], dtype=torch.long),
@@ -326,7 +335,7 @@ def decode_fixture_state_dict(g, cfg: OracleConfig, dtype=torch.float32):
 def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: float = 0.02,
                     with_vision=True, fast_big=False):
     """Deterministic N(0, std) weights (numpy PCG64 so the stream is platform independent);
-    norm weights 1 + N(0, 0.1) so that their gradients are exercised.  fast_big=True draws tensors of more than 2^24 elements
+    norm weights 1 + N(0, 0.1) so that their gradients are exercised.  fast_big=True draws tensors of more than 2^20 elements
     from torch's multi-threaded generator instead (full-width test cases: ~1.5 G values; the device model and the oracle
     are built from the same dict in the same process, so platform independence is not needed there)."""
     import numpy as np
@@ -338,7 +347,7 @@ def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: floa
         n = 1
         for d in shape:
             n *= d
-        if fast_big and n > (1 << 24):
+        if fast_big and n > (1 << 20):
             return (torch.randn(*shape, generator=tg, dtype=torch.float32) * s).to(dtype)
         return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * s).to(dtype)
 
