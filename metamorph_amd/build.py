@@ -10,9 +10,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "decode.hip", "losses.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-         "-Wno-unused-result"]
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn3_wide.hip", "decode.hip", "losses.hip"]
+HEADERS = ["mm355_common.h", "attn2.h", "attn3_kernels.h"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD) everywhere except the one-wave-per-SIMD kernels of
+# attn3_wide.hip, which need the accumulator half of the unified 512-entry file
+FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FLAGS_OF = {"attn3_wide.hip": BASE_FLAGS}
 
 
 def _hipcc():
@@ -24,7 +28,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + ["mm355_common.h", "attn2.h"]:
+    for f in SOURCES + HEADERS:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(os.path.dirname(PKG), "include", "mm355.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
@@ -42,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS_OF.get(src, FLAGS), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[mm355 build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

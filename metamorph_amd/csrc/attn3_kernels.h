@@ -1,0 +1,395 @@
+// Kernel templates of the d == 128 attention path shared by attn3.hip (RQ = 2: two waves per SIMD) and attn3_wide.hip (RQ = 4: one wave
+// per SIMD with the whole 512-register file; that translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form so that the accumulators
+// can live in AGPRs).
+#pragma once
+// Attention, d == 128 fast path (gfx950): the formulation of attn2.hip (swapped products on natural [rows][128] tiles, P^T / dS^T
+// never leave registers) with the staging rebuilt around the LDS-DMA engine:
+//   * K / V tiles of 64 keys go HBM -> LDS with global_load_lds_dwordx4 (1 KiB = 4 tile rows per wave instruction; the XOR
+//     swizzle is applied on the per-lane SOURCE address, the LDS side is lane-linear) into a two-deep ring, so a tile costs
+//     no VGPRs, no ds_write and ONE barrier; tile t+1 is in flight while tile t is consumed
+//   * a wave owns 32 query rows (two 16-column fragments) and re-uses every K / V fragment read for both
+//   * the row maximum is all-reduced on the VALU (v_permlane16/32_swap); row sums stay per lane until the epilogue
+//   * heavy (late) causal query blocks are launched first
+// Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
+#include "attn2.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace attn3 {
+using namespace attn2;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int DP = 128;
+constexpr int DS = 128;
+constexpr int TILE = 64 * DS * 2;                            // 16 KiB: [64 rows][128] bf16
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float M_INIT = -1.0e30f;                           // finite "minus infinity" of the running maximum (log2 domain)
+
+// per-lane source byte offsets of the four 1-KiB pieces a wave moves per tile: piece p = wave*4 + i covers tile rows 4p..4p+3
+struct TileSrc {
+    uint32_t off[4];
+    MM_DEV void init(int wave, int lane, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swzN<DS>(row);       // logical chunk that belongs in physical slot (lane & 15)
+            off[i] = (uint32_t)(row * ld * 2 + c * 16);
+        }
+    }
+};
+
+// tile rows [row0, row0 + 64) of a [L][ld] matrix -> LDS tile `dst` (this wave's four pieces)
+MM_DEV void dma_tile(const uint16_t* base, int64_t ld, int row0, int L, const TileSrc& ts, unsigned char* dst, int wave_s, int lane) {
+    unsigned char* d0 = dst + wave_s * 4096;
+    if (row0 + 64 <= L) {
+        const unsigned char* tb = (const unsigned char*)(base + (int64_t)row0 * ld);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(tb + ts.off[i]), (lptr_t)(d0 + i * 1024), 16, 0, 0);
+    } else {                                                 // ragged last tile: clamp the rows (masked by the caller)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave_s * 4 + i) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swzN<DS>(row);
+            const uint16_t* src = base + (int64_t)min(row0 + row, L - 1) * ld + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d0 + i * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// 1-D grid -> (x, head, sample) with all blocks that share K / V (fwd, dQ: the query blocks of a GQA group) or Q / dO (dK/dV:
+// the key blocks of a query head) on ONE XCD, so the shared tiles stay in that XCD's 4-MiB L2: hardware deals consecutive
+// block ids round-robin over the 8 XCDs, so XCD x is given the x-th contiguous eighth of the logical order
+// (x fastest, then head, then sample).  `reverse` walks x downwards: causal work grows with the query block index (fwd, dQ)
+// and shrinks with the key block index (dK/dV); the heavy blocks go first either way.
+MM_DEV void block_coords(int nx, int Hq, bool reverse, int& x, int& hq, int& b) {
+    const int total = gridDim.x, bid = blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    x = reverse ? nx - 1 - logical % nx : logical % nx;
+    const int rest = logical / nx;
+    hq = rest % Hq;
+    b = rest / Hq;
+}
+
+// ================================================================================================
+// forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
+// ================================================================================================
+template <int RQ>
+__global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
+    // RQ 16-row groups per wave: RQ = 2 -> 32 query rows per wave, two workgroups per CU (two waves per SIMD) -- the default;
+    // RQ = 4 -> 64 rows per wave, ONE wave per SIMD with the whole register file: every K / V fragment read serves four MFMAs
+    // instead of two, half the LDS traffic per flop (the tr_b64 gathers cost ~7.5 LDS cycles each: tools/probes/lds_pattern_probe).
+    // Measured (B = 12, L = 2048, 32/8 heads): RQ = 4 is SLOWER, 1.06 vs 0.69 ms forward and +0.5 ms in dQ -- with one wave per SIMD
+    // nothing overlaps the softmax VALU phase with the MFMA phases, and a compiler-scheduled in-wave pipeline (S(h+1) || softmax(h) ||
+    // PV(h-1) in one basic block) was slower still (1.34 ms: ~1 300 accumulator<->VGPR moves).  Kept as an opt-in A/B (MM355_ATTN_RQ=4).
+    constexpr int KS = 4, NF = 8, ROWS = 16 * RQ, BQ = 4 * ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    int xb, hq, b;
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
+    const int q0 = xb * BQ;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    uint16_t* o_base = a.o + row_base * a.ld_o + (int64_t)hq * DP;
+    float* lse_base = a.lse + ((int64_t)b * a.Hq + hq) * L;
+
+    if (q0 >= seqlen) {                                      // whole block is padding: o = 0, lse = 0
+        for (int v = tid; v < BQ * (DP / 8); v += 256) {
+            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+            if (q0 + r < L) *(u32x4*)(o_base + (int64_t)(q0 + r) * a.ld_o + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int r = tid; r < BQ; r += 256)
+            if (q0 + r < L) lse_base[q0 + r] = 0.f;
+        return;
+    }
+
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * DP;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * DP;
+    TileSrc ts;
+    ts.init(wave, lane, a.ld_k);
+    dma_tile(kbase, a.ld_k, 0, L, ts, smem, wave, lane);
+    dma_tile(vbase, a.ld_k, 0, L, ts, smem + 2 * TILE, wave, lane);
+
+    const int qw0 = q0 + wave * ROWS;                        // first query row of this wave
+    bf16x8 qf[RQ][KS];                                       // B operand: Q[q = fr][d chunk]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const uint16_t* qp = a.q + (row_base + min(qw0 + rq * 16 + fr, L - 1)) * a.ld_q + (int64_t)hq * DP;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
+    }
+    f32x4 ot[RQ][NF];                                        // O^T[d = j*16 + fq*4 + r][q = fr]
+    float m_run[RQ], l_part[RQ];                             // l_part: this lane's share of the row sum
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        m_run[rq] = M_INIT; l_part[rq] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) ot[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // LDS read offsets inside a tile: K rows (b128) and V gathers (tr_b64)
+    int k_off[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);        // + j * 16 rows = j * 4096 B (swizzle period 8 rows)
+    const float sl2 = a.scale * LOG2E;                       // scores in log2 domain: exp2(s*sl2 - m)
+    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                        // everybody's have; everybody is done with tile t-1
+        if (t + 1 < ntiles) {
+            dma_tile(kbase, a.ld_k, kv0 + 64, L, ts, smem + ((t + 1) & 1) * TILE, wave, lane);
+            dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
+        }
+        const unsigned char* sK = smem + (t & 1) * TILE;
+        const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
+        // a wave whose rows all precede this tile (causal) has nothing to do here
+        if (a.causal && kv0 > qw0 + ROWS - 1) continue;
+
+        f32x4 st[RQ][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+            }
+        const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            if (need_mask) {
+                const int qg = qw0 + rq * 16 + fr;
+                const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
+            }
+            float mx = fmaxf(fmaxf(st[rq][0][0], st[rq][0][1]), fmaxf(st[rq][0][2], st[rq][0][3]));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(st[rq][j][0], st[rq][j][1]), fmaxf(st[rq][j][2], st[rq][j][3])));
+            mx = quad_max(mx) * sl2;                         // max of the RAW scores (scale > 0 commutes with max)
+            // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew by more
+            // than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR)
+            if (__any(mx > m_run[rq] + RESCALE_THR)) {
+                const float mn = fmaxf(m_run[rq], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
+                l_part[rq] *= alpha;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+                m_run[rq] = mn;
+            }
+            const float mref = m_run[rq];
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
+                    st[rq][j][r] = p;
+                    rs += p;
+                }
+            l_part[rq] += rs;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 pb[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);          // V^T[d][keys perm]
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+            }
+        }
+    }
+    __syncthreads();                                         // ring is free: reuse it as the output staging area
+
+    // epilogue: O = O^T / l  -> bf16 [q][d] in LDS -> row-contiguous 16-B stores
+    unsigned char* so = smem + wave * (ROWS * DP * 2);
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qg = qw0 + rq * 16 + fr;
+        const bool valid = qg < seqlen;
+        const float l_run = quad_sum(l_part[rq]);
+        const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            u32x2 w;
+            w.x = pack2bf(ot[rq][j][0] * inv, ot[rq][j][1] * inv);
+            w.y = pack2bf(ot[rq][j][2] * inv, ot[rq][j][3] * inv);
+            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+        }
+        if (fq == 0 && qg < L) lse_base[qg] = valid ? (m_run[rq] + log2f(l_run)) * 0.6931471805599453f : 0.f;
+    }
+    __syncthreads();
+    for (int v = lane; v < ROWS * (DP / 8); v += 64) {
+        const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+        const int qg = qw0 + r;
+        if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+// ================================================================================================
+// dQ: workgroup = 128 query rows (4 waves x 32); per KV tile S^T = K Q^T and dP^T = V dO^T share the fragment reads of both
+// 16-row groups, dS^T feeds dQ^T += K^T dS^T from registers; bf16 result written straight to its column block
+// ================================================================================================
+template <int RQ>
+__global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
+    constexpr int KS = 4, NF = 8, ROWS = 16 * RQ, BQ = 4 * ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    int xb, hq, b;
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
+    const int q0 = xb * BQ;
+    const int hk = hq / (a.Hq / a.Hkv);
+    const int L = a.L;
+    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
+    const int64_t row_base = (int64_t)b * L;
+    uint16_t* dq_base = a.dqb + row_base * a.ld_dq + (int64_t)hq * DP;
+
+    if (q0 >= seqlen) {                                      // padded query rows carry zero gradient
+        for (int v = tid; v < BQ * (DP / 8); v += 256) {
+            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+            if (q0 + r < L) *(u32x4*)(dq_base + (int64_t)(q0 + r) * a.ld_dq + c) = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
+    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
+    const int ntiles = (kv_end + 63) >> 6;
+    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * DP;
+    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * DP;
+    TileSrc ts;
+    ts.init(wave, lane, a.ld_k);
+    dma_tile(kbase, a.ld_k, 0, L, ts, smem, wave, lane);
+    dma_tile(vbase, a.ld_k, 0, L, ts, smem + 2 * TILE, wave, lane);
+
+    const int qw0 = q0 + wave * ROWS;
+    bf16x8 qf[RQ][KS], dof[RQ][KS];
+    float lse2[RQ], del[RQ];
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const int qc = min(qw0 + rq * 16 + fr, L - 1);
+        const uint16_t* qp = a.q + (row_base + qc) * a.ld_q + (int64_t)hq * DP;
+        const uint16_t* dp = a.d_o + (row_base + qc) * a.ld_o + (int64_t)hq * DP;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
+            dof[rq][kk] = *(const bf16x8*)(dp + kk * 32 + fq * 8);
+        }
+        lse2[rq] = a.lse_in[((int64_t)b * a.Hq + hq) * L + qc] * LOG2E;            // log2 domain
+        del[rq] = a.delta[((int64_t)b * a.Hq + hq) * L + qc];
+    }
+    f32x4 dqt[RQ][NF];                                       // dQ^T[d = j*16 + fq*4 + r][q = fr]
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) dqt[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k_off[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
+    const float sl2 = a.scale * LOG2E;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntiles) {
+            dma_tile(kbase, a.ld_k, kv0 + 64, L, ts, smem + ((t + 1) & 1) * TILE, wave, lane);
+            dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
+        }
+        const unsigned char* sK = smem + (t & 1) * TILE;
+        const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
+        if (a.causal && kv0 > qw0 + ROWS - 1) continue;
+
+        // per 16-key group j: S^T and dP^T for both row groups, then dS^T = P^T o (dP^T - delta) * scale in place of S^T
+        // (dP^T is transient: 8 registers instead of 32)
+        const bool need_mask = (kv0 + 64 > seqlen) || (qw0 + ROWS > seqlen) || (a.causal && kv0 + 63 > qw0);
+        int lim[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            const int qg = qw0 + rq * 16 + fr;
+            const int kmax = qg >= seqlen ? -1 : (a.causal ? min(qg, seqlen - 1) : seqlen - 1);      // last visible key
+            lim[rq] = kmax - kv0 - fq * 4;
+        }
+        f32x4 st[RQ][4];
+        auto scores = [&](auto mask_c) {
+            constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 dpt[RQ];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) { st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[rq] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+                    const bf16x8 vf = *(const bf16x8*)(sV + j * 4096 + k_off[kk]);
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) {
+                        st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                        dpt[rq] = mfma16(vf, dof[rq][kk], dpt[rq]);
+                    }
+                }
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -lse2[rq]));
+                        if (MASK) p = (j * 16 + r > lim[rq]) ? 0.f : p;
+                        st[rq][j][r] = p * (dpt[rq][r] - del[rq]) * a.scale;
+                    }
+            }
+        };
+        if (need_mask) scores(std::true_type{}); else scores(std::false_type{});
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 sb[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) sb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 ka = read_nat_perm<DS>(sK, kk * 32, j, fr, fq);          // K^T[d][keys perm]
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) dqt[rq][j] = mfma16(ka, sb[rq], dqt[rq][j]);
+            }
+        }
+    }
+    __syncthreads();
+    // dq[q][d] bf16 -> LDS [32 q][128] per wave -> row-contiguous 16-B stores (rows >= seqlen are zero)
+    unsigned char* so = smem + wave * (ROWS * DP * 2);
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        const float keep = (qw0 + rq * 16 + fr) < seqlen ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            u32x2 w;
+            w.x = pack2bf(dqt[rq][j][0] * keep, dqt[rq][j][1] * keep);
+            w.y = pack2bf(dqt[rq][j][2] * keep, dqt[rq][j][3] * keep);
+            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
+        }
+    }
+    __syncthreads();
+    for (int v = lane; v < ROWS * (DP / 8); v += 64) {
+        const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
+        if (qw0 + r < L) *(u32x4*)(dq_base + (int64_t)(qw0 + r) * a.ld_dq + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
+    }
+}
+
+}  // namespace attn3

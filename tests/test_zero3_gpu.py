@@ -74,7 +74,8 @@ def test_zero3_equals_zero2_bit_for_bit(ckpt):
     (`gradient_checkpointing`, the 70B recipe) the layer is gathered three times per step: forward, recompute, backward."""
     l2, e2, p2, _ = _train(2, ckpt=ckpt)
     l3, e3, p3, opt = _train(3, ckpt=ckpt)
-    assert l2 == l3 and e2 == e3, (l2, l3, e2, e3)
+    # (the scalar loss is an fp32 atomicAdd over rows: equal to rounding, not bit for bit; the gradients do not depend on it)
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(l2, l3)) and abs(e2 - e3) <= 1e-6 * abs(e2), (l2, l3, e2, e3)
     assert torch.equal(p2, p3)
     rep = opt.memory_report()
     assert rep["param_slots"] > 0 and rep["param_shards"] > 0 and l3[-1] < l3[0]
@@ -102,7 +103,8 @@ def test_zero3_rccl_call_pattern_single_rank():
     try:
         losses, ev, flat, opt = _train(3)
         assert opt._coll and opt.world == 1
-        assert losses == base and ev == ebase and torch.equal(flat, pbase)
+        assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(losses, base)) and abs(ev - ebase) <= 1e-6 * abs(ev)
+        assert torch.equal(flat, pbase)
     finally:
         dist.destroy_process_group()
         del os.environ["MM355_ZERO2_FORCE_COLLECTIVES"]
