@@ -368,11 +368,12 @@ def main():
         # the gfx950 x2 read correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed
         # under profiles/; they only apply to the configuration they were taken on.
         traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "r1_step_b12_hbm_traffic_e.json")
-        if args.batch == 12 and args.layers == 32 and os.path.exists(tpath):
+        tname = {12: "r1_step_b12_hbm_traffic_e.json", 16: "r2_step_b16_hbm_traffic.json"}.get(args.batch, "none")
+        tpath = os.path.join(REPO, "profiles", tname)
+        if args.layers == 32 and args.seq == 2048 and args.frames == 1 and os.path.exists(tpath):
             for k in json.load(open(tpath))["kernels"]:
                 if k["kernel"].startswith("gemm_pp_kernel<false, false>"):
-                    traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/r1_step_b12_hbm_traffic_e.json"
+                    traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + tname
         alg_bytes = sum(r[4] for r in timer.records) / n_gemm
         roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),

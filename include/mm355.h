@@ -141,6 +141,11 @@ int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_b
 int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, float theta, void* stream);
 int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                   const mm355_bf16* cos_t, const mm355_bf16* sin_t, int inverse, void* stream);
+/* the same with a per-sample position offset (int32[B], device): position of row (b,l) is l + pos_offset[b]; the tables need
+ * L + max(pos_offset) rows.  Left-padded batches (tokenizer_padding_side = "left", metamorph_arch.py:362-386) are run right-aligned
+ * to row 0 with pos_offset[b] = number of padding rows, which reproduces HF's position ids (arange(L), padding included). */
+int mm355_rope_qk_pos(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                      const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset, int inverse, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention -- torch SDPA as driven by HF LlamaModel (causal + key padding, GQA, fp32 softmax; K10)

@@ -32,14 +32,15 @@ __global__ void rope_table_kernel(uint16_t* __restrict__ cos_o, uint16_t* __rest
 // forward : y1 = bf(bf(x1*c) + bf(-x2*s)),  y2 = bf(bf(x2*c) + bf(x1*s))     (HF rounding order)
 // inverse : dx1 = dy1*c + dy2*s,            dx2 = dy2*c - dy1*s
 __global__ __launch_bounds__(NT) void rope_qk_kernel(uint16_t* __restrict__ qkv, int64_t ld, int B, int L, int H, int d,
-                                                     const uint16_t* __restrict__ cos_t, const uint16_t* __restrict__ sin_t, int inverse) {
+                                                     const uint16_t* __restrict__ cos_t, const uint16_t* __restrict__ sin_t, int inverse,
+                                                     const int32_t* __restrict__ pos_off) {
     const int half = d >> 1, vph = half >> 3;               // vectors per half head
     const int64_t total = (int64_t)B * L * H * vph;
     for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
         const int v = (int)(i % vph);
         const int hd = (int)((i / vph) % H);
         const int64_t row = i / ((int64_t)vph * H);
-        const int l = (int)(row % L);
+        const int l = (int)(row % L) + (pos_off ? pos_off[row / L] : 0);     // table row = position id (left padding: row index + offset)
         uint16_t* p1 = qkv + row * ld + (int64_t)hd * d + v * 8;
         uint16_t* p2 = p1 + half;
         float x1[8], x2[8], c[8], s[8], y1[8], y2[8];
@@ -345,7 +346,14 @@ extern "C" int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, 
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!qkv || !cos_t || !sin_t || B <= 0 || L <= 0 || Hq <= 0 || Hkv < 0 || d <= 0 || (d & 15) || (ld & 7)) return MM355_EINVAL;
     const int64_t H = Hq + Hkv;                              // q heads then k heads are contiguous column blocks
-    LAUNCH(rope_qk_kernel, grid_for(B * L * H * (d / 16)), qkv, ld, (int)B, (int)L, (int)H, (int)d, cos_t, sin_t, inverse);
+    LAUNCH(rope_qk_kernel, grid_for(B * L * H * (d / 16)), qkv, ld, (int)B, (int)L, (int)H, (int)d, cos_t, sin_t, inverse, (const int32_t*)nullptr);
+}
+extern "C" int mm355_rope_qk_pos(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, const mm355_bf16* cos_t,
+                                 const mm355_bf16* sin_t, const int32_t* pos_offset, int inverse, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!qkv || !cos_t || !sin_t || B <= 0 || L <= 0 || Hq <= 0 || Hkv < 0 || d <= 0 || (d & 15) || (ld & 7)) return MM355_EINVAL;
+    const int64_t H = Hq + Hkv;
+    LAUNCH(rope_qk_kernel, grid_for(B * L * H * (d / 16)), qkv, ld, (int)B, (int)L, (int)H, (int)d, cos_t, sin_t, inverse, pos_offset);
 }
 extern "C" int mm355_swiglu_fwd(const mm355_bf16* gu, mm355_bf16* act, int64_t M, int64_t I, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch

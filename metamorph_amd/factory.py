@@ -14,15 +14,15 @@ TINYLLAMA_1B = dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=
 
 def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tokens=256, mm_projector_type="mlp2x_gelu",
                 vision_head="mlp", normalize_vision=True, apply_softmax=False, use_vision_ar=True, vision_coef=1.0, max_length=4096,
-                padding_side="right", image_start_id=None, state_dict=None, device=None, dtype=torch.bfloat16,
-                init_on_device=False):
+                padding_side="right", image_start_id=None, image_token_reduction="interpolation", state_dict=None, device=None,
+                dtype=torch.bfloat16, init_on_device=False):
     llm = dict(llm)
     cfg = MetaMorphConfig(max_position_embeddings=8192, attention_bias=False, tie_word_embeddings=False, **llm)
     cfg.mm_vision_tower = "siglip/CLIP-ViT-SO400M-14-384"
     cfg.mm_projector_type = mm_projector_type
-    cfg.mm_hidden_size = (vision_geometry or {}).get("hidden_size", 1152)
+    cfg.mm_hidden_size = (vision_geometry or {}).get("hidden_size", 1152) * (4 if image_token_reduction == "concat_interpolation" else 1)
     cfg.num_image_tokens = num_image_tokens
-    cfg.image_token_reduction = "interpolation"
+    cfg.image_token_reduction = image_token_reduction
     cfg.freeze_vision = True
     cfg.normalize_vision = normalize_vision
     cfg.apply_softmax = apply_softmax
@@ -37,7 +37,11 @@ def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tok
     with ctx:
         model = MetaMorphLlamaForCausalLM(cfg, use_vision_ar=use_vision_ar, vision_head=vision_head, vision_coef=vision_coef,
                                           normalize_vision=normalize_vision, apply_softmax=apply_softmax, vision_delay_load=True)
-        model.get_model().vision_tower.load_model(random_init=True)
+        tower_sd = None
+        if state_dict is not None:                           # mixers of the 'mlpmixer' reduction live on the tower wrapper
+            tower_sd = {k[len("model.vision_tower."):]: v for k, v in state_dict.items() if k.startswith("model.vision_tower.")
+                        and not k.startswith("model.vision_tower.vision_tower.")} or None
+        model.get_model().vision_tower.load_model(random_init=True, state_dict=tower_sd)
     if state_dict is not None:
         missing, unexpected = model.load_state_dict(state_dict, strict=False)
         missing = [k for k in missing if "post_layernorm" not in k]

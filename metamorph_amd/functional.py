@@ -171,15 +171,30 @@ def commit_fused_grad(params, fused, accumulate, bufs):
         commit_grad(p, tgt)
 
 
-def transpose_padded(x2d):
-    """x [R, C] -> [C, Rp] with Rp = R rounded up to 8 and zero padding columns (a legal GEMM K dimension)."""
+def _padded_rows(R, long_k=False):
+    """K dimension a transposed copy of R rows gets: a multiple of 8 (legal GEMM K), or of 128 for a long contraction headed for
+    the ping-pong kernel (whole pairs of 64-wide K tiles: keeps a ragged token count off the register-staged fallback kernel)."""
+    return (R + 127) // 128 * 128 if (long_k and R >= 512) else (R + 7) // 8 * 8
+
+
+def transpose_padded(x2d, Rp=None):
+    """x [R, C] -> [C, Rp] with zero padding columns (they add nothing to a product contracted over them); Rp defaults to R
+    rounded up to 8."""
     R, C = x2d.shape
-    Rp = (R + 7) // 8 * 8
+    Rp = _padded_rows(R) if Rp is None else Rp
     buf = torch.empty((C, Rp), device=x2d.device, dtype=BF16)
     if Rp != R:
-        buf[:, R:].zero_()                                    # only the (< 8) padding columns
+        buf[:, R:].zero_()                                    # only the padding columns
     ops.transpose(x2d, out=buf[:, :R])
     return buf
+
+
+def _dw_operands(dy2d, x2d, dyT=None, xT=None):
+    """Contraction-major operands (dy^T [N, Mp], x^T [K, Mp]) of a weight-gradient GEMM in NT form; a copy a producer already
+    wrote (dyT / xT) fixes Mp, otherwise long contractions are padded to whole pairs of K tiles."""
+    R = (dy2d if dy2d is not None else x2d).shape[0]
+    Rp = dyT.shape[1] if dyT is not None else (xT.shape[1] if xT is not None else _padded_rows(R, long_k=True))
+    return (transpose_padded(dy2d, Rp) if dyT is None else dyT, transpose_padded(x2d, Rp) if xT is None else xT)
 
 
 def weight_grad_gemm(dy2d, x2d, out, accumulate, dyT=None, xT=None):
@@ -192,13 +207,8 @@ def weight_grad_gemm(dy2d, x2d, out, accumulate, dyT=None, xT=None):
             ops.gemm_tn(dy2d, x2d, out, accumulate=accumulate)
             return
     # dyT / xT: contraction-major copies a producer already wrote (the row-major argument may then be None)
-    ops.gemm(transpose_padded(dy2d) if dyT is None else dyT, transpose_padded(x2d) if xT is None else xT, out=out,
-             accumulate=accumulate)
-
-
-def _dw_operands(dy2d, x2d, dyT=None, xT=None):
-    """Contraction-major operands (dy^T [N, Mp], x^T [K, Mp]) of a weight-gradient GEMM in NT form."""
-    return (transpose_padded(dy2d) if dyT is None else dyT, transpose_padded(x2d) if xT is None else xT)
+    a, b = _dw_operands(dy2d, x2d, dyT, xT)
+    ops.gemm(a, b, out=out, accumulate=accumulate)
 
 
 def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
@@ -206,7 +216,7 @@ def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
     waves of workgroups than two launches?  (Both must be problems the ping-pong kernel takes on its own: >= 200 tiles.)"""
     t0 = -(-rows0 // 256) * -(-cols0 // 256)
     t1 = -(-rows1 // 256) * -(-cols1 // 256)
-    kp = (contraction + 7) // 8 * 8
+    kp = _padded_rows(contraction, long_k=True)
     if min(t0, t1) < 200 or kp % 128:
         return False
     return -(-(t0 + t1) // _CUS) < -(-t0 // _CUS) + -(-t1 // _CUS)
@@ -226,9 +236,10 @@ def input_grad_gemm(dy2d, w, out=None, residual=None):
 class LayerMeta:
     """Geometry shared by all decoder layers of one forward pass."""
 
-    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens, recompute=False):
+    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens, recompute=False, pos_offset=None):
         self.B, self.L, self.Hq, self.Hkv, self.d, self.I, self.eps = B, L, Hq, Hkv, d, I, eps
         self.cos, self.sin, self.seqlens = cos, sin, seqlens
+        self.pos_offset = pos_offset        # int32 [B] or None: RoPE position of row (b, l) = l + pos_offset[b] (left-padded batches)
         self.scale = d ** -0.5
         # gradient checkpointing (reference train.py:1443-1449 + `--gradient_checkpointing True` in every launch script): keep only
         # the layer input, re-run the layer's forward kernels at the start of its backward
@@ -244,7 +255,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps)
     qkv = ops.gemm(n1, wqkv)
     del n1
-    ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin)
+    ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)
     nq, nk = m.Hq * m.d, m.Hkv * m.d
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
@@ -340,7 +351,7 @@ class DecoderLayerFn(Function):
         ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
                      m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:])
         del do
-        ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True)
+        ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True, pos_offset=m.pos_offset)
         wqkv = fused_weight(qkv_params)
         dn1 = input_grad_gemm(dqkv, wqkv)
         if any(p.requires_grad for p in qkv_params):
@@ -730,6 +741,89 @@ class GeluFn(Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return ops.gelu_bwd(x, dy.contiguous(), ctx.kind), None
+
+
+class TransposeFn(Function):
+    """x [R, C] -> x^T [C, Rp] (zero-padded columns when Rp > R); backward transposes the live part back."""
+
+    @staticmethod
+    def forward(ctx, x, Rp):
+        ctx.R = x.shape[0]
+        return transpose_padded(x, Rp) if Rp is not None else _transpose_exact(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _transpose_exact(dy[:, :ctx.R]), None
+
+
+def _transpose_exact(x2d):
+    R, C = x2d.shape
+    out = torch.empty((C, R), device=x2d.device, dtype=BF16)
+    ops.transpose(x2d, out=out)
+    return out
+
+
+class PadFn(Function):
+    """t [N, K] (or [N]) -> zero-padded [Np, Kp] (or [Np]): legal GEMM operand shapes for odd widths; backward slices."""
+
+    @staticmethod
+    def forward(ctx, t, Np, Kp):
+        ctx.shape = tuple(t.shape)
+        src = t.data if isinstance(t, torch.nn.Parameter) else t
+        if t.dim() == 1:
+            out = torch.zeros((Np,), device=t.device, dtype=t.dtype)
+            out[:t.shape[0]].copy_(src)
+        else:
+            out = torch.zeros((Np, Kp), device=t.device, dtype=t.dtype)
+            out[:t.shape[0], :t.shape[1]].copy_(src)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        sl = dy[:ctx.shape[0]] if len(ctx.shape) == 1 else dy[:ctx.shape[0], :ctx.shape[1]]
+        return sl.contiguous(), None, None
+
+
+class LinearWBFn(Function):
+    """y = x W^T + b with weight / bias passed as TENSORS (gradients returned through autograd, e.g. to PadColsFn)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.gemm(x, weight, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = input_grad_gemm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            weight_grad_gemm(dy, x, dw, False)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            s = torch.zeros(dy.shape[1], device=dy.device, dtype=torch.float32)
+            ops.colsum_f32(dy, s)
+            db = torch.empty(dy.shape[1], device=dy.device, dtype=BF16)
+            ops.axpy_(db, s, None, 1.0, False)
+        return dx, dw, db
+
+
+class RowsPermuteFn(Function):
+    """out[r] = x[fwd[r]] (fwd[r] = -1 -> zero row); backward gathers with the inverse map.  Moves a left-padded batch to the
+    right-padded row layout the attention kernels take (per-sample lengths from row 0) and back."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_i32, inv_i32):
+        ctx.save_for_backward(inv_i32)
+        return ops.rows_gather(x, fwd_i32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inv,) = ctx.saved_tensors
+        return ops.rows_gather(dy.contiguous(), inv), None, None
 
 
 class RowsGatherFn(Function):

@@ -50,6 +50,19 @@ def _rope_theta(config):
     return float(getattr(config, "rope_theta", 10000.0))
 
 
+def _left_pad_maps(seqlens, B, L):
+    """Row maps between the left-padded layout (valid rows [L - n_b, L)) and the right-padded one (valid rows [0, n_b)):
+    (to_right [B*L]: source row of every right-layout row, -1 = zero row; to_left: the inverse; off [B] = L - n_b), all int32."""
+    to_right = np.full(B * L, -1, dtype=np.int32)
+    to_left = np.full(B * L, -1, dtype=np.int32)
+    off = (L - np.asarray(seqlens, dtype=np.int64)).astype(np.int32)
+    for b in range(B):
+        n = int(seqlens[b])
+        to_right[b * L:b * L + n] = b * L + off[b] + np.arange(n, dtype=np.int32)
+        to_left[b * L + off[b]:(b + 1) * L] = b * L + np.arange(n, dtype=np.int32)
+    return to_right, to_left, off
+
+
 class _Attention(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -123,7 +136,12 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         self.normalize_vision = bool(normalize_vision) or bool(getattr(config, "normalize_vision", False))
         self.apply_softmax = bool(apply_softmax)
         vision_head = getattr(config, "vision_head_type", vision_head)
-        hv = getattr(config, "mm_hidden_size", 1152)          # the reference hard-codes 1152 (metamorph_llama.py:255)
+        # the reference hard-codes 1152 (metamorph_llama.py:255) = the SO400M feature width; here: the tower's feature width, i.e.
+        # mm_hidden_size, or a quarter of it under 'concat_interpolation' (mm_hidden_size = 4 x tower width, siglip_encoder.py:110) --
+        # so that reference checkpoints load unchanged in every configuration
+        hv = getattr(config, "mm_hidden_size", 1152)
+        if getattr(config, "image_token_reduction", "none") == "concat_interpolation":
+            hv //= 4
         h = config.hidden_size
         if vision_head == "linear":
             self.vision_head = HipLinear(h, h)
@@ -133,6 +151,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
             self.vision_head = nn.Sequential(HipLinear(h, h), HipGELU(), HipLinear(h, h), HipGELU(), HipLinear(h, hv))
         else:
             self.vision_head = HipLinear(h, hv)
+        self._vision_head_out = h if vision_head == "linear" else hv
         self.use_vision_ar = use_vision_ar
         self.vision_coef = vision_coef
         self._loss_language_t = None
@@ -199,11 +218,10 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         # inputs_embeds supplied by the caller: derive the index arrays from the given tensors (one host copy)
         B, L, _ = inputs_embeds.shape
         msk = np.ones((B, L), dtype=bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
-        if getattr(self.config, "tokenizer_padding_side", "right") == "left" and not msk.all():
-            raise NotImplementedError("left padding: the attention kernel takes per-sample lengths (right padding) only")
+        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"
         seqlens = msk.sum(1).astype(np.int32)
-        if not all(msk[b, : seqlens[b]].all() for b in range(B)):
-            raise NotImplementedError("attention_mask must be a right-padding mask")
+        if not all((msk[b, L - seqlens[b]:] if left else msk[b, : seqlens[b]]).all() for b in range(B)):
+            raise NotImplementedError("attention_mask must be a contiguous padding mask on the configured tokenizer_padding_side")
         lab = None if labels is None else labels.detach().cpu().numpy()
         pos = np.zeros((B, L), dtype=np.int64) if image_positions is None else image_positions.detach().cpu().numpy()
         nxt = np.zeros((B, L), dtype=bool)
@@ -221,7 +239,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                           position_ids=np.zeros((B, L), dtype=np.int64), seqlens=seqlens, target_keep=np.zeros(0, dtype=np.int64),
                           feat_row=z, pred_rows=np.flatnonzero(nxt.reshape(-1)).astype(np.int32), shift_targets=st,
                           ce_rows=ce_rows, n_valid=n_valid, emb_tok=z, emb_seg=np.zeros(1, dtype=np.int32), emb_pos=z,
-                          images_consumed=0)
+                          images_consumed=0, padding_side="left" if left else "right")
         return upload_plan(plan, inputs_embeds.device)
 
     # ------------------------------------------------------------------ the hot path
@@ -244,20 +262,32 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         B, L, h = inputs_embeds.shape
         pd = self._plan_for(inputs_embeds, attention_mask, labels, image_positions)
         plan = pd["host"]
-        if plan.padding_side == "left" and not plan.attention_mask.all():
-            raise NotImplementedError("left padding: the attention kernel takes per-sample lengths (right padding) only")
         dev = inputs_embeds.device
         Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
         d = h // Hq
-        cos, sin = self.model.rope_tables(L, dev)
+        # Left padding (tokenizer_padding_side = "left", reference metamorph_arch.py:362-386): the attention kernels take per-sample
+        # lengths counted from row 0, so the batch is moved to the right-padded row layout for the decoder and back afterwards; the
+        # RoPE position of a moved row stays its ORIGINAL row index (HF: position_ids = arange(L), padding included), which the
+        # kernels get as a per-sample offset.  Causal attention over the valid rows is unchanged by the move.
+        shift = plan.padding_side == "left" and not plan.attention_mask.all()
+        pos_off = None
+        if shift:
+            to_right, to_left, off = _left_pad_maps(plan.seqlens, B, L)
+            moved = torch.from_numpy(np.concatenate([to_right, to_left, off])).to(dev)
+            to_right_d, to_left_d, pos_off = moved[:B * L], moved[B * L:2 * B * L], moved[2 * B * L:]
+        cos, sin = self.model.rope_tables(2 * L if shift else L, dev)
         meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],
-                           recompute=bool(self.model.gradient_checkpointing) and self.training)
+                           recompute=bool(self.model.gradient_checkpointing) and self.training, pos_offset=pos_off)
 
         x = inputs_embeds.reshape(B * L, h)
         if not x.is_contiguous():
             x = x.contiguous()
+        if shift:
+            x = F.RowsPermuteFn.apply(x, to_right_d, to_left_d)
         for layer in self.model.layers:
             x = F.decoder_layer(x, layer, meta)
+        if shift:
+            x = F.RowsPermuteFn.apply(x, to_left_d, to_right_d)
         hid = self.model.norm(x)                                       # [B*L, h]
         hidden_states = hid.view(B, L, h)
 
@@ -295,8 +325,10 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                     Rt = tgt.shape[0]
                     if R == 0 and Rt == 0 and (cosine or self.apply_softmax):
                         l_img = nan          # mean over an empty tensor -- SURVEY A9 (understanding-only / text-only batches)
-                    elif R != Rt and cosine:
-                        l_img = ce           # F.cosine_similarity raises on the row mismatch; the reference's try/except (:451-455)
+                    elif cosine and (R != Rt or tgt.shape[1] != self._vision_head_out):
+                        # F.cosine_similarity raises on a row-count mismatch -- or, under 'concat_interpolation', on the width mismatch
+                        # between the 1152-wide head and the 4 x 1152 targets -- and the reference's try/except (:451-455) substitutes CE
+                        l_img = ce
                     elif R != Rt or R == 0:
                         # soft-CE: broadcasting error; mean-abs (`mse_loss_fn`): a Python float has no .item() / division by len 0
                         raise RuntimeError(f"image-AR head ({'soft-CE' if self.apply_softmax else 'mean-abs'}): {R} prediction rows vs "

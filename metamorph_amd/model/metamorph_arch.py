@@ -110,9 +110,15 @@ class MetaMorphMetaForCausalLM(ABC):
     # ------------------------------------------------------------------ A4
     def encode_images(self, images, return_prob=False):
         """tower -> mm_projector; second return = detached regression targets (reference metamorph_arch.py:140-164)."""
-        if return_prob:
-            raise NotImplementedError("return_prob=True belongs to the 'mlpsoftmax' connector, which has no HIP kernel")
         image_features = self.get_model().get_vision_tower()(images)
+        if return_prob:                                      # 'mlpsoftmax' connector taken apart (metamorph_arch.py:143-158)
+            F.params_ready(None)
+            linear1, softmax, linear2 = self.get_model().mm_projector[0], self.get_model().mm_projector[1], self.get_model().mm_projector[2]
+            n, t, c = image_features.shape
+            z = linear1(image_features.reshape(n * t, c).to(BF16).contiguous())
+            target_prob = softmax(z, temperature=self.get_model().temperature_in)
+            out = linear2(target_prob).view(n, t, -1)
+            return out, target_prob.view(n, t, -1), out.detach().clone()
         ar_image_features = self._project(image_features)
         return ar_image_features, image_features.detach()
 

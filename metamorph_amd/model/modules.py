@@ -89,3 +89,18 @@ class HipEmbedding(nn.Module):
         flat = ids.reshape(-1).to(torch.int32)
         out = ops.splice_gather(self.weight.data, None, flat, self.embedding_dim)
         return out.view(*ids.shape, self.embedding_dim)
+
+
+class HipSoftmax(nn.Module):
+    """nn.Softmax(dim=-1) over the feature dimension (the 'mlpsoftmax' connector, reference multimodal_projector/builder.py:45-50);
+    `temperature` divides the input first (encode_images(return_prob=True): softmax(x / temperature_in), metamorph_arch.py:151)."""
+
+    def __init__(self, dim=-1):
+        super().__init__()
+        if dim != -1:
+            raise NotImplementedError("HipSoftmax: only the feature dimension (dim=-1) has a kernel")
+
+    def forward(self, x, temperature=1.0):
+        shp = x.shape
+        y = F.SoftmaxRowsFn.apply(x.reshape(-1, shp[-1]).contiguous(), float(temperature))
+        return y.view(shp)

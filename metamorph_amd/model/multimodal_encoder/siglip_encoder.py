@@ -268,11 +268,10 @@ class SiglipVisionTower(nn.Module):
         self._interp_size = interp
         self.hidden_size = self.geometry["hidden_size"]
         self.image_processor = None
+        if self.image_token_reduction == "concat_interpolation":     # reference siglip_encoder.py:109-110
+            self.hidden_size = 4 * self.geometry["hidden_size"]
         if not delay_load:
             self.load_model()
-        if self.image_token_reduction in ("mlpmixer", "concat_interpolation"):
-            raise NotImplementedError(f"image_token_reduction={self.image_token_reduction!r} has no HIP kernel "
-                                      "(every shipped recipe uses 'interpolation')")
 
     def load_model(self, device_map=None, state_dict=None, random_init=False):
         """Builds the tower.  Weights come from `state_dict` (HF SigLIP vision keys), from the HF hub checkpoint
@@ -292,7 +291,17 @@ class SiglipVisionTower(nn.Module):
         if state_dict is not None:
             own = self.vision_tower.state_dict()
             self.vision_tower.load_state_dict({k: v for k, v in state_dict.items() if k in own}, strict=False)
-        self.hidden_size = self.geometry["hidden_size"]
+        hv = self.geometry["hidden_size"]
+        self.hidden_size = 4 * hv if self.image_token_reduction == "concat_interpolation" else hv
+        if self.image_token_reduction == "mlpmixer" and not hasattr(self, "token_mixer"):     # reference siglip_encoder.py:100-107
+            patches = (self.geometry["image_size"] // self.geometry["patch_size"]) ** 2
+            self.token_mixer = nn.Sequential(HipLinear(patches, self.image_token_len))
+            self.channel_mixer = nn.Sequential(HipLinear(hv, hv))
+            if state_dict is not None:
+                for name, mod in (("token_mixer", self.token_mixer), ("channel_mixer", self.channel_mixer)):
+                    sub = {k[len(name) + 1:]: v for k, v in state_dict.items() if k.startswith(name + ".")}
+                    if sub:
+                        mod.load_state_dict(sub)
         self.is_loaded = True
 
     def feature_select(self, hidden_last):
@@ -309,24 +318,76 @@ class SiglipVisionTower(nn.Module):
         b, num_tokens, dim = feats.shape
         side_in = int(math.isqrt(num_tokens))
         side_out = side_in
+        from ... import functional as F
+        reduction = "interpolation"
         if num_tokens != self.image_token_len:
             if self.image_token_len == -1:
                 return torch.zeros((b, num_tokens, dim), device=feats.device, dtype=feats.dtype)
-            if self.image_token_reduction != "interpolation":
+            reduction = self.image_token_reduction
+            if reduction == "interpolation":
+                side_out = int(np.random.randint(1, 25)) if self.image_token_len == 0 else int(np.sqrt(self.image_token_len))
+            elif reduction == "mlpmixer":                        # token mixing over the patch axis, then a channel Linear (:164-168)
+                feats = self._mlpmixer(feats, train)
+            elif reduction == "concat_interpolation":            # interpolate to 4 T tokens, concatenate every 2 x 2 block (:169-199)
+                feats = self._concat_interpolation(feats, side_in, train)
+                side_in = side_out = int(math.isqrt(self.image_token_len))
+            else:
                 raise NotImplementedError("Not Implemented!")
-            side_out = int(np.random.randint(1, 25)) if self.image_token_len == 0 else int(np.sqrt(self.image_token_len))
-        from ... import functional as F
+        if reduction != "interpolation":
+            side_in = side_out = 1                               # nothing left to interpolate: only the optional L2 normalisation below
+            b, t, c = feats.shape
+            feats = feats.reshape(b * t, 1, c)
         if side_out != side_in or self.normalize_vision:
             if train:
                 feats = F.BilinearL2NormFn.apply(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
             else:
                 feats = ops.bilinear_l2norm(feats.contiguous(), side_in, side_out, bool(self.normalize_vision))
+        if reduction != "interpolation":
+            feats = feats.reshape(b, t, c)
         if self.apply_softmax:                                   # softmax(feat / 0.07) (siglip_encoder.py:210-211)
             n, t, c = feats.shape
             flat = feats.reshape(n * t, c).contiguous()
             flat = F.SoftmaxRowsFn.apply(flat, 0.07) if train else ops.softmax_rows(flat, 0.07)
             feats = flat.view(n, t, c)
         return feats
+
+    def _mlpmixer(self, feats, train):
+        """[b, P, c] -> token_mixer over P (Linear(P, T) applied to the transposed features) -> [b, T, c] -> channel_mixer.
+        The contraction runs over the patch axis, so each image is transposed ([c, P], zero-padded to a legal GEMM K) first."""
+        from ... import functional as F
+        b, P, c = feats.shape
+        tm, cm = self.token_mixer[0], self.channel_mixer[0]
+        T = tm.weight.shape[0]
+        Pp, Tp = (P + 7) // 8 * 8, (T + 7) // 8 * 8              # legal GEMM K / leading dimensions: zero padding, sliced off below
+        wt, bt = tm.weight, tm.bias
+        if Pp != P or Tp != T:
+            wt, bt = F.PadFn.apply(tm.weight, Tp, Pp), F.PadFn.apply(tm.bias, Tp, None)
+        outs = []
+        for i in range(b):
+            xt = F.TransposeFn.apply(feats[i].contiguous(), Pp)  # [c, Pp]
+            y = F.LinearWBFn.apply(xt, wt, bt)                   # [c, Tp]  (bias along the token axis)
+            outs.append(F.TransposeFn.apply(y, None)[:T])        # [T, c]
+        y = (torch.cat(outs, 0) if b > 1 else outs[0]).contiguous()
+        return cm(y).view(b, T, c)
+
+    def _concat_interpolation(self, feats, side_in, train):
+        from ... import functional as F
+        b, _, c = feats.shape
+        s = int(math.isqrt(self.image_token_len))
+        mid = 2 * s                                              # intermediate grid: 4 T tokens
+        if mid != side_in:
+            x = (F.BilinearL2NormFn.apply(feats.contiguous(), side_in, mid, False) if train
+                 else ops.bilinear_l2norm(feats.contiguous(), side_in, mid, False))
+        else:
+            x = feats.contiguous()
+        # out[b, (I, J), (di * 2 + dj) * c + ch] = x[b, (2 I + di) * mid + 2 J + dj, ch]: one row gather
+        I, J, di, dj = np.meshgrid(np.arange(s), np.arange(s), np.arange(2), np.arange(2), indexing="ij")
+        src = ((2 * I + di) * mid + 2 * J + dj).reshape(-1)
+        idx = (np.arange(b)[:, None] * (mid * mid) + src[None, :]).reshape(-1).astype(np.int32)
+        idx_d = torch.from_numpy(idx).to(feats.device)
+        x2 = x.reshape(b * mid * mid, c)
+        g = F.RowsGatherFn.apply(x2, idx_d) if (train and x2.requires_grad) else ops.rows_gather(x2, idx_d)
+        return g.view(b, s * s, 4 * c)
 
     @property
     def dtype(self):

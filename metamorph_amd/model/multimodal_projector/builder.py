@@ -5,7 +5,7 @@ import re
 
 import torch.nn as nn
 
-from ..modules import HipGELU, HipLinear
+from ..modules import HipGELU, HipLinear, HipSoftmax
 
 
 class IdentityMap(nn.Module):
@@ -31,7 +31,7 @@ def build_vision_projector(config, delay_load=False, **kwargs):
         return nn.Sequential(*mods)
     if projector_type == "identity":
         return IdentityMap()
-    if projector_type == "mlpsoftmax":
-        raise NotImplementedError("mm_projector_type='mlpsoftmax' (softmax connector) is not used by any shipped recipe "
-                                  "and has no HIP kernel yet")
+    if projector_type == "mlpsoftmax":       # Linear -> Softmax(dim=-1) -> Linear (reference builder.py:45-50)
+        return nn.Sequential(HipLinear(config.mm_hidden_size, config.hidden_size), HipSoftmax(dim=-1),
+                             HipLinear(config.hidden_size, config.hidden_size))
     raise ValueError(f"Unknown projector type: {projector_type}")

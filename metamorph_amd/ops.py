@@ -308,12 +308,18 @@ def rope_table(L, d, theta, device):
     return cos, sin
 
 
-def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False):
-    """In place on the q (first Hq*d columns) and k (next Hkv*d columns) blocks of qkv [B*L, ld]."""
-    _chk_dev(qkv, cos, sin)
+def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False, pos_offset=None):
+    """In place on the q (first Hq*d columns) and k (next Hkv*d columns) blocks of qkv [B*L, ld]; pos_offset (int32 [B], device):
+    position of row (b, l) is l + pos_offset[b] (the caller guarantees the tables are long enough)."""
+    _chk_dev(qkv, cos, sin, pos_offset)
     p, M, _, ld = _rows2d(qkv)
     assert M == B * L and cos.shape[0] >= L
-    _lib.check(_L().mm355_rope_qk(p, ld, B, L, Hq, Hkv, d, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "mm355_rope_qk")
+    if pos_offset is None:
+        _lib.check(_L().mm355_rope_qk(p, ld, B, L, Hq, Hkv, d, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "mm355_rope_qk")
+    else:
+        assert pos_offset.dtype == torch.int32 and pos_offset.numel() == B
+        _lib.check(_L().mm355_rope_qk_pos(p, ld, B, L, Hq, Hkv, d, cos.data_ptr(), sin.data_ptr(), pos_offset.data_ptr(), int(inverse), _stream()),
+                   "mm355_rope_qk_pos")
     return qkv
 
 

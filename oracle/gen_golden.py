@@ -93,9 +93,9 @@ def build_reference(cfg: OracleConfig, sd, dtype, **ctor):
                          attention_bias=False, tie_word_embeddings=False)
     hf.mm_vision_tower = "siglip/CLIP-ViT-SO400M-14-384"
     hf.mm_projector_type = cfg.mm_projector_type
-    hf.mm_hidden_size = cfg.v_hidden
+    hf.mm_hidden_size = cfg.v_hidden * (4 if cfg.image_token_reduction == "concat_interpolation" else 1)
     hf.num_image_tokens = cfg.num_image_tokens
-    hf.image_token_reduction = "interpolation"
+    hf.image_token_reduction = cfg.image_token_reduction
     hf.freeze_vision = True
     hf.normalize_vision = cfg.normalize_vision
     hf.apply_softmax = cfg.apply_softmax
@@ -113,6 +113,10 @@ def build_reference(cfg: OracleConfig, sd, dtype, **ctor):
                               hidden_act="gelu_pytorch_tanh")
     tower.vision_tower = SiglipVisionModel(vcfg)
     tower.is_loaded = True
+    if cfg.image_token_reduction == "mlpmixer":              # what the tower's constructor builds once it is loaded (:100-107)
+        P = (cfg.v_image // cfg.v_patch) ** 2
+        tower.token_mixer = torch.nn.Sequential(torch.nn.Linear(P, cfg.num_image_tokens))
+        tower.channel_mixer = torch.nn.Sequential(torch.nn.Linear(cfg.v_hidden, cfg.v_hidden))
     missing, unexpected = model.load_state_dict(sd, strict=False)
     missing = [k for k in missing if "post_layernorm" not in k and ".head." not in k]
     assert not missing and not unexpected, (missing, unexpected)
@@ -387,16 +391,23 @@ E2E_CASES = [
     ("multi_frame", 4, True, "cos"),
     ("mixed", 4, True, "l1"), ("generation_only", 4, True, "l1"),
     ("mixed", 4, True, "softce"), ("generation_only", 4, True, "softce_raw"),
+    ("mixed", 4, True, "cos", "left"),               # tokenizer_padding_side = "left" (metamorph_arch.py:362-386)
+    ("mixed", 4, True, "cos", "right", {"mm_projector_type": "mlpsoftmax"}),      # Linear -> Softmax -> Linear connector
+    ("mixed", 1, True, "cos", "right", {"image_token_reduction": "concat_interpolation"}),   # 16 patches -> 4 -> one 4 x 1152-wide token
+    ("understanding_only", 4, False, "cos", "right", {"image_token_reduction": "mlpmixer"}),
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
 
 def gen_e2e():
     shared = np.random.default_rng(41)               # the first five cases draw their images from ONE stream, in this order
-    for i, (kind, T, use_ar, variant) in enumerate(E2E_CASES):
+    for i, case in enumerate(E2E_CASES):
+        kind, T, use_ar, variant = case[:4]
+        side = case[4] if len(case) > 4 else "right"
+        extra = case[5] if len(case) > 5 else {}
         rng = shared if i < 5 else np.random.default_rng(4100 + i)
         nv, sm = HEAD_VARIANTS[variant]
-        cfg = tiny_cfg(num_image_tokens=T, use_vision_ar=use_ar, normalize_vision=nv, apply_softmax=sm)
+        cfg = tiny_cfg(num_image_tokens=T, use_vision_ar=use_ar, normalize_vision=nv, apply_softmax=sm, tokenizer_padding_side=side, **extra)
         sd = init_state_dict(cfg, seed=43)
         ids, lab = e2e_batch(kind)
         pad_id = 128001
@@ -405,7 +416,7 @@ def gen_e2e():
         msk_t = ids_t.ne(pad_id)
         n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
-        suffix = "" if variant == "cos" else "_" + variant
+        suffix = ("" if variant == "cos" else "_" + variant) + ("" if side == "right" else "_" + side) + "".join("_" + str(v) for v in extra.values())
         for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             model = build_reference(cfg, sd, dt)
             for n, p in model.named_parameters():
@@ -413,7 +424,9 @@ def gen_e2e():
             out = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images.to(dt))
             rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, images=images,
                        seed=np.int64(43), rows_per_image=np.int64(T), use_vision_ar=np.int64(use_ar),
-                       normalize_vision=np.int64(nv), apply_softmax=np.int64(sm),
+                       normalize_vision=np.int64(nv), apply_softmax=np.int64(sm), left=np.int64(side == "left"),
+                       mm_projector_type=np.array(cfg.mm_projector_type), image_token_reduction=np.array(cfg.image_token_reduction),
+                       target_features_shape=np.array(model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images.to(dt))[7].shape),
                        loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language),
                        loss_image_ar=np.float64(model.loss_image_ar),
                        logits_sub=out.logits[:, :, ::997], hidden=out.hidden_states)

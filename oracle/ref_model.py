@@ -56,6 +56,7 @@ class OracleConfig:
     tokenizer_model_max_length: int | None = 4096
     tokenizer_padding_side: str = "right"
     image_start_id: int = IMAGE_START_ID
+    image_token_reduction: str = "interpolation"       # | "mlpmixer" | "concat_interpolation" (siglip_encoder.py:151-204)
 
     @property
     def head_dim(self):
@@ -95,7 +96,20 @@ def vision_features(sd, cfg: OracleConfig, images: torch.Tensor, train_vision: b
     torch.set_grad_enabled(not freeze_vision) (reference siglip_encoder.py:138-139)."""
     with torch.set_grad_enabled(train_vision):
         f = siglip_hidden(sd, cfg, images).to(images.dtype)
-        f = ops.bilinear_reduce(f, cfg.num_image_tokens)
+        if f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "mlpmixer":
+            # token_mixer = Linear(P, T) over the patch axis, then channel_mixer = Linear(hv, hv)  (siglip_encoder.py:164-168)
+            p = "model.vision_tower."
+            f = ops.linear(f.transpose(1, 2), sd[p + "token_mixer.0.weight"], sd[p + "token_mixer.0.bias"]).transpose(1, 2)
+            f = ops.linear(f, sd[p + "channel_mixer.0.weight"], sd[p + "channel_mixer.0.bias"])
+        elif f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "concat_interpolation":
+            # bilinear to 4 T tokens, then every 2 x 2 block of the grid concatenated along the channels (siglip_encoder.py:169-199)
+            N, _, C = f.shape
+            s = int(math.isqrt(cfg.num_image_tokens))
+            g = ops.bilinear_reduce(f, 4 * cfg.num_image_tokens).view(N, 2 * s, 2 * s, C)
+            g = g.view(N, s, 2, s, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, s * s, 4 * C)
+            f = g
+        else:
+            f = ops.bilinear_reduce(f, cfg.num_image_tokens)
         if cfg.normalize_vision:
             f = ops.l2_normalize(f)
         if cfg.apply_softmax:
@@ -120,6 +134,9 @@ def mm_projector(sd, cfg: OracleConfig, feat):
         return ops.linear(feat, sd["model.mm_projector.weight"], sd["model.mm_projector.bias"])
     if t == "identity":
         return feat
+    if t == "mlpsoftmax":                                    # Linear -> Softmax(dim=-1) -> Linear (multimodal_projector/builder.py:45-50)
+        z = ops.linear(feat, sd["model.mm_projector.0.weight"], sd["model.mm_projector.0.bias"])
+        return ops.linear(torch.softmax(z, dim=-1), sd["model.mm_projector.2.weight"], sd["model.mm_projector.2.bias"])
     if t.startswith("mlp") and t.endswith("x_gelu"):
         return _mlp(sd, "model.mm_projector.", feat, int(t[3:-6]))
     raise ValueError(f"Unknown projector type: {t}")
@@ -240,8 +257,8 @@ def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, re
     if cfg.apply_softmax:
         l_img = ops.soft_ce_loss(tgt, pred)
     elif cfg.normalize_vision:
-        if tgt.shape[0] != pred.shape[0]:
-            l_img = ce                                         # the try/except at :451-455
+        if tgt.shape != pred.shape:
+            l_img = ce                                         # the try/except at :451-455 (row count or -- concat_interpolation -- width)
         else:
             l_img = ops.cosine_loss(tgt, pred)
     else:
@@ -369,15 +386,16 @@ def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: floa
         sd[p + "input_layernorm.weight"] = norm_w(h)
         sd[p + "post_attention_layernorm.weight"] = norm_w(h)
     sd["model.norm.weight"] = norm_w(h)
-    hv = cfg.v_hidden
-    n_lin = {"linear": 1, "identity": 0}.get(cfg.mm_projector_type)
+    hv = cfg.v_hidden                                     # tower feature width = vision_head output width (reference literal 1152)
+    hv_mm = hv * (4 if cfg.image_token_reduction == "concat_interpolation" else 1)              # mm_hidden_size: projector input
+    n_lin = {"linear": 1, "identity": 0, "mlpsoftmax": 2}.get(cfg.mm_projector_type)
     if n_lin is None:
         n_lin = int(cfg.mm_projector_type[3:-6])
     if cfg.mm_projector_type == "linear":
-        sd["model.mm_projector.weight"] = rnd(h, hv); sd["model.mm_projector.bias"] = rnd(h)
+        sd["model.mm_projector.weight"] = rnd(h, hv_mm); sd["model.mm_projector.bias"] = rnd(h)
     else:
         for j in range(n_lin):
-            sd[f"model.mm_projector.{2 * j}.weight"] = rnd(h, hv if j == 0 else h)
+            sd[f"model.mm_projector.{2 * j}.weight"] = rnd(h, hv_mm if j == 0 else h)
             sd[f"model.mm_projector.{2 * j}.bias"] = rnd(h)
     sd["model.vision_proj.weight"] = rnd(h, 4096)       # dead Linear(4096, h), metamorph_arch.py:31
     sd["model.vision_proj.bias"] = rnd(h)
@@ -396,6 +414,11 @@ def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: floa
     if with_vision:
         vp = "model.vision_tower.vision_tower."
         P = (cfg.v_image // cfg.v_patch) ** 2
+        if cfg.image_token_reduction == "mlpmixer":
+            sd["model.vision_tower.token_mixer.0.weight"] = rnd(cfg.num_image_tokens, P, s=0.2)
+            sd["model.vision_tower.token_mixer.0.bias"] = rnd(cfg.num_image_tokens, s=0.2)
+            sd["model.vision_tower.channel_mixer.0.weight"] = rnd(hv, hv)
+            sd["model.vision_tower.channel_mixer.0.bias"] = rnd(hv)
         sd[vp + "embeddings.patch_embedding.weight"] = rnd(hv, 3, cfg.v_patch, cfg.v_patch)
         sd[vp + "embeddings.patch_embedding.bias"] = rnd(hv)
         sd[vp + "embeddings.position_embedding.weight"] = rnd(P, hv)

@@ -42,6 +42,7 @@ def hip_model(cfg: OracleConfig, sd, **kw):
                num_attention_heads=cfg.v_heads, image_size=cfg.v_image, patch_size=cfg.v_patch, layer_norm_eps=cfg.v_ln_eps)
     return build_model(llm, geo, num_image_tokens=cfg.num_image_tokens, use_vision_ar=cfg.use_vision_ar,
                        normalize_vision=cfg.normalize_vision, apply_softmax=cfg.apply_softmax, image_start_id=cfg.image_start_id,
+                       mm_projector_type=cfg.mm_projector_type, image_token_reduction=cfg.image_token_reduction,
                        vision_coef=cfg.vision_coef, max_length=cfg.tokenizer_model_max_length,
                        padding_side=cfg.tokenizer_padding_side, state_dict=sd, device=DEV, **kw)
 
@@ -105,7 +106,9 @@ def test_e2e_forward_backward(path):
     g = np.load(path)
     g32 = np.load(path.replace("_bf16", "_f32"))
     cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), use_vision_ar=bool(int(g["use_vision_ar"])),
-                   normalize_vision=bool(int(g["normalize_vision"])), apply_softmax=bool(int(g["apply_softmax"])))
+                   normalize_vision=bool(int(g["normalize_vision"])), apply_softmax=bool(int(g["apply_softmax"])),
+                   tokenizer_padding_side="left" if int(g["left"]) else "right", mm_projector_type=str(g["mm_projector_type"]),
+                   image_token_reduction=str(g["image_token_reduction"]))
     sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16)
     model = hip_model(cfg, sd)
     model.train()
@@ -137,6 +140,7 @@ def test_e2e_forward_backward(path):
     o32 = oracle_forward(init_state_dict(cfg, seed=int(g["seed"])), cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]),
                          T(g["images"]), return_logits=False)
     mask = o32["attention_mask"]
+    assert torch.equal(mask, torch.zeros_like(mask)) is False and (not int(g["left"]) or bool(mask[:, -1].all()))   # left: valid rows end at L
     e_hip = rel(hs[mask], T(g32["hidden"])[mask])
     e_ref = rel(T(g["hidden"])[mask], T(g32["hidden"])[mask])
     print(f"   hidden rel err vs fp32: hip={e_hip:.4e} reference-bf16={e_ref:.4e}")

@@ -95,6 +95,9 @@ def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path):
     # first moments after two identical steps: m = 0.1 * (0.9 g1 + g2) * coef -- equal to bf16-noise level over the whole shard
     zr = opt
     assert float((z.exp_avg - zr.exp_avg).norm() / zr.exp_avg.norm()) < 2e-3
+    from metamorph_amd import functional as F
+    F.set_layer_grad_hook(None)
+    F.set_param_ready_hook(None)
 
 
 def test_gradient_checkpointing_recompute_is_bit_identical():
@@ -116,7 +119,7 @@ def test_gradient_checkpointing_recompute_is_bit_identical():
         out = model(**batch)
         out.loss.backward()
         grads.append((float(out.loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
-    assert grads[0][0] == grads[1][0]
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])      # the scalar loss is an fp32 atomicAdd over rows: equal to rounding
     assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 40
     for n in grads[0][1]:
         assert torch.equal(grads[0][1][n], grads[1][1][n]), n
