@@ -267,7 +267,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if (args.gpus > 1 or os.environ.get("MM355_BENCH_SELF_LAUNCH") == "1") and "RANK" not in os.environ:   # (=1: exercise the launcher on one GPU)
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU over RCCL), exactly the command line the
         # docstring gives; rank 0 of the child job prints the ONE JSON line on this process's stdout
         return self_launch(args.gpus)
