@@ -40,6 +40,9 @@ typedef __attribute__((address_space(3))) s16x4* lds4_t;
 // X[row0 + fq*4 + e][c16*16 + fr] (e < 4) and X[row0 + 16 + fq*4 + e - 4][c16*16 + fr] (e >= 4) from a natural tile
 template <int DS>
 MM_DEV bf16x8 read_nat_perm(const unsigned char* s, int row0, int c16, int fr, int fq) {
+#ifdef MM355_ABLATE_TR        // TIMING-ONLY ablation build (wrong results): what would a ds_read_b128 in place of the two tr_b64 gathers buy?
+    return *(const bf16x8*)(s + offN<DS>(row0 + fr, c16 * 2 + (fq & 1)) + (fq >> 1) * 8 * DS * 2 * 0);
+#endif
     const int j = fr >> 2, q4 = fr & 3;
     const int chunk = c16 * 2 + (q4 >> 1), sub = (q4 & 1) * 8;
     const int r_lo = row0 + fq * 4 + j, r_hi = r_lo + 16;

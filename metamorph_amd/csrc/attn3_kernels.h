@@ -143,12 +143,14 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
 
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
+#ifndef MM355_ABL_NOSYNC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile t have landed
         __builtin_amdgcn_s_barrier();                        // everybody's have; everybody is done with tile t-1
         if (t + 1 < ntiles) {
             dma_tile(kbase, a.ld_k, kv0 + 64, L, ts, smem + ((t + 1) & 1) * TILE, wave, lane);
             dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
         }
+#endif
         const unsigned char* sK = smem + (t & 1) * TILE;
         const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
         // a wave whose rows all precede this tile (causal) has nothing to do here
@@ -166,11 +168,21 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
             for (int j = 0; j < 4; ++j) {
                 const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+                for (int rq = 0; rq < RQ; ++rq) {
+#ifdef MM355_ABL_NOQK                                        // timing-only ablation builds (tools/): see DESIGN section 4
+                    asm volatile("" :: "v"(kf));
+                    st[rq][j][0] += (float)kk;
+#else
+                    st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+#endif
+                }
             }
         const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
+#ifdef MM355_ABL_NOSM
+            continue;
+#endif
             if (need_mask) {
                 const int qg = qw0 + rq * 16 + fr;
                 const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
@@ -199,7 +211,11 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+#ifdef MM355_ABL_NOEXP
+                    const float p = fmaf(st[rq][j][r], sl2, -mref);
+#else
                     const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
+#endif
                     st[rq][j][r] = p;
                     rs += p;
                 }
@@ -214,7 +230,14 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
             for (int j = 0; j < NF; ++j) {
                 const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);          // V^T[d][keys perm]
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+                for (int rq = 0; rq < RQ; ++rq) {
+#ifdef MM355_ABL_NOPV
+                    asm volatile("" :: "v"(va), "v"(pb[rq]));
+                    ot[rq][j][0] += (float)kk;
+#else
+                    ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+#endif
+                }
             }
         }
     }

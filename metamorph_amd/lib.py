@@ -11,7 +11,7 @@ import re
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libmm355.so")
+LIB_PATH = os.environ.get("MM355_LIB_PATH") or os.path.join(PKG, "lib", "libmm355.so")   # (override: timing-only ablation builds, tools/)
 HEADER = os.path.join(os.path.dirname(PKG), "include", "mm355.h")
 
 
