@@ -62,14 +62,18 @@ MM_DEV void swap32(float& a, float& b) {
     const unsigned r0 = r[0], r1 = r[1];
     a = __uint_as_float(r0); b = __uint_as_float(r1);
 }
+// single-instruction maxima: fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max x, x in front of every operand
+// (IEEE sNaN quieting) -- three instructions where one does; scores are finite or -inf here
+MM_DEV float max2_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+MM_DEV float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 MM_DEV float quad_max(float x) {
     float a = x, b = x;
     asm volatile("" : "+v"(b));
     swap16(a, b);
-    a = fmaxf(a, b); b = a;
+    a = max2_raw(a, b); b = a;
     asm volatile("" : "+v"(b));
     swap32(a, b);
-    return fmaxf(a, b);
+    return max2_raw(a, b);
 }
 MM_DEV float quad_sum(float x) {
     float a = x, b = x;

@@ -191,9 +191,14 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
             }
-            float mx = fmaxf(fmaxf(st[rq][0][0], st[rq][0][1]), fmaxf(st[rq][0][2], st[rq][0][3]));
-#pragma unroll
-            for (int j = 1; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(st[rq][j][0], st[rq][j][1]), fmaxf(st[rq][j][2], st[rq][j][3])));
+            float mx = max3_raw(st[rq][0][0], st[rq][0][1], st[rq][0][2]);                 // 16 values: 8 v_max3 / v_max
+            mx = max3_raw(mx, st[rq][0][3], st[rq][1][0]);
+            mx = max3_raw(mx, st[rq][1][1], st[rq][1][2]);
+            mx = max3_raw(mx, st[rq][1][3], st[rq][2][0]);
+            mx = max3_raw(mx, st[rq][2][1], st[rq][2][2]);
+            mx = max3_raw(mx, st[rq][2][3], st[rq][3][0]);
+            mx = max3_raw(mx, st[rq][3][1], st[rq][3][2]);
+            mx = max2_raw(mx, st[rq][3][3]);
             mx = quad_max(mx) * sl2;                         // max of the RAW scores (scale > 0 commutes with max)
             // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew by more
             // than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR)
