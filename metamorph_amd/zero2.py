@@ -215,7 +215,13 @@ class Zero2AdamW(torch.optim.Optimizer):
     def enable_overlap(self):
         """Route DecoderLayerFn's "layer gradients are final" announcements to this optimizer."""
         from . import functional as F
-        F.set_layer_grad_hook(lambda layer: self.notify_segment_ready(getattr(layer, "_mm_segment", None)))
+        mine = {id(p) for p in self.params}
+
+        def done(layer):                                     # the hook is process-wide: ignore layers of any other model
+            p0 = next(layer.parameters(), None)
+            if p0 is not None and id(p0) in mine:
+                self.notify_segment_ready(getattr(layer, "_mm_segment", None))
+        F.set_layer_grad_hook(done)
         if self.async_update:
             self.enable_async_wait()
         return self

@@ -63,7 +63,7 @@ class _Slot:
 
 class Zero3AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, process_group=None,
-                 shard_update=None, sumsq=None, clip_coef=None, accumulate=None, param_slots=3, grad_slots=2):
+                 shard_update=None, sumsq=None, clip_coef=None, accumulate=None, param_slots=3, grad_slots=2, min_shard_numel=1 << 20):
         params = list(params)
         if params and isinstance(params[0], dict):
             groups = [dict(g, params=[p for p in g["params"] if p.requires_grad]) for g in params]
@@ -86,6 +86,9 @@ class Zero3AdamW(torch.optim.Optimizer):
         self._accumulate = accumulate or _hip_accumulate
         self._step = 0
         self._n_param_slots, self._n_grad_slots = max(2, int(param_slots)), max(1, int(grad_slots))
+        # a decoder-layer run smaller than this stays resident (parameter groups cut a layer into runs: with the reference's decay /
+        # no-decay groups the two norm weights of a layer form their own 2 x h run -- not worth a full-size slot and a collective)
+        self._min_shard = int(min_shard_numel)
         self._layout([p for g in self.param_groups for p in g["params"]])
         self._hooked = False
 
@@ -114,13 +117,13 @@ class Zero3AdamW(torch.optim.Optimizer):
                 offs.append(pos)
                 pos += p.numel()
             segs.append({"key": key[0], "group": key[1], "params": ps, "offs": offs, "shapes": [tuple(p.shape) for p in ps], "n": n, "m": m,
-                         "so": so, "sharded": key[0] is not None})
+                         "so": so, "sharded": key[0] is not None and n_raw >= self._min_shard})
             so += m
         self.segs = segs
         self.shard = so
-        self.seg_of_key = {}
+        self.seg_of_key = {}                                # layer key -> its SHARDED segments
         for i, sg in enumerate(segs):
-            if sg["key"] is not None:
+            if sg["sharded"]:
                 self.seg_of_key.setdefault(sg["key"], []).append(i)
         self.layer_order = [i for i, sg in enumerate(segs) if sg["sharded"]]           # forward walk order
         max_n = max([segs[i]["n"] for i in self.layer_order], default=0)
@@ -175,6 +178,9 @@ class Zero3AdamW(torch.optim.Optimizer):
             return self._pslot_of[i]
         # victim: a free slot, else the least recently used one that is not protected (the layer being computed right now)
         cands = [sl for sl in self._pslots if sl.seg is None] or [sl for sl in self._pslots if sl.seg not in protect]
+        if not cands:                                        # a layer with more sharded runs than slots: grow the pool
+            cands = [_Slot(torch.empty_like(self._pslots[0].buf))]
+            self._pslots.append(cands[0])
         slot = min(cands, key=lambda sl: sl.stamp)
         slot.stamp = self._p_rr
         if slot.seg is not None:
@@ -226,13 +232,16 @@ class Zero3AdamW(torch.optim.Optimizer):
     def _attach_grad_slot(self, i):
         if i in self._gslot_of:
             return
-        slot = self._gslots[self._g_rr % len(self._gslots)]
+        free = [sl for sl in self._gslots if sl.seg is None]
+        if not free:                                         # more runs of one layer in flight than slots: grow the pool
+            free = [_Slot(torch.empty_like(self._gslots[0].buf))]
+            self._gslots.append(free[0])
+        slot = min(free, key=lambda sl: sl.stamp)
         self._g_rr += 1
+        slot.stamp = self._g_rr
         if slot.work is not None:                            # the reduce-scatter that last read this buffer
             slot.work()
             slot.work = None
-        if slot.seg is not None:
-            self._gslot_of.pop(slot.seg, None)
         sg = self.segs[i]
         slot.seg = i
         self._gslot_of[i] = slot
@@ -292,11 +301,21 @@ class Zero3AdamW(torch.optim.Optimizer):
         "layer X's backward is finished" -> reduce-scatter."""
         from . import functional as F
 
+        mine = {id(p) for p in self.params}
+
+        def owns(layer):                                     # the hooks are process-wide: ignore layers of any other model
+            p0 = next(layer.parameters(), None) if layer is not None else None
+            return p0 is not None and id(p0) in mine
+
         def ready(layer, backward=False):
-            if layer is not None:
+            if owns(layer):
                 self.ensure_params(getattr(layer, "_mm_segment", None), backward=backward)
+
+        def done(layer):
+            if owns(layer):
+                self.layer_backward_done(getattr(layer, "_mm_segment", None))
         F.set_param_ready_hook(ready)
-        F.set_layer_grad_hook(lambda layer: self.layer_backward_done(getattr(layer, "_mm_segment", None)))
+        F.set_layer_grad_hook(done)
         self._hooked = True
         return self
 

@@ -39,7 +39,8 @@ def _collator():
     return DataCollatorForSupervisedDataset(tokenizer=FakeTokenizer(model_max_length=64))
 
 
-def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path):
+@pytest.mark.parametrize("zero_stage", [2, 3])
+def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path, zero_stage):
     from transformers import TrainingArguments
     from metamorph_amd.trainer import MetaMorphTrainer
     from metamorph_amd.zero2 import Zero2AdamW, tag_segments
@@ -57,10 +58,20 @@ def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path):
                              gradient_checkpointing=True, report_to=[], save_strategy="no", logging_steps=1,
                              remove_unused_columns=False, dataloader_num_workers=0, dataloader_pin_memory=False)
     model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
-    trainer = SeqTrainer(model=model, args=args, train_dataset=ds, data_collator=collate)
+    # zero_stage=3: the reference's scripts/zero3.json recipe -- decoder-layer parameters sharded, gathered per layer through the hooks
+    trainer = SeqTrainer(model=model, args=args, train_dataset=ds, data_collator=collate, zero_stage=zero_stage,
+                         zero2_kwargs=dict(min_shard_numel=1) if zero_stage == 3 else None)
     out = trainer.train()
     z = trainer._zero2()
-    assert isinstance(z, Zero2AdamW) and z._step == 2
+    from metamorph_amd.zero3 import Zero3AdamW
+    assert isinstance(z, Zero3AdamW if zero_stage == 3 else Zero2AdamW) and z._step == 2
+    from metamorph_amd import functional as F
+    F.set_layer_grad_hook(None)
+    F.set_param_ready_hook(None)
+    if zero_stage == 3:                                     # compare the gathered full parameters below
+        full = z.gather_full_parameters()
+        for p_, t_ in full.items():
+            p_.data = t_
     assert model.model.gradient_checkpointing and model.is_gradient_checkpointing    # HF's gradient_checkpointing_enable() was honoured
     assert type(trainer.model_wrapped) is type(model)                                 # no DDP / DataParallel wrapper
     assert np.isfinite(out.training_loss)
@@ -89,12 +100,16 @@ def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path):
         if p.requires_grad:
             a, b = p.data.float(), q.data.float()
             same, rel_l2 = float((a == b).float().mean()), float((a - b).norm() / b.norm().clamp_min(1e-20))
-            if same < 0.999 or rel_l2 > 1e-3:
+            # (ZeRO-3 folds every micro-step's reduce-scattered bf16 slice into the gradient shard: one more bf16 rounding per micro-step
+            # than ZeRO-2's in-epilogue accumulation, so with accumulation 3 its parameters agree to bf16 noise, not bit for bit)
+            lim_same, lim_rel = (0.999, 1e-3) if zero_stage == 2 else (0.85, 3e-3)
+            if same < lim_same or rel_l2 > lim_rel:
                 bad.append((n, same, rel_l2))
     assert not bad, f"Trainer-driven (checkpointed) and hand-written steps differ (name, fraction bit-equal, rel L2): {bad[:8]} ({len(bad)} tensors)"
     # first moments after two identical steps: m = 0.1 * (0.9 g1 + g2) * coef -- equal to bf16-noise level over the whole shard
     zr = opt
-    assert float((z.exp_avg - zr.exp_avg).norm() / zr.exp_avg.norm()) < 2e-3
+    if zero_stage == 2:
+        assert float((z.exp_avg - zr.exp_avg).norm() / zr.exp_avg.norm()) < 2e-3
     from metamorph_amd import functional as F
     F.set_layer_grad_hook(None)
     F.set_param_ready_hook(None)

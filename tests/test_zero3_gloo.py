@@ -77,7 +77,7 @@ def _worker(rank, world, port, tmp):
         model = _build()
         params = [p for p in model.parameters() if p.requires_grad]
         opt = Zero3AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0, shard_update=_oracle_update,
-                         sumsq=_oracle_sumsq, clip_coef=_oracle_clip, accumulate=_accum, param_slots=2, grad_slots=1).enable_hooks()
+                         sumsq=_oracle_sumsq, clip_coef=_oracle_clip, accumulate=_accum, param_slots=2, grad_slots=1, min_shard_numel=1).enable_hooks()
         layers = model.get_model().layers
         assert len(opt.layer_order) == 4 and all(opt.segs[i]["m"] * world == opt.segs[i]["n"] for i in opt.layer_order)
         # released layers hold no storage; resident tensors do
@@ -141,11 +141,47 @@ def test_zero3_single_process_matches_zero2():
         kw = dict(lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0, shard_update=_oracle_update, sumsq=_oracle_sumsq,
                   clip_coef=_oracle_clip)
         if cls is Zero3AdamW:
-            opt = cls(params, accumulate=_accum, **kw).enable_hooks()
+            opt = cls(params, accumulate=_accum, min_shard_numel=1, **kw).enable_hooks()
         else:
             opt = cls(params, **kw).enable_overlap()
         try:
             for step in (1, 2, 3):
+                opt.zero_grad()
+                _walk(model, opt, step, 0, 0, F, cls is Zero3AdamW)
+                opt.step()
+            if cls is Zero3AdamW:
+                full = opt.gather_full_parameters()
+                outs.append(torch.cat([(full[p] if p in full else p.data).reshape(-1) for p in params]))
+            else:
+                outs.append(torch.cat([p.data.reshape(-1) for p in params]))
+        finally:
+            F.set_param_ready_hook(None)
+            F.set_layer_grad_hook(None)
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-6, atol=1e-7)
+
+
+def test_zero3_with_decay_groups_cutting_through_the_layers():
+    """The reference's optimizer groups (weight decay off for norm weights and biases, metamorph_trainer.py:170-245) cut every decoder
+    layer into two runs: the Linear weights (sharded) and the two norm weights (2 x h elements: below `min_shard_numel`, they stay
+    resident).  Same parameters as Zero2AdamW on the same groups."""
+    from metamorph_amd import functional as F
+    from metamorph_amd.trainer import optimizer_grouped_parameters
+    from metamorph_amd.zero2 import Zero2AdamW
+    from metamorph_amd.zero3 import Zero3AdamW
+    outs = []
+    for cls in (Zero3AdamW, Zero2AdamW):
+        model = _build()
+        groups = optimizer_grouped_parameters(model, 0.1)
+        params = [p for g in groups for p in g["params"]]
+        kw = dict(lr=1e-2, betas=(0.9, 0.95), max_grad_norm=1.0, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
+        if cls is Zero3AdamW:
+            opt = cls(groups, accumulate=_accum, min_shard_numel=4096, grad_slots=1, **kw).enable_hooks()
+            layer_segs = [sg for sg in opt.segs if sg["key"] is not None]
+            assert len(layer_segs) == 8 and sum(sg["sharded"] for sg in layer_segs) == 4          # 4 layers x (weights | norms)
+        else:
+            opt = cls(groups, **kw).enable_overlap()
+        try:
+            for step in (1, 2):
                 opt.zero_grad()
                 _walk(model, opt, step, 0, 0, F, cls is Zero3AdamW)
                 opt.step()

@@ -34,7 +34,7 @@ def _train(stage, steps=3, accum=1, ckpt=False, clip=0.0, layers=3, param_slots=
     tag_segments(model)
     params = [p for p in model.parameters() if p.requires_grad]
     if stage == 3:
-        opt = Zero3AdamW(params, lr=1e-3, max_grad_norm=clip, param_slots=param_slots, grad_slots=1).enable_hooks()
+        opt = Zero3AdamW(params, lr=1e-3, max_grad_norm=clip, param_slots=param_slots, grad_slots=1, min_shard_numel=1).enable_hooks()
     else:
         opt = Zero2AdamW(params, lr=1e-3, max_grad_norm=clip).enable_overlap()
     losses = []
