@@ -132,4 +132,7 @@ class MetaMorphTrainer(Trainer):
     def _save(self, output_dir=None, state_dict=None):
         if getattr(self.args, "tune_mm_mlp_adapter", False):
             return
+        z = self._zero2()
+        if state_dict is None and isinstance(z, Zero3AdamW):    # the module tree holds no decoder-layer weights between steps: gather
+            state_dict = {k: v.cpu() for k, v in z.full_state_dict(self.model).items()}
         super()._save(output_dir, state_dict)

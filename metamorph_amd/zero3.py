@@ -440,6 +440,40 @@ class Zero3AdamW(torch.optim.Optimizer):
                 out[p] = full[o:o + n].view(shp)
         return out
 
+    # ------------------------------------------------------------------ checkpointing of the rank's shard
+    def state_dict(self):
+        self.synchronize()
+        return {"step": self._step, "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "world": self.world,
+                "rank": self.rank, "total": self.total, "zero_stage": 3,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        if sd["world"] != self.world or sd["total"] != self.total:
+            raise ValueError("Zero3AdamW shard checkpoint was written with a different world size / parameter set")
+        self._step = sd["step"]
+        self.master.copy_(sd["master"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+        # the bf16 parameters follow the restored master weights
+        for sg in self.segs:
+            dst = sg["p_shard"] if sg["sharded"] else sg["my_param"]
+            dst.copy_(self.master[sg["so"]:sg["so"] + sg["m"]].to(dst.dtype))
+        self.release_params()
+
+    def full_state_dict(self, model):
+        """model.state_dict() with the sharded decoder layers gathered (`stage3_gather_16bit_weights_on_model_save`): what
+        `save_pretrained` must be given under ZeRO-3, where the module tree itself holds no layer weights between steps."""
+        full = self.gather_full_parameters()
+        by_id = {id(p): t for p, t in full.items()}
+        out = {}
+        names = {id(p): n for n, p in model.named_parameters()}
+        for name, t in model.state_dict(keep_vars=True).items():
+            out[name] = by_id.get(id(t), t).detach()
+        assert all(names[i] in out for i in by_id)
+        return out
+
     def memory_report(self):
         """Bytes held by this rank, by role."""
         e = self.master.element_size()
