@@ -55,7 +55,7 @@ def grad_summary(t):
 
 
 def rel(a, b):
-    a, b = a.float().cpu(), b.float().cpu()
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-12))
 
 
