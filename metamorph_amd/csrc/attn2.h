@@ -51,6 +51,20 @@ MM_DEV bf16x8 read_nat_perm(const unsigned char* s, int row0, int c16, int fr, i
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same gather with the lane-dependent part of the address hoisted: nat_perm_off() is loop-invariant per 16-column group c16
+// (one VGPR each); a tile row block row0 (a multiple of 8, so the swizzle phase is unchanged) and the +16-row half are
+// immediates of the two reads.
+template <int DS> MM_DEV int nat_perm_off(int c16, int fr, int fq) {
+    const int j = fr >> 2, q4 = fr & 3;
+    return offN<DS>(fq * 4 + j, c16 * 2 + (q4 >> 1)) + (q4 & 1) * 8;
+}
+template <int DS> MM_DEV bf16x8 read_nat_perm_at(const unsigned char* s, int row0, int off) {
+    const unsigned char* p = s + row0 * (DS * 2) + off;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p + 16 * DS * 2));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // all-reduce over the four lanes {l, l^16, l^32, l^48} that share one query column, on the VALU (v_permlane*_swap), no LDS
 MM_DEV void swap16(float& a, float& b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);

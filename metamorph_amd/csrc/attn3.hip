@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512) void fwd_pp_kernel(Args a) {
     const int grp = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
     int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, inner_heads(a.Hq, a.Hq / a.Hkv), true, xb, hq, b);
     const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     const int fr = lane & 15, fq = lane >> 4;
     const int group = a.Hq / a.Hkv;
     int xb, hk, b;
-    block_coords((a.L + 63) / 64, a.Hkv, false, xb, hk, b);        // one block per KV head: it walks the query heads of its group
+#ifndef MM355_DKDV_INNER
+#define MM355_DKDV_INNER inner_heads(a.Hkv, 1)
+#endif
+    block_coords((a.L + 63) / 64, a.Hkv, MM355_DKDV_INNER, false, xb, hk, b);   // one block per KV head: it walks the query heads of its group
     const int kv0 = xb * 64;
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
@@ -308,7 +311,11 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     int k_off[4];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
+    int t_off[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) t_off[j] = nat_perm_off<DS>(j, fr, fq);
     const float sl2 = a.scale * LOG2E;
+    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2}, scv = f32x4{a.scale, a.scale, a.scale, a.scale};
     const int kg = mykey0 + fr;
 
     for (int it = 0, itq = 0; it < n_tot; ++it, itq = (itq + 1 == n_it ? 0 : itq + 1)) {
@@ -345,23 +352,24 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
                     }
             };
             auto soft = [&](int i) {                         // P in place of S, dS = P o (dP - delta) * scale in place of dP
-                const f32x4 l4 = *(const f32x4*)(sStat + i * 16 + fq * 4);
-                const f32x4 d4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4);
+                const f32x4 nl4 = *(const f32x4*)(sStat + i * 16 + fq * 4) * -LOG2E;           // packed fp32 throughout
+                const f32x4 nd4 = *(const f32x4*)(sStat + QT + i * 16 + fq * 4) * -a.scale;
+                f32x4 p = __builtin_elementwise_fma(s[i], sl2v, nl4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[i][r], sl2, -l4[r] * LOG2E));
-                    if (MASK) p = ((unsigned)(i * 16 + r - lo) < span) ? p : 0.f;
-                    s[i][r] = p;
-                    dp[i][r] = p * (dp[i][r] - d4[r]) * a.scale;
+                    p[r] = __builtin_amdgcn_exp2f(p[r]);
+                    if (MASK) p[r] = ((unsigned)(i * 16 + r - lo) < span) ? p[r] : 0.f;
                 }
+                s[i] = p;
+                dp[i] = p * __builtin_elementwise_fma(dp[i], scv, nd4);
             };
             auto grads = [&](int ks) {
                 const bf16x8 pa = pack_acc(s[2 * ks], s[2 * ks + 1]);
                 const bf16x8 dsa = pack_acc(dp[2 * ks], dp[2 * ks + 1]);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const bf16x8 dob8 = read_nat_perm<DS>(sDO, ks * 32, j, fr, fq);
-                    const bf16x8 qb8 = read_nat_perm<DS>(sQ, ks * 32, j, fr, fq);
+                    const bf16x8 dob8 = read_nat_perm_at<DS>(sDO, ks * 32, t_off[j]);
+                    const bf16x8 qb8 = read_nat_perm_at<DS>(sQ, ks * 32, t_off[j]);
                     dvacc[j] = mfma16(pa, dob8, dvacc[j]);
                     dkacc[j] = mfma16(dsa, qb8, dkacc[j]);
                 }

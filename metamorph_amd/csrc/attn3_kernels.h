@@ -13,6 +13,9 @@
 // Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
 #include "attn2.h"
 #include <type_traits>
+#ifndef MM355_FWD_VARIANT
+#define MM355_FWD_VARIANT 1
+#endif
 #include <cstdlib>
 
 namespace attn3 {
@@ -48,30 +51,37 @@ MM_DEV void dma_tile(const uint16_t* base, int64_t ld, int row0, int L, const Ti
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(tb + ts.off[i]), (lptr_t)(d0 + i * 1024), 16, 0, 0);
     } else {                                                 // ragged last tile: clamp the rows (masked by the caller)
+        const unsigned char* tb = (const unsigned char*)(base + (int64_t)row0 * ld);
+        const int last = L - 1 - row0;
+        const uint32_t ldb = (uint32_t)ld * 2u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (wave_s * 4 + i) * 4 + (lane >> 4);
             const int c = (lane & 15) ^ swzN<DS>(row);
-            const uint16_t* src = base + (int64_t)min(row0 + row, L - 1) * ld + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d0 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(tb + (uint32_t)min(row, last) * ldb + (uint32_t)(c * 16)), (lptr_t)(d0 + i * 1024), 16, 0, 0);
         }
     }
 }
 
 // 1-D grid -> (x, head, sample) with all blocks that share K / V (fwd, dQ: the query blocks of a GQA group) or Q / dO (dK/dV:
 // the key blocks of a query head) on ONE XCD, so the shared tiles stay in that XCD's 4-MiB L2: hardware deals consecutive
-// block ids round-robin over the 8 XCDs, so XCD x is given the x-th contiguous eighth of the logical order
-// (x fastest, then head, then sample).  `reverse` walks x downwards: causal work grows with the query block index (fwd, dQ)
-// and shrinks with the key block index (dK/dV); the heavy blocks go first either way.
-MM_DEV void block_coords(int nx, int Hq, bool reverse, int& x, int& hq, int& b) {
+// block ids round-robin over the 8 XCDs, so XCD x is given the x-th contiguous eighth of the logical order.
+// Logical order: `inner` heads fastest, then x, then the remaining heads, then the sample; `reverse` walks x downwards.  Causal
+// work grows with the query block index (fwd, dQ) and shrinks with the key block index (dK/dV): with x SLOWER than a few heads, the
+// heavy blocks of several heads start together and the light ones fill the tail.  (x fastest -- 15, 14, ..., 0 per head -- leaves
+// the last head's heaviest block to start late: 7 % / 13 % longer kernels in a dispatch simulation with measured block times.)
+MM_DEV void block_coords(int nx, int H, int inner, bool reverse, int& x, int& h, int& b) {
     const int total = gridDim.x, bid = blockIdx.x;
     const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    x = reverse ? nx - 1 - logical % nx : logical % nx;
-    const int rest = logical / nx;
-    hq = rest % Hq;
-    b = rest / Hq;
+    const int span = nx * inner, within = logical % span, rest = logical / span, outer = H / inner;
+    const int xx = within / inner;
+    x = reverse ? nx - 1 - xx : xx;
+    h = (rest % outer) * inner + within % inner;
+    b = rest / outer;
 }
+// heads walked fastest: the GQA group (its blocks share K / V), else four heads when they divide evenly
+MM_DEV int inner_heads(int H, int group) { return group > 1 ? group : ((H & 3) == 0 ? 4 : ((H & 1) == 0 ? 2 : 1)); }
 
 // ================================================================================================
 // forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
@@ -86,11 +96,15 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
     // PV(h-1) in one basic block) was slower still (1.34 ms: ~1 300 accumulator<->VGPR moves).  Kept as an opt-in A/B (MM355_ATTN_RQ=4).
     constexpr int KS = 4, NF = 8, ROWS = 16 * RQ, BQ = 4 * ROWS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
+#ifdef MM355_ATTN_TIMING                                     // TIMING-ONLY build: phase timestamps of wave 0 overwrite the block's lse rows
+    const long long tm0 = __builtin_readcyclecounter();
+    long long tm1 = 0, tmd = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, inner_heads(a.Hq, a.Hq / a.Hkv), true, xb, hq, b);
     const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
@@ -127,18 +141,23 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
         for (int kk = 0; kk < KS; ++kk) qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
     }
     f32x4 ot[RQ][NF];                                        // O^T[d = j*16 + fq*4 + r][q = fr]
-    float m_run[RQ], l_part[RQ];                             // l_part: this lane's share of the row sum
+    float m_run[RQ];
+    f32x4 l_part[RQ];                                        // this lane's share of the row sum, four partial sums (packed adds)
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) {
-        m_run[rq] = M_INIT; l_part[rq] = 0.f;
+        m_run[rq] = M_INIT; l_part[rq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NF; ++j) ot[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // LDS read offsets inside a tile: K rows (b128) and V gathers (tr_b64)
-    int k_off[4];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);        // + j * 16 rows = j * 4096 B (swizzle period 8 rows)
+    // LDS read offsets inside a tile.  K rows (b128): offN(fr, kk*4 + fq) = fr*256 + ((fq ^ swz(fr)) << 4 ^ kk << 6); V gathers (tr_b64):
+    // nat_perm_off(j) = row*256 + sub + ((hi ^ swz(row)) << 4 ^ j << 5).  Only the lane-constant halves live across the tile loop (four
+    // registers); the per-kk / per-j offsets are one v_xad_u32 each, re-derived per tile behind an opaque copy -- twelve loop-invariant
+    // address registers are what hipcc spills first (and a scratch reload carries a vmcnt(0) that serialises the LDS-DMA).
+    const int k_base = fr * (DS * 2), k_x = (fq ^ swzN<DS>(fr)) << 4;
+    const int v_row = fq * 4 + (fr >> 2);
+    const int v_base = v_row * (DS * 2) + (fr & 1) * 8, v_x = (((fr & 3) >> 1) ^ swzN<DS>(v_row)) << 4;
     const float sl2 = a.scale * LOG2E;                       // scores in log2 domain: exp2(s*sl2 - m)
+    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2};
     constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
 
     for (int t = 0; t < ntiles; ++t) {
@@ -151,22 +170,44 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
             dma_tile(vbase, a.ld_k, kv0 + 64, L, ts, smem + (2 + ((t + 1) & 1)) * TILE, wave, lane);
         }
 #endif
+#ifdef MM355_ATTN_TIMING
+        if (t == 0) tm1 = __builtin_readcyclecounter();
+        if (t == ntiles - 2) tmd = __builtin_readcyclecounter();
+#endif
         const unsigned char* sK = smem + (t & 1) * TILE;
         const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
         // a wave whose rows all precede this tile (causal) has nothing to do here
         if (a.causal && kv0 > qw0 + ROWS - 1) continue;
+        int k_off[4], v_off[NF];
+        {
+            int kx = k_x, vx = v_x;
+            asm volatile("" : "+v"(kx), "+v"(vx));           // keep the derivation inside the loop
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) k_off[kk] = (kx ^ (kk << 6)) + k_base;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) v_off[j] = (vx ^ (j << 5)) + v_base;
+        }
 
         f32x4 st[RQ][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Fragment reads are issued a whole phase ahead of their MFMAs: left to itself hipcc sinks every ds_read next to its use
+        // (read x4, wait, 2 MFMAs), which exposes one LDS round trip per MFMA pair.  All 16 K reads go out first; the 32 V gathers
+        // go out behind the score MFMAs, so that their latency is covered by the softmax.
+        bf16x8 kfr[KS][4];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kfr[kk][j] = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+        __builtin_amdgcn_sched_barrier(0);
         // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+                const bf16x8 kf = kfr[kk][j];
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) {
 #ifdef MM355_ABL_NOQK                                        // timing-only ablation builds (tools/): see DESIGN section 4
@@ -177,13 +218,12 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
 #endif
                 }
             }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef MM355_ABL_NOSM
         const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
+        if (need_mask) {
 #pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-#ifdef MM355_ABL_NOSM
-            continue;
-#endif
-            if (need_mask) {
+            for (int rq = 0; rq < RQ; ++rq) {
                 const int qg = qw0 + rq * 16 + fr;
                 const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
 #pragma unroll
@@ -191,41 +231,81 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
             }
-            float mx = max3_raw(st[rq][0][0], st[rq][0][1], st[rq][0][2]);                 // 16 values: 8 v_max3 / v_max
-            mx = max3_raw(mx, st[rq][0][3], st[rq][1][0]);
-            mx = max3_raw(mx, st[rq][1][1], st[rq][1][2]);
-            mx = max3_raw(mx, st[rq][1][3], st[rq][2][0]);
-            mx = max3_raw(mx, st[rq][2][1], st[rq][2][2]);
-            mx = max3_raw(mx, st[rq][2][3], st[rq][3][0]);
-            mx = max3_raw(mx, st[rq][3][1], st[rq][3][2]);
-            mx = max2_raw(mx, st[rq][3][3]);
-            mx = quad_max(mx) * sl2;                         // max of the RAW scores (scale > 0 commutes with max)
-            // deferred rescale: only move the running max (and touch the O accumulators) when some row's max grew by more
-            // than 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR)
-            if (__any(mx > m_run[rq] + RESCALE_THR)) {
-                const float mn = fmaxf(m_run[rq], mx);
+        }
+        float mx[RQ];
+        bool grow = false;
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            float m = max3_raw(st[rq][0][0], st[rq][0][1], st[rq][0][2]);                  // 16 values: 8 v_max3 / v_max
+            m = max3_raw(m, st[rq][0][3], st[rq][1][0]);
+            m = max3_raw(m, st[rq][1][1], st[rq][1][2]);
+            m = max3_raw(m, st[rq][1][3], st[rq][2][0]);
+            m = max3_raw(m, st[rq][2][1], st[rq][2][2]);
+            m = max3_raw(m, st[rq][2][3], st[rq][3][0]);
+            m = max3_raw(m, st[rq][3][1], st[rq][3][2]);
+            m = max2_raw(m, st[rq][3][3]);
+            mx[rq] = quad_max(m) * sl2;                      // max of the RAW scores (scale > 0 commutes with max)
+            grow |= mx[rq] > m_run[rq] + RESCALE_THR;
+        }
+        // deferred rescale: only move the running maxima (and touch the O accumulators) when some row's max grew by more than
+        // 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR).  ONE wave-uniform branch for both row
+        // groups, so that everything after it -- V gathers, exponentials, P V -- is a single basic block the scheduler can overlap.
+        if (__any(grow)) {
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+                const float mn = fmaxf(m_run[rq], mx[rq]);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
                 l_part[rq] *= alpha;
 #pragma unroll
                 for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
                 m_run[rq] = mn;
             }
-            const float mref = m_run[rq];
-            float rs = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#ifdef MM355_ABL_NOEXP
-                    const float p = fmaf(st[rq][j][r], sl2, -mref);
-#else
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
-#endif
-                    st[rq][j][r] = p;
-                    rs += p;
-                }
-            l_part[rq] += rs;
         }
+#endif
+        // the V gathers of the first 32 keys go out first: their LDS round trip is covered by the exponentials (those of the
+        // second 32 keys are issued beside the first half's MFMAs)
+        bf16x8 vfr[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) vfr[j] = read_nat_perm_at<DS>(sV, 0, v_off[j]);                   // V^T[d][keys perm]
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef MM355_ABL_NOSM
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            // exp2(s * sl2 - m) and the row sums on packed fp32 (v_pk_fma_f32 / v_pk_add_f32)
+            const float nm = -m_run[rq];
+            const f32x4 nmv = f32x4{nm, nm, nm, nm};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 x = __builtin_elementwise_fma(st[rq][j], sl2v, nmv);
+#ifndef MM355_ABL_NOEXP
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+#endif
+                st[rq][j] = x;
+            }
+            l_part[rq] += (st[rq][0] + st[rq][1]) + (st[rq][2] + st[rq][3]);
+        }
+#endif
+#if MM355_FWD_VARIANT == 2
+        bf16x8 pb[2][RQ];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) pb[kk][rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+        __builtin_amdgcn_sched_barrier(0);                   // (the scores are dead from here on: their registers hold the gathers)
+        bf16x8 vfr1[NF];                                     // second 32 keys: in flight beside the first half's MFMAs
+#pragma unroll
+        for (int j = 0; j < NF; ++j) vfr1[j] = read_nat_perm_at<DS>(sV, 32, v_off[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const bf16x8 va = kk == 0 ? vfr[j] : vfr1[j];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[kk][rq], ot[rq][j]);
+            }
+#else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 pb[RQ];
@@ -233,7 +313,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
             for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);          // V^T[d][keys perm]
+                const bf16x8 va = kk == 0 ? vfr[j] : read_nat_perm_at<DS>(sV, 32, v_off[j]);
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) {
 #ifdef MM355_ABL_NOPV
@@ -245,7 +325,11 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
                 }
             }
         }
+#endif
     }
+#ifdef MM355_ATTN_TIMING
+    const long long tm2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();                                         // ring is free: reuse it as the output staging area
 
     // epilogue: O = O^T / l  -> bf16 [q][d] in LDS -> row-contiguous 16-B stores
@@ -254,7 +338,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
     for (int rq = 0; rq < RQ; ++rq) {
         const int qg = qw0 + rq * 16 + fr;
         const bool valid = qg < seqlen;
-        const float l_run = quad_sum(l_part[rq]);
+        const float l_run = quad_sum((l_part[rq][0] + l_part[rq][1]) + (l_part[rq][2] + l_part[rq][3]));
         const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -271,6 +355,14 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
         const int qg = qw0 + r;
         if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
     }
+#ifdef MM355_ATTN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tm3 = __builtin_readcyclecounter();
+    if (tid == 0) {
+        long long* w = (long long*)(lse_base + q0);
+        w[0] = tm1 - tm0; w[1] = tmd - tm1; w[2] = tm2 - tmd; w[3] = tm3 - tm2; w[4] = ntiles; w[5] = xb; w[6] = tm0; w[7] = tm3;
+    }
+#endif
 }
 
 // ================================================================================================
@@ -285,7 +377,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, true, xb, hq, b);
+    block_coords((a.L + BQ - 1) / BQ, a.Hq, inner_heads(a.Hq, a.Hq / a.Hkv), true, xb, hq, b);
     const int q0 = xb * BQ;
     const int hk = hq / (a.Hq / a.Hkv);
     const int L = a.L;
@@ -333,7 +425,18 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
     int k_off[4];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
+    int t_off[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) t_off[j] = nat_perm_off<DS>(j, fr, fq);
     const float sl2 = a.scale * LOG2E;
+    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2}, scv = f32x4{a.scale, a.scale, a.scale, a.scale};
+    f32x4 nlse[RQ], ndel[RQ];                                // -lse (log2 domain), -delta * scale
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        nlse[rq] = f32x4{-lse2[rq], -lse2[rq], -lse2[rq], -lse2[rq]};
+        const float nd = -del[rq] * a.scale;
+        ndel[rq] = f32x4{nd, nd, nd, nd};
+    }
 
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
@@ -376,13 +479,15 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
                     }
                 }
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq)
+                for (int rq = 0; rq < RQ; ++rq) {            // dS^T = P^T o (dP^T - delta) * scale, on packed fp32
+                    f32x4 p = __builtin_elementwise_fma(st[rq][j], sl2v, nlse[rq]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -lse2[rq]));
-                        if (MASK) p = (j * 16 + r > lim[rq]) ? 0.f : p;
-                        st[rq][j][r] = p * (dpt[rq][r] - del[rq]) * a.scale;
+                        p[r] = __builtin_amdgcn_exp2f(p[r]);
+                        if (MASK) p[r] = (j * 16 + r > lim[rq]) ? 0.f : p[r];
                     }
+                    st[rq][j] = p * __builtin_elementwise_fma(dpt[rq], scv, ndel[rq]);
+                }
             }
         };
         if (need_mask) scores(std::true_type{}); else scores(std::false_type{});
@@ -393,7 +498,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
             for (int rq = 0; rq < RQ; ++rq) sb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const bf16x8 ka = read_nat_perm<DS>(sK, kk * 32, j, fr, fq);          // K^T[d][keys perm]
+                const bf16x8 ka = read_nat_perm_at<DS>(sK, kk * 32, t_off[j]);        // K^T[d][keys perm]
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) dqt[rq][j] = mfma16(ka, sb[rq], dqt[rq][j]);
             }

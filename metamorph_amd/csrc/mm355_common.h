@@ -21,7 +21,12 @@ MM_DEV uint16_t f2bf(float f) {                      // RNE, lowers to v_cvt_pk_
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
-MM_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// one v_cvt_pk_bf16_f32 (the scalar form costs two conversions, a shift and an or)
+typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mm_bf16x2 __attribute__((ext_vector_type(2)));
+MM_DEV uint32_t pack2bf(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(mm_f32x2{lo, hi}, mm_bf16x2));
+}
 MM_DEV float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 MM_DEV float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 MM_DEV float round_bf(float f) { return bf2f(f2bf(f)); }
