@@ -13,9 +13,6 @@
 // Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
 #include "attn2.h"
 #include <type_traits>
-#ifndef MM355_FWD_VARIANT
-#define MM355_FWD_VARIANT 1
-#endif
 #include <cstdlib>
 
 namespace attn3 {
@@ -83,6 +80,150 @@ MM_DEV void block_coords(int nx, int H, int inner, bool reverse, int& x, int& h,
 // heads walked fastest: the GQA group (its blocks share K / V), else four heads when they divide evenly
 MM_DEV int inner_heads(int H, int group) { return group > 1 ? group : ((H & 3) == 0 ? 4 : ((H & 1) == 0 ? 2 : 1)); }
 
+// One K / V tile of 64 keys for RQ 16-row groups of one wave: S^T = K Q^T, online softmax (log2 domain, deferred rescale), O^T += V^T P^T.
+struct FwdLane {
+    int fr, fq, k_base, k_x, v_base, v_x;
+    MM_DEV void init(int fr_, int fq_) {
+        fr = fr_; fq = fq_;
+        k_base = fr * (DS * 2); k_x = (fq ^ swzN<DS>(fr)) << 4;
+        const int v_row = fq * 4 + (fr >> 2);
+        v_base = v_row * (DS * 2) + (fr & 1) * 8; v_x = (((fr & 3) >> 1) ^ swzN<DS>(v_row)) << 4;
+    }
+};
+template <int RQ>
+MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, int qw0, int seqlen, int causal, float sl2, const FwdLane& ln,
+                     const bf16x8 (&qf)[RQ][4], f32x4 (&ot)[RQ][8], float (&m_run)[RQ], f32x4 (&l_part)[RQ]) {
+    constexpr int KS = 4, NF = 8;
+    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
+    const int fr = ln.fr, fq = ln.fq, k_base = ln.k_base, k_x = ln.k_x, v_base = ln.v_base, v_x = ln.v_x;
+    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2};
+    int k_off[4], v_off[NF];
+    {
+        int kx = k_x, vx = v_x;
+        asm volatile("" : "+v"(kx), "+v"(vx));           // keep the derivation inside the loop
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) k_off[kk] = (kx ^ (kk << 6)) + k_base;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) v_off[j] = (vx ^ (j << 5)) + v_base;
+    }
+
+    f32x4 st[RQ][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // all 16 K fragment reads go out ahead of the score MFMAs (left to itself hipcc sinks every ds_read next to its use and spends
+    // 256 registers on its own prefetch; this form needs 242 -- the two schedules time the same, profiles/r2_attn_persist_hoist_ab.log)
+    bf16x8 kfr[KS][4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kfr[kk][j] = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
+    __builtin_amdgcn_sched_barrier(0);
+    // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 kf = kfr[kk][j];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+#ifdef MM355_ABL_NOQK                                        // timing-only ablation builds (tools/): see DESIGN section 4
+                asm volatile("" :: "v"(kf));
+                st[rq][j][0] += (float)kk;
+#else
+                st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
+#endif
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef MM355_ABL_NOSM
+    const bool need_mask = (kv0 + 64 > seqlen) || (causal && kv0 + 63 > qw0);
+    if (need_mask) {
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            const int qg = qw0 + rq * 16 + fr;
+            const int lim = (causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
+        }
+    }
+    float mx[RQ];
+    bool grow = false;
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        float m = max3_raw(st[rq][0][0], st[rq][0][1], st[rq][0][2]);                  // 16 values: 8 v_max3 / v_max
+        m = max3_raw(m, st[rq][0][3], st[rq][1][0]);
+        m = max3_raw(m, st[rq][1][1], st[rq][1][2]);
+        m = max3_raw(m, st[rq][1][3], st[rq][2][0]);
+        m = max3_raw(m, st[rq][2][1], st[rq][2][2]);
+        m = max3_raw(m, st[rq][2][3], st[rq][3][0]);
+        m = max3_raw(m, st[rq][3][1], st[rq][3][2]);
+        m = max2_raw(m, st[rq][3][3]);
+        mx[rq] = quad_max(m) * sl2;                      // max of the RAW scores (scale > 0 commutes with max)
+        grow |= mx[rq] > m_run[rq] + RESCALE_THR;
+    }
+    // deferred rescale: only move the running maxima (and touch the O accumulators) when some row's max grew by more than
+    // 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR).  ONE wave-uniform branch for both row
+    // groups, so that everything after it -- V gathers, exponentials, P V -- is a single basic block the scheduler can overlap.
+    if (__any(grow)) {
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            const float mn = fmaxf(m_run[rq], mx[rq]);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
+            l_part[rq] *= alpha;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
+            m_run[rq] = mn;
+        }
+    }
+#endif
+    // the V gathers of the first 32 keys go out before the exponentials, which cover their LDS round trip
+    bf16x8 vfr[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) vfr[j] = read_nat_perm_at<DS>(sV, 0, v_off[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef MM355_ABL_NOSM
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+        // exp2(s * sl2 - m) and the row sums on packed fp32 (v_pk_fma_f32 / v_pk_add_f32)
+        const float nm = -m_run[rq];
+        const f32x4 nmv = f32x4{nm, nm, nm, nm};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = __builtin_elementwise_fma(st[rq][j], sl2v, nmv);
+#ifndef MM355_ABL_NOEXP
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+#endif
+            st[rq][j] = x;
+        }
+        l_part[rq] += (st[rq][0] + st[rq][1]) + (st[rq][2] + st[rq][3]);
+    }
+#endif
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 pb[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const bf16x8 va = kk == 0 ? vfr[j] : read_nat_perm_at<DS>(sV, 32, v_off[j]);      // V^T[d][keys perm]
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+#ifdef MM355_ABL_NOPV
+                asm volatile("" :: "v"(va), "v"(pb[rq]));
+                ot[rq][j][0] += (float)kk;
+#else
+                ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
+#endif
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // forward: workgroup = 128 query rows (4 waves x 32), KV tiles of 64 keys
 // ================================================================================================
@@ -90,7 +231,7 @@ template <int RQ>
 __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
     // RQ 16-row groups per wave: RQ = 2 -> 32 query rows per wave, two workgroups per CU (two waves per SIMD) -- the default;
     // RQ = 4 -> 64 rows per wave, ONE wave per SIMD with the whole register file: every K / V fragment read serves four MFMAs
-    // instead of two, half the LDS traffic per flop (the tr_b64 gathers cost ~7.5 LDS cycles each: tools/probes/lds_pattern_probe).
+    // instead of two, half the LDS traffic per flop (not the limiter: LDS is 20 % busy, tools/probes/lds_throughput_probe).
     // Measured (B = 12, L = 2048, 32/8 heads): RQ = 4 is SLOWER, 1.06 vs 0.69 ms forward and +0.5 ms in dQ -- with one wave per SIMD
     // nothing overlaps the softmax VALU phase with the MFMA phases, and a compiler-scheduled in-wave pipeline (S(h+1) || softmax(h) ||
     // PV(h-1) in one basic block) was slower still (1.34 ms: ~1 300 accumulator<->VGPR moves).  Kept as an opt-in A/B (MM355_ATTN_RQ=4).
@@ -153,12 +294,9 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
     // nat_perm_off(j) = row*256 + sub + ((hi ^ swz(row)) << 4 ^ j << 5).  Only the lane-constant halves live across the tile loop (four
     // registers); the per-kk / per-j offsets are one v_xad_u32 each, re-derived per tile behind an opaque copy -- twelve loop-invariant
     // address registers are what hipcc spills first (and a scratch reload carries a vmcnt(0) that serialises the LDS-DMA).
-    const int k_base = fr * (DS * 2), k_x = (fq ^ swzN<DS>(fr)) << 4;
-    const int v_row = fq * 4 + (fr >> 2);
-    const int v_base = v_row * (DS * 2) + (fr & 1) * 8, v_x = (((fr & 3) >> 1) ^ swzN<DS>(v_row)) << 4;
+    FwdLane ln;
+    ln.init(fr, fq);
     const float sl2 = a.scale * LOG2E;                       // scores in log2 domain: exp2(s*sl2 - m)
-    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2};
-    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
 
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
@@ -178,154 +316,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
         const unsigned char* sV = smem + (2 + (t & 1)) * TILE;
         // a wave whose rows all precede this tile (causal) has nothing to do here
         if (a.causal && kv0 > qw0 + ROWS - 1) continue;
-        int k_off[4], v_off[NF];
-        {
-            int kx = k_x, vx = v_x;
-            asm volatile("" : "+v"(kx), "+v"(vx));           // keep the derivation inside the loop
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) k_off[kk] = (kx ^ (kk << 6)) + k_base;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) v_off[j] = (vx ^ (j << 5)) + v_base;
-        }
-
-        f32x4 st[RQ][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Fragment reads are issued a whole phase ahead of their MFMAs: left to itself hipcc sinks every ds_read next to its use
-        // (read x4, wait, 2 MFMAs), which exposes one LDS round trip per MFMA pair.  All 16 K reads go out first; the 32 V gathers
-        // go out behind the score MFMAs, so that their latency is covered by the softmax.
-        bf16x8 kfr[KS][4];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kfr[kk][j] = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
-        __builtin_amdgcn_sched_barrier(0);
-        // d-step outermost: eight independent accumulator chains, so that back-to-back MFMAs never wait on their own result
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 kf = kfr[kk][j];
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-#ifdef MM355_ABL_NOQK                                        // timing-only ablation builds (tools/): see DESIGN section 4
-                    asm volatile("" :: "v"(kf));
-                    st[rq][j][0] += (float)kk;
-#else
-                    st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
-#endif
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef MM355_ABL_NOSM
-        const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
-        if (need_mask) {
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-                const int qg = qw0 + rq * 16 + fr;
-                const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;   // last visible key, tile-relative
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
-            }
-        }
-        float mx[RQ];
-        bool grow = false;
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-            float m = max3_raw(st[rq][0][0], st[rq][0][1], st[rq][0][2]);                  // 16 values: 8 v_max3 / v_max
-            m = max3_raw(m, st[rq][0][3], st[rq][1][0]);
-            m = max3_raw(m, st[rq][1][1], st[rq][1][2]);
-            m = max3_raw(m, st[rq][1][3], st[rq][2][0]);
-            m = max3_raw(m, st[rq][2][1], st[rq][2][2]);
-            m = max3_raw(m, st[rq][2][3], st[rq][3][0]);
-            m = max3_raw(m, st[rq][3][1], st[rq][3][2]);
-            m = max2_raw(m, st[rq][3][3]);
-            mx[rq] = quad_max(m) * sl2;                      // max of the RAW scores (scale > 0 commutes with max)
-            grow |= mx[rq] > m_run[rq] + RESCALE_THR;
-        }
-        // deferred rescale: only move the running maxima (and touch the O accumulators) when some row's max grew by more than
-        // 2^THR; otherwise P is exponentiated against the old max (bounded by 2^THR).  ONE wave-uniform branch for both row
-        // groups, so that everything after it -- V gathers, exponentials, P V -- is a single basic block the scheduler can overlap.
-        if (__any(grow)) {
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-                const float mn = fmaxf(m_run[rq], mx[rq]);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
-                l_part[rq] *= alpha;
-#pragma unroll
-                for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
-                m_run[rq] = mn;
-            }
-        }
-#endif
-        // the V gathers of the first 32 keys go out first: their LDS round trip is covered by the exponentials (those of the
-        // second 32 keys are issued beside the first half's MFMAs)
-        bf16x8 vfr[NF];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) vfr[j] = read_nat_perm_at<DS>(sV, 0, v_off[j]);                   // V^T[d][keys perm]
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef MM355_ABL_NOSM
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-            // exp2(s * sl2 - m) and the row sums on packed fp32 (v_pk_fma_f32 / v_pk_add_f32)
-            const float nm = -m_run[rq];
-            const f32x4 nmv = f32x4{nm, nm, nm, nm};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 x = __builtin_elementwise_fma(st[rq][j], sl2v, nmv);
-#ifndef MM355_ABL_NOEXP
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
-#endif
-                st[rq][j] = x;
-            }
-            l_part[rq] += (st[rq][0] + st[rq][1]) + (st[rq][2] + st[rq][3]);
-        }
-#endif
-#if MM355_FWD_VARIANT == 2
-        bf16x8 pb[2][RQ];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) pb[kk][rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
-        __builtin_amdgcn_sched_barrier(0);                   // (the scores are dead from here on: their registers hold the gathers)
-        bf16x8 vfr1[NF];                                     // second 32 keys: in flight beside the first half's MFMAs
-#pragma unroll
-        for (int j = 0; j < NF; ++j) vfr1[j] = read_nat_perm_at<DS>(sV, 32, v_off[j]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const bf16x8 va = kk == 0 ? vfr[j] : vfr1[j];
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[kk][rq], ot[rq][j]);
-            }
-#else
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 pb[RQ];
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const bf16x8 va = kk == 0 ? vfr[j] : read_nat_perm_at<DS>(sV, 32, v_off[j]);
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-#ifdef MM355_ABL_NOPV
-                    asm volatile("" :: "v"(va), "v"(pb[rq]));
-                    ot[rq][j][0] += (float)kk;
-#else
-                    ot[rq][j] = mfma16(va, pb[rq], ot[rq][j]);
-#endif
-                }
-            }
-        }
-#endif
+        fwd_tile<RQ>(sK, sV, kv0, qw0, seqlen, a.causal, sl2, ln, qf, ot, m_run, l_part);
     }
 #ifdef MM355_ATTN_TIMING
     const long long tm2 = __builtin_readcyclecounter();

@@ -2,8 +2,8 @@
 // One workgroup of four waves per CU = one wave per SIMD with the whole 512-entry register file (accumulators in AGPRs): this file is
 // built WITHOUT -mllvm -amdgpu-mfma-vgpr-form=1 (metamorph_amd/build.py), which the rest of the library uses to keep its two-waves-per-
 // SIMD kernels inside 256 VGPRs.  Why 64 rows: every K / V fragment read (ds_read_b128 rows, ds_read_b64_tr_b16 gathers) then feeds
-// four MFMAs instead of two; at 32 rows per wave the LDS fragment traffic of eight waves (about 2 400 LDS cycles per KV tile, the
-// tr_b64 gathers cost ~7.5 cycles each -- tools/probes/lds_pattern_probe.hip) exceeds the MFMA time of the tile (2 176 cycles per SIMD).
+// four MFMAs instead of two.  (The premise did not hold up: with eight waves reading, the gathers cost 2.4 LDS cycles and the row reads
+// 4.3, the LDS is 20 % busy in the 32-row kernels -- tools/probes/lds_throughput_probe.hip)
 // EXPERIMENT, opt-in (MM355_ATTN_RQ=4 / MM355_ATTN_RQ_DQ=4): parity-green but slower than the 32-row default, see attn3_kernels.h.
 #include "attn3_kernels.h"
 
