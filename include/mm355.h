@@ -98,7 +98,8 @@ int mm355_gemm_nn_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* Bt, i
 int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols,
                          mm355_bf16* out, int64_t ld_out, void* stream);
 
-/* column sums: db[n] (+)= sum_m dY[m][n]  (bias gradients of mm_projector / vision_head). */
+/* column sums: db[n] += sum_m dY[m][n]  (bias gradients of mm_projector / vision_head).  Deterministic: one workgroup owns 64 columns
+ * and all M rows (four row phases, fixed-order reduction), no atomics. */
 int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -311,8 +312,10 @@ int mm355_softmax_rows_bwd(const mm355_bf16* y, const mm355_bf16* dy, mm355_bf16
 int mm355_adamw_shard(float* p32, float* m, float* v, const mm355_bf16* g, mm355_bf16* p_out, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float bias_corr1, float bias_corr2, const float* grad_scale_dev, void* stream);
-/* out[0] += sum x^2 (grad-norm partial) */
-int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, void* stream);
+/* out[0] += sum x^2 (grad-norm partial).  Deterministic (no atomics): per-workgroup sums go to `partials` (caller-allocated,
+ * MM355_SUMSQ_PARTIALS floats, contents scratch) and are added in index order by a second one-workgroup launch. */
+#define MM355_SUMSQ_PARTIALS 2048
+int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, float* partials, void* stream);
 /* clip coefficient: coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) * pre_scale */
 int mm355_clip_coef(const float* sumsq, float max_norm, float pre_scale, float* coef, void* stream);
 

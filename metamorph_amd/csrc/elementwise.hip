@@ -1,6 +1,7 @@
 // Elementwise / gather-scatter HBM-bound kernels (gfx950): RoPE, SwiGLU, GELU, casts, AdamW shard update,
 // grad-norm, per-head transposes, im2col for the SigLIP patch embedding, splice gather/scatter.
 #include "mm355_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -218,7 +219,10 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p32, floa
         pout[i] = f2bf(p);
     }
 }
-__global__ __launch_bounds__(NT) void sumsq_kernel(const uint16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
+// Grad-norm partials, deterministic: block b writes its sum to partials[b] (a fixed grid-stride walk, a fixed tree inside the block),
+// sumsq_finish_kernel adds the partials in index order.  No atomics: the clip coefficient -- and through it every AdamW update -- is
+// bit-identical from run to run.
+__global__ __launch_bounds__(NT) void sumsq_kernel(const uint16_t* __restrict__ x, int64_t n, float* __restrict__ partials) {
     __shared__ float red[NT / 64];
     float s = 0.f;
     const int64_t nv = n >> 3;
@@ -230,7 +234,14 @@ __global__ __launch_bounds__(NT) void sumsq_kernel(const uint16_t* __restrict__ 
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { const float f = bf2f(x[(nv << 3) + threadIdx.x]); s += f * f; }
     s = block_sum<NT>(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(NT) void sumsq_finish_kernel(const float* __restrict__ partials, int count, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += NT) s += partials[i];
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) out[0] += s;
 }
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float pre, float* __restrict__ coef) {
     const float nrm = sqrtf(*sumsq);
@@ -417,10 +428,13 @@ extern "C" int mm355_adamw_shard(float* p32, float* m, float* v, const mm355_bf1
     if (!p32 || !m || !v || !g || !p_out || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return MM355_EINVAL;
     LAUNCH(adamw_kernel, grid_for(n), p32, m, v, g, p_out, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
 }
-extern "C" int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, void* stream) {
+extern "C" int mm355_sumsq_bf16(const mm355_bf16* x, int64_t n, float* out, float* partials, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
-    if (!x || !out || n <= 0 || !mm_aligned16(x)) return MM355_EINVAL;
-    LAUNCH(sumsq_kernel, grid_for(n / 8 + 1), x, n, out);
+    if (!x || !out || !partials || n <= 0 || !mm_aligned16(x)) return MM355_EINVAL;
+    const int blocks = (int)std::min<int64_t>((n / 8 + NT) / NT, MM355_SUMSQ_PARTIALS);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, n, partials);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, (const float*)partials, blocks, out);
+    return mm_launch_status();
 }
 extern "C" int mm355_clip_coef(const float* sumsq, float max_norm, float pre_scale, float* coef, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch

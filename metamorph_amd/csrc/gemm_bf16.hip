@@ -947,15 +947,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
     }
 }
 
-// column sums of a [M][N] bf16 matrix into fp32 (atomic accumulate; caller zeroes)
-__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, int64_t ld, int M, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+// column sums of a [M][N] bf16 matrix added to fp32 out[N]: a workgroup owns 64 columns and every row (thread = column x one of four row
+// phases, then a fixed-order sum over the phases): deterministic, no atomics
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int cq = threadIdx.x & 63, rp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cq;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += bf2f(x[(int64_t)r * ld + c]);
-    atomicAdd(out + c, s);
+    if (c < N)
+        for (int r = rp; r < M; r += 4) s += bf2f(x[(int64_t)r * ld + c]);
+    part[rp][cq] = s;
+    __syncthreads();
+    if (rp == 0 && c < N) out[c] += (part[0][cq] + part[1][cq]) + (part[2][cq] + part[3][cq]);
 }
 
 }  // namespace
@@ -1073,8 +1076,6 @@ extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t
 extern "C" int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dY || !db_f32 || M <= 0 || N <= 0) return MM355_EINVAL;
-    const int rpb = 256;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + rpb - 1) / rpb));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32);
     return mm_launch_status();
 }

@@ -591,10 +591,22 @@ def adamw_shard_(p32, m, v, g, p_out, lr, beta1, beta2, eps, wd, step, grad_scal
                                       eps, wd, bc1, bc2, _p(grad_scale_dev), _stream()), "mm355_adamw_shard")
 
 
-def sumsq_(x, out_f32):
+SUMSQ_PARTIALS = 2048            # MM355_SUMSQ_PARTIALS (include/mm355.h)
+_sumsq_partials = {}
+
+
+def sumsq_(x, out_f32, partials=None):
+    """out_f32[0] += sum(x^2), deterministic (two launches, no atomics).  `partials`: fp32 scratch of SUMSQ_PARTIALS elements; by
+    default one buffer per (device, stream), so launches on different streams never share it."""
     _chk_dev(x, out_f32)
     assert x.is_contiguous()
-    _lib.check(_L().mm355_sumsq_bf16(x.data_ptr(), x.numel(), out_f32.data_ptr(), _stream()), "mm355_sumsq_bf16")
+    if partials is None:
+        key = (x.device, _stream())
+        partials = _sumsq_partials.get(key)
+        if partials is None:
+            partials = _sumsq_partials[key] = torch.empty(SUMSQ_PARTIALS, dtype=torch.float32, device=x.device)
+    assert partials.dtype == torch.float32 and partials.numel() >= SUMSQ_PARTIALS and partials.device == x.device
+    _lib.check(_L().mm355_sumsq_bf16(x.data_ptr(), x.numel(), out_f32.data_ptr(), partials.data_ptr(), _stream()), "mm355_sumsq_bf16")
     return out_f32
 
 

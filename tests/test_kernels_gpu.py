@@ -251,6 +251,33 @@ def test_gemm_tn_rejects_ragged_k(ops):
         ops.gemm_tn(at, bt, torch.empty(64, 64, device=DEV, dtype=torch.bfloat16))
 
 
+def test_grad_norm_and_bias_grad_sums_are_deterministic(ops):
+    """mm355_sumsq_bf16 / mm355_colsum_bf16 use no atomics: repeated launches give the same bits, and both ACCUMULATE into `out`."""
+    x = (torch.randn(37_000_003, device=DEV) * 0.3).bfloat16()          # > MM355_SUMSQ_PARTIALS workgroups, ragged tail
+    outs = []
+    for _ in range(4):
+        s = torch.zeros(1, device=DEV)
+        ops.sumsq_(x, s)
+        outs.append(s.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = float((x.double() ** 2).sum())
+    assert abs(float(outs[0]) - ref) <= 2e-5 * ref
+    s2 = outs[0].clone()
+    ops.sumsq_(x[:1000], s2)                                           # accumulates
+    assert abs(float(s2) - float(outs[0]) - float((x[:1000].double() ** 2).sum())) <= 1e-5 * ref
+    y = (torch.randn(4099, 1160, device=DEV) * 0.5).bfloat16()
+    cs = []
+    for _ in range(3):
+        c = torch.zeros(1160, device=DEV)
+        ops.colsum_f32(y, c)
+        cs.append(c.clone())
+    assert torch.equal(cs[0], cs[1]) and torch.equal(cs[0], cs[2])
+    close(cs[0].cpu(), y.float().sum(0).cpu(), 1e-4, 1e-2, "colsum big")
+    c2 = cs[0].clone()
+    ops.colsum_f32(y, c2)
+    close(c2.cpu(), 2 * y.float().sum(0).cpu(), 1e-4, 2e-2, "colsum accumulates")
+
+
 def test_transpose_and_colsum(ops):
     for (r, c) in [(64, 64), (200, 136), (729, 1152), (130, 72)]:
         x = rnd(r, c, seed=r)

@@ -69,7 +69,7 @@ def _train(stage, steps=3, accum=1, ckpt=False, clip=0.0, layers=3, param_slots=
 
 @pytest.mark.parametrize("ckpt", [False, True])
 def test_zero3_equals_zero2_bit_for_bit(ckpt):
-    """No clipping (the only nondeterministic kernel is the grad-norm atomics), no accumulation: the same kernels see the same bytes
+    """No clipping, no accumulation: the same kernels see the same bytes
     whether the parameters come from the flat buffer or from a gathered slot => identical losses and parameters.  With recompute
     (`gradient_checkpointing`, the 70B recipe) the layer is gathered three times per step: forward, recompute, backward."""
     l2, e2, p2, _ = _train(2, ckpt=ckpt)
