@@ -387,6 +387,9 @@ ATT_CASES = [  # B, L, Hq, Hkv, d, causal, seqlens
     (1, 513, 4, 2, 128, True, None),                    # d == 128 LDS-DMA kernels: several 128-row query blocks, ragged tail
     (2, 200, 2, 2, 128, False, [200, 77]),
     (2, 256, 4, 1, 128, True, [1, 256]),
+    (1, 300, 6, 3, 128, True, None),                    # block order: groups of 2 heads walked fastest; dK/dV: odd KV-head count
+    (1, 260, 5, 5, 128, True, None),                    # no GQA, odd head count: one head at a time
+    (2, 384, 12, 4, 128, True, [300, 384]),             # groups of 3
 ]
 
 
