@@ -90,30 +90,24 @@ struct FwdLane {
         v_base = v_row * (DS * 2) + (fr & 1) * 8; v_x = (((fr & 3) >> 1) ^ swzN<DS>(v_row)) << 4;
     }
 };
+// ---- the four phases of one K / V tile of 64 keys for RQ 16-row groups of one wave ----
+// S^T = K Q^T.  All 16 K fragment reads go out ahead of the MFMAs behind scheduling barriers (left to itself hipcc sinks every ds_read next
+// to its use and spends 256 registers on its own prefetch; the pinned form needs 242 and times the same,
+// profiles/r2_attn_persist_hoist_ab.log).
 template <int RQ>
-MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, int qw0, int seqlen, int causal, float sl2, const FwdLane& ln,
-                     const bf16x8 (&qf)[RQ][4], f32x4 (&ot)[RQ][8], float (&m_run)[RQ], f32x4 (&l_part)[RQ]) {
-    constexpr int KS = 4, NF = 8;
-    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
-    const int fr = ln.fr, fq = ln.fq, k_base = ln.k_base, k_x = ln.k_x, v_base = ln.v_base, v_x = ln.v_x;
-    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2};
-    int k_off[4], v_off[NF];
+MM_DEV void fwd_scores(const unsigned char* sK, const FwdLane& ln, const bf16x8 (&qf)[RQ][4], f32x4 (&st)[RQ][4]) {
+    constexpr int KS = 4;
+    int k_off[4];
     {
-        int kx = k_x, vx = v_x;
-        asm volatile("" : "+v"(kx), "+v"(vx));           // keep the derivation inside the loop
+        int kx = ln.k_x;
+        asm volatile("" : "+v"(kx));                         // keep the derivation inside the tile loop
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) k_off[kk] = (kx ^ (kk << 6)) + k_base;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) v_off[j] = (vx ^ (j << 5)) + v_base;
+        for (int kk = 0; kk < KS; ++kk) k_off[kk] = (kx ^ (kk << 6)) + ln.k_base;
     }
-
-    f32x4 st[RQ][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // all 16 K fragment reads go out ahead of the score MFMAs (left to itself hipcc sinks every ds_read next to its use and spends
-    // 256 registers on its own prefetch; this form needs 242 -- the two schedules time the same, profiles/r2_attn_persist_hoist_ab.log)
     bf16x8 kfr[KS][4];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -137,7 +131,15 @@ MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, 
             }
         }
     __builtin_amdgcn_sched_barrier(0);
-#ifndef MM355_ABL_NOSM
+}
+
+// mask, row maxima (log2 domain), deferred rescale of the running state
+template <int RQ>
+MM_DEV void fwd_rowmax(f32x4 (&st)[RQ][4], int kv0, int qw0, int seqlen, int causal, float sl2, const FwdLane& ln,
+                       f32x4 (&ot)[RQ][8], float (&m_run)[RQ], f32x4 (&l_part)[RQ]) {
+    constexpr int NF = 8;
+    constexpr float RESCALE_THR = 6.0f;                      // log2 units: keep the old running max while it grows < 2^6
+    const int fr = ln.fr, fq = ln.fq;
     const bool need_mask = (kv0 + 64 > seqlen) || (causal && kv0 + 63 > qw0);
     if (need_mask) {
 #pragma unroll
@@ -179,16 +181,14 @@ MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, 
             m_run[rq] = mn;
         }
     }
-#endif
-    // the V gathers of the first 32 keys go out before the exponentials, which cover their LDS round trip
-    bf16x8 vfr[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) vfr[j] = read_nat_perm_at<DS>(sV, 0, v_off[j]);
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef MM355_ABL_NOSM
+}
+
+// P = exp2(s * sl2 - m) in place of the scores, row sums; packed fp32 (v_pk_fma_f32 / v_pk_add_f32)
+template <int RQ>
+MM_DEV void fwd_exp(f32x4 (&st)[RQ][4], float sl2, const float (&m_run)[RQ], f32x4 (&l_part)[RQ]) {
+    const f32x4 sl2v = f32x4{sl2, sl2, sl2, sl2};
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) {
-        // exp2(s * sl2 - m) and the row sums on packed fp32 (v_pk_fma_f32 / v_pk_add_f32)
         const float nm = -m_run[rq];
         const f32x4 nmv = f32x4{nm, nm, nm, nm};
 #pragma unroll
@@ -202,7 +202,19 @@ MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, 
         }
         l_part[rq] += (st[rq][0] + st[rq][1]) + (st[rq][2] + st[rq][3]);
     }
-#endif
+}
+
+MM_DEV void fwd_v_offsets(const FwdLane& ln, int (&v_off)[8]) {
+    int vx = ln.v_x;
+    asm volatile("" : "+v"(vx));                             // keep the derivation inside the tile loop
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v_off[j] = (vx ^ (j << 5)) + ln.v_base;
+}
+
+// O^T += V^T P^T; vfr0: the V gathers of the first 32 keys, already issued by the caller
+template <int RQ>
+MM_DEV void fwd_pv(const unsigned char* sV, const int (&v_off)[8], const bf16x8 (&vfr0)[8], const f32x4 (&st)[RQ][4], f32x4 (&ot)[RQ][8]) {
+    constexpr int NF = 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         bf16x8 pb[RQ];
@@ -210,7 +222,7 @@ MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, 
         for (int rq = 0; rq < RQ; ++rq) pb[rq] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            const bf16x8 va = kk == 0 ? vfr[j] : read_nat_perm_at<DS>(sV, 32, v_off[j]);      // V^T[d][keys perm]
+            const bf16x8 va = kk == 0 ? vfr0[j] : read_nat_perm_at<DS>(sV, 32, v_off[j]);      // V^T[d][keys perm]
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) {
 #ifdef MM355_ABL_NOPV
@@ -222,6 +234,28 @@ MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, 
             }
         }
     }
+}
+
+// one tile, phases in sequence (the one-tile-at-a-time kernels)
+template <int RQ>
+MM_DEV void fwd_tile(const unsigned char* sK, const unsigned char* sV, int kv0, int qw0, int seqlen, int causal, float sl2, const FwdLane& ln,
+                     const bf16x8 (&qf)[RQ][4], f32x4 (&ot)[RQ][8], float (&m_run)[RQ], f32x4 (&l_part)[RQ]) {
+    f32x4 st[RQ][4];
+    fwd_scores<RQ>(sK, ln, qf, st);
+#ifndef MM355_ABL_NOSM
+    fwd_rowmax<RQ>(st, kv0, qw0, seqlen, causal, sl2, ln, ot, m_run, l_part);
+#endif
+    // the V gathers of the first 32 keys go out before the exponentials, which cover their LDS round trip
+    int v_off[8];
+    fwd_v_offsets(ln, v_off);
+    bf16x8 vfr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vfr[j] = read_nat_perm_at<DS>(sV, 0, v_off[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef MM355_ABL_NOSM
+    fwd_exp<RQ>(st, sl2, m_run, l_part);
+#endif
+    fwd_pv<RQ>(sV, v_off, vfr, st, ot);
 }
 
 // ================================================================================================
