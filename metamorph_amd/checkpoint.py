@@ -134,3 +134,6 @@ def load_consolidated_optimizer_state(opt, model, ckpt):
     for sg in opt.segs:
         sg["my_param"].copy_(opt.master[sg["so"]:sg["so"] + sg["m"]].to(sg["my_param"].dtype))
     opt._all_gather_params()
+    if opt.master.is_cuda:                                   # parameters changed behind torch's version counters
+        from . import functional as F
+        F.bump_param_generation()

@@ -13,14 +13,21 @@ delegation with `Zero2AdamW` (metamorph_amd/zero2.py):
   * gradient clipping moves into the optimizer (`max_grad_norm` is the norm of the MEAN gradient over ranks, computed from the sharded
     reduce-scattered buffer; HF's own `clip_grad_norm_` would see un-reduced local gradients);
   * `training_step` arms the overlapped reduce-scatter on the last micro-step of an accumulation window;
-  * `gradient_checkpointing=True` (every reference launch script) maps onto per-layer recompute in `DecoderLayerFn`.
+  * `gradient_checkpointing=True` (every reference launch script) maps onto per-layer recompute in `DecoderLayerFn`;
+  * optimizer checkpoints: HF writes `optimizer.state_dict()` from rank 0 only, which under a sharded optimizer is one rank's slice.
+    `_save_optimizer_and_scheduler` / `_load_optimizer_and_scheduler` write and read the whole state instead: ZeRO-2 as ONE
+    world-size-independent file (`checkpoint.consolidate_optimizer_state`: fp32 master / moments per parameter name), ZeRO-3 as one
+    shard file per rank (the reference's DeepSpeed checkpoints are per-rank `zero_pp_rank_*` files as well).
 """
 from __future__ import annotations
+
+import os
+import warnings
 
 import torch
 from transformers import Trainer
 
-from .checkpoint import save_trainer_adapter_checkpoint
+from .checkpoint import consolidate_optimizer_state, load_consolidated_optimizer_state, save_trainer_adapter_checkpoint
 from .zero2 import Zero2AdamW, tag_segments
 from .zero3 import Zero3AdamW
 
@@ -128,6 +135,43 @@ class MetaMorphTrainer(Trainer):
         if z is not None:
             z.synchronize()
         super()._save_checkpoint(model, trial)
+
+    # ------------------------------------------------------------------ optimizer state: every rank's shard, not rank 0's
+    _OPT, _SCHED = "optimizer.pt", "scheduler.pt"
+
+    def _save_optimizer_and_scheduler(self, output_dir):
+        z = self._zero2()
+        if z is None:
+            return super()._save_optimizer_and_scheduler(output_dir)
+        os.makedirs(output_dir, exist_ok=True)
+        if isinstance(z, Zero3AdamW):
+            torch.save(z.state_dict(), os.path.join(output_dir, f"zero3_rank{z.rank}-of-{z.world}-{self._OPT}"))
+            marker = {"zero_stage": 3, "world": z.world}                 # what HF's resume logic looks for
+        else:
+            marker = consolidate_optimizer_state(z, self.model)          # collective: every rank takes part, rank 0 gets the result
+        if self.args.should_save:
+            torch.save(marker, os.path.join(output_dir, self._OPT))
+            with warnings.catch_warnings(record=True):
+                torch.save(self.lr_scheduler.state_dict(), os.path.join(output_dir, self._SCHED))
+
+    def _load_optimizer_and_scheduler(self, checkpoint):
+        z = self._zero2()
+        if checkpoint is None or z is None:
+            return super()._load_optimizer_and_scheduler(checkpoint)
+        path = os.path.join(checkpoint, self._OPT)
+        if not os.path.isfile(path):
+            return
+        if isinstance(z, Zero3AdamW):
+            shard = os.path.join(checkpoint, f"zero3_rank{z.rank}-of-{z.world}-{self._OPT}")
+            if not os.path.isfile(shard):
+                raise FileNotFoundError(f"{shard}: ZeRO-3 optimizer shards are per rank; resume with the world size that wrote them")
+            z.load_state_dict(torch.load(shard, map_location=z.master.device, weights_only=True))
+        else:
+            load_consolidated_optimizer_state(z, self.model, torch.load(path, map_location="cpu", weights_only=True))
+        sched = os.path.join(checkpoint, self._SCHED)
+        if os.path.isfile(sched):
+            with warnings.catch_warnings(record=True):
+                self.lr_scheduler.load_state_dict(torch.load(sched, map_location="cpu", weights_only=True))
 
     def _save(self, output_dir=None, state_dict=None):
         if getattr(self.args, "tune_mm_mlp_adapter", False):

@@ -377,6 +377,17 @@ class Zero3AdamW(torch.optim.Optimizer):
             g, p_out = (sg["g_shard"], sg["p_shard"]) if sg["sharded"] else (sg["my_grad"], sg["my_param"])
             self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], g, p_out, *self._hyper(sg["group"]))
         # resident parameters are all-gathered now; sharded layers at their next use (their slots hold stale copies: drop them)
+        self._all_gather_resident()
+        self.release_params()
+        for sg in self.segs:
+            if sg["sharded"]:
+                sg["g_live"] = False
+        if self.master.is_cuda:
+            from . import functional as F
+            F.bump_param_generation()
+        return None
+
+    def _all_gather_resident(self):
         for sg in self.segs:
             if sg["sharded"] or not self._coll:
                 continue
@@ -387,14 +398,6 @@ class Zero3AdamW(torch.optim.Optimizer):
                 dist.all_gather(parts, sg["my_param"].clone(), group=self.pg)
                 for r, t in enumerate(parts):
                     sg["param"][r * sg["m"]:(r + 1) * sg["m"]].copy_(t)
-        self.release_params()
-        for sg in self.segs:
-            if sg["sharded"]:
-                sg["g_live"] = False
-        if self.master.is_cuda:
-            from . import functional as F
-            F.bump_param_generation()
-        return None
 
     def release_params(self):
         """Forget every gathered layer (after an update, or to free nothing but bookkeeping: the slots themselves persist)."""
@@ -460,7 +463,11 @@ class Zero3AdamW(torch.optim.Optimizer):
         for sg in self.segs:
             dst = sg["p_shard"] if sg["sharded"] else sg["my_param"]
             dst.copy_(self.master[sg["so"]:sg["so"] + sg["m"]].to(dst.dtype))
+        self._all_gather_resident()                         # the other ranks' slices of the resident tensors
         self.release_params()
+        if self.master.is_cuda:
+            from . import functional as F
+            F.bump_param_generation()
 
     def full_state_dict(self, model):
         """model.state_dict() with the sharded decoder layers gathered (`stage3_gather_16bit_weights_on_model_save`): what

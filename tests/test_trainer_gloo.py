@@ -70,6 +70,23 @@ def _train(out_dir, per_device_bs, accum, steps):
         Zero2AdamW.arm_overlap = orig
     z = tr._zero2()
     assert isinstance(z, Zero2AdamW) and z._step == steps and z.max_grad_norm == 0.5 and tr.args.max_grad_norm == 0.0
+    # optimizer checkpoint through the Trainer's own hooks: the WHOLE state (every rank's shard), restorable into a fresh optimizer
+    ck = os.path.join(os.path.dirname(out_dir), "opt_ckpt_" + os.path.basename(out_dir).lstrip("r0123456789"))
+    tr._save_optimizer_and_scheduler(ck)
+    if dist.is_initialized():
+        dist.barrier()
+    tr2 = SeqTrainer(model=Toy(), args=args, train_dataset=_DS(64), zero2_kwargs=dict(
+        shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip))
+    tr2.create_optimizer_and_scheduler(num_training_steps=steps)
+    tr2._load_optimizer_and_scheduler(ck)
+    z2 = tr2._zero2()
+    assert z2._step == z._step
+    for k in ("master", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(z2, k), getattr(z, k)), k
+    for pa, pb in zip(tr2.model.parameters(), model.parameters()):       # the bf16/fp32 parameters follow the restored master copy
+        assert torch.equal(pa.data, pb.data)
+    saved = torch.load(os.path.join(ck, "optimizer.pt"), weights_only=True)
+    assert set(saved["state"]) == {n for n, _ in model.named_parameters()}  # per-name, world-size independent
     assert type(tr.model_wrapped) is Toy and type(tr.model) is Toy, type(tr.model_wrapped)        # no DDP wrapper
     assert len(armed) == steps, (len(armed), steps)                                                # once per accumulation window
     assert len(z.segs) >= 3                                                                        # layers tagged as segments

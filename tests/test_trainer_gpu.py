@@ -68,6 +68,29 @@ def test_hf_trainer_two_steps_with_gradient_checkpointing(tmp_path, zero_stage):
     from metamorph_amd import functional as F
     F.set_layer_grad_hook(None)
     F.set_param_ready_hook(None)
+    # optimizer checkpoint through the Trainer's hooks: the whole sharded state (ZeRO-2: one per-name, world-size independent file;
+    # ZeRO-3: one shard file per rank), restored into a fresh optimizer over DIFFERENT initial weights
+    ck = str(tmp_path / "opt_ckpt")
+    trainer._save_optimizer_and_scheduler(ck)
+    m2 = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]) + 1, dtype=torch.bfloat16))
+    t2 = SeqTrainer(model=m2, args=args, train_dataset=ds, data_collator=collate, zero_stage=zero_stage,
+                    zero2_kwargs=dict(min_shard_numel=1) if zero_stage == 3 else None)
+    t2.create_optimizer_and_scheduler(num_training_steps=2)
+    t2._load_optimizer_and_scheduler(ck)
+    z2 = t2._zero2()
+    assert z2 is not z and z2._step == 2
+    for k in ("master", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(z2, k), getattr(z, k)), k
+    if zero_stage == 2:                                     # the bf16 parameters follow the restored master copy
+        for (n, pa), (_, pb) in zip(m2.named_parameters(), model.named_parameters()):
+            if pa.requires_grad:
+                assert torch.equal(pa.data, pb.data), n
+    else:
+        for sa, sb in zip(z2.segs, z.segs):
+            assert torch.equal(sa["p_shard"] if sa["sharded"] else sa["my_param"], sb["p_shard"] if sb["sharded"] else sb["my_param"])
+    del m2, t2, z2
+    F.set_layer_grad_hook(None)
+    F.set_param_ready_hook(None)
     if zero_stage == 3:                                     # compare the gathered full parameters below
         full = z.gather_full_parameters()
         for p_, t_ in full.items():
