@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--vit-layers", type=int, default=27)
     ap.add_argument("--zero", type=int, default=2, choices=(2, 3), help="3: decoder-layer parameters sharded (Zero3AdamW, BASELINE configs[4] machinery); NOT the headline config")
     ap.add_argument("--grad-checkpointing", action="store_true", help="per-layer recompute (reference --gradient_checkpointing True); NOT the headline config")
+    ap.add_argument("--host-inputs", action="store_true", help="ids / labels / mask / fp32 pixels start every step in pinned HOST memory (PCIe-inclusive "
+                    "rate for DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -74,6 +76,8 @@ def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
     labels[gen, last] = -200
     mask = torch.ones(B, n_ids, dtype=torch.bool)
     images = torch.randn(B * frames, 3, 384, 384, generator=g)
+    if device is None:                                       # --host-inputs: what a DataLoader with pin_memory hands the Trainer
+        return tuple(t.pin_memory() for t in (ids, labels, mask, images))
     return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
 
 
@@ -323,12 +327,19 @@ def main():
         opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
     t_build = time.time() - t_build
 
-    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, dev, seed=1234 + rank, frames=args.frames, all_generation=args.all_generation)
+    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank,
+                                           frames=args.frames, all_generation=args.all_generation)
+    host = (ids, labels, mask, images) if args.host_inputs else None
+    host_bytes = sum(t.numel() * t.element_size() for t in host) if host else 0
     timer = GemmTimer()
     if not args.no_kernel_timing:
         timer.install()
 
     def step():
+        nonlocal ids, labels, mask, images
+        if host is not None:                                 # host -> HBM inside the step (HF Trainer._prepare_inputs), pixels cast on the device
+            ids, labels, mask = (t.to(dev, non_blocking=True) for t in host[:3])
+            images = host[3].to(dev, non_blocking=True).to(torch.bfloat16)
         opt.zero_grad()
         out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images)
         opt.arm_overlap()                                        # no accumulation: these gradients are final
@@ -392,7 +403,8 @@ def main():
             "metric": "train tokens/sec (LLaMA-3-8B + SigLIP-SO400M, seq2048, 256 img toks), whole job",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/pixels)",
+            "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/pixels)" + (
+                f"; INPUTS FROM PINNED HOST MEMORY every step ({host_bytes} B/step over PCIe: not the headline configuration)" if host else ""),
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
