@@ -300,7 +300,7 @@ def main():
 
     llm = dict(LLAMA3_8B, num_hidden_layers=args.layers)
     geo = dict(num_hidden_layers=args.vit_layers)
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)                                      # identical initial weights on every rank (data parallel); the BATCH is seeded per rank
     t_build = time.time()
     model = build_model(llm, geo, num_image_tokens=args.image_tokens, max_length=4096, device=dev, init_on_device=True)
     model.train()
