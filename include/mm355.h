@@ -110,6 +110,15 @@ int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, fl
  * ------------------------------------------------------------------------------------------------ */
 int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h,
                       float eps, void* stream);
+/* the same, also returning rstd[m] = rsqrt(mean(x[m]^2) + eps) (fp32, M values; NULL = not wanted) ... */
+int mm355_rmsnorm_fwd_rstd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, float* rstd_out, int64_t M, int64_t h,
+                           float eps, void* stream);
+/* ... from which the backward pass takes the TRANSPOSED normalised activations in one pass:
+ *   out_t[c][m] = w[c] * bf16(x[m][c] * rstd[m]),   out_t is [h][ld_out], ld_out >= M (columns M..ld_out are not written)
+ * = the contraction-major operand of the qkv / gate_up weight-gradient GEMMs (HF computes those from the saved norm output,
+ * reference call site metamorph_llama.py:349-359); bit-identical to transposing mm355_rmsnorm_fwd's result. */
+int mm355_rmsnorm_apply_t(const mm355_bf16* x, const mm355_bf16* w, const float* rstd, int64_t M, int64_t h,
+                          mm355_bf16* out_t, int64_t ld_out, void* stream);
 int mm355_rmsnorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_bf16* w,
                       const mm355_bf16* dres, mm355_bf16* dx, float* dw_f32, float* workspace,
                       int64_t M, int64_t h, float eps, void* stream);

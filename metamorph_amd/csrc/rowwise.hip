@@ -14,7 +14,7 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------------------------------------
 template <int VPT>
 __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
-                                                         uint16_t* __restrict__ y, int h, float eps) {
+                                                         uint16_t* __restrict__ y, float* __restrict__ rstd_out, int h, float eps) {
     __shared__ float red[NT / 64];
     const int64_t row = blockIdx.x;
     const int nv = h >> 3;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const uint16_t* __restr
     }
     ss = block_sum<NT>(ss, red);
     const float rstd = rsqrtf(ss / (float)h + eps);
+    if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int v = threadIdx.x + i * NT;
@@ -41,6 +42,53 @@ __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const uint16_t* __restr
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = wv[e] * round_bf(xv[i][e] * rstd);
             *(u32x4*)(y + row * h + v * 8) = pack8(o);
+        }
+    }
+}
+
+// y^T of the same RMSNorm from the SAVED per-row rstd: out_t[c][r] = w[c] * bf16(x[r][c] * rstd[r]) -- the contraction-major operand the
+// weight-gradient GEMMs of qkv / gate_up want.  One pass (read x, write y^T) instead of recomputing y and transposing it (two reads, two
+// writes); bit-identical to transposing rmsnorm_fwd's output.  64 x 64 tiles through LDS, 16-B accesses on both sides.
+__global__ __launch_bounds__(256) void rmsnorm_apply_t_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                              const float* __restrict__ rstd, int M, int h,
+                                                              uint16_t* __restrict__ out, int64_t ld_out) {
+    __shared__ uint16_t tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, r = v >> 3, c = (v & 7) * 8;
+        const int gr = r0 + r, gc = c0 + c;
+        uint16_t tmp[8];
+        if (gr < M && gc + 8 <= h) {
+            float xv[8], wv[8], o[8];
+            unpack8(*(const u32x4*)(x + (int64_t)gr * h + gc), xv);
+            unpack8(*(const u32x4*)(w + gc), wv);
+            const float rs = rstd[gr];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * round_bf(xv[e] * rs);
+            *(u32x4*)tmp = pack8(o);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tmp[e] = 0;          // (h % 8 == 0: a vector is inside or outside as a whole)
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][c + e] = tmp[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256, c = v >> 3, r = (v & 7) * 8;   // output row = input col c
+        const int gc = c0 + c, gr = r0 + r;
+        if (gc >= h) continue;
+        uint16_t tmp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmp[e] = tile[r + e][c];
+        if (gr + 8 <= M && ((ld_out & 7) == 0)) {
+            *(u32x4*)(out + (int64_t)gc * ld_out + gr) = *(const u32x4*)tmp;
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (gr + e < M) out[(int64_t)gc * ld_out + gr + e] = tmp[e];
         }
     }
 }
@@ -519,13 +567,27 @@ int dispatch_vpt(int h, F&& f) {
 
 }  // namespace
 
-extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h, float eps, void* stream) {
+extern "C" int mm355_rmsnorm_fwd_rstd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, float* rstd_out, int64_t M, int64_t h, float eps,
+                                      void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !w || !y || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff) return MM355_EINVAL;
     return dispatch_vpt((int)h, [&](auto vpt) {
-        hipLaunchKernelGGL((rmsnorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, y, (int)h, eps);
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<decltype(vpt)::value>), dim3((unsigned)M), dim3(NT), 0, (hipStream_t)stream, x, w, y, rstd_out,
+                           (int)h, eps);
         return mm_launch_status();
     });
+}
+extern "C" int mm355_rmsnorm_fwd(const mm355_bf16* x, const mm355_bf16* w, mm355_bf16* y, int64_t M, int64_t h, float eps, void* stream) {
+    return mm355_rmsnorm_fwd_rstd(x, w, y, nullptr, M, h, eps, stream);
+}
+extern "C" int mm355_rmsnorm_apply_t(const mm355_bf16* x, const mm355_bf16* w, const float* rstd, int64_t M, int64_t h, mm355_bf16* out_t,
+                                     int64_t ld_out, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!x || !w || !rstd || !out_t || M <= 0 || h <= 0 || (h & 7) || M > 0x7fffffff || ld_out < M) return MM355_EINVAL;
+    if (!mm_aligned16(x) || !mm_aligned16(w) || !mm_aligned16(out_t)) return MM355_EINVAL;
+    dim3 grid((unsigned)((h + 63) / 64), (unsigned)((M + 63) / 64));
+    hipLaunchKernelGGL(rmsnorm_apply_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, rstd, (int)M, (int)h, out_t, ld_out);
+    return mm_launch_status();
 }
 
 // dw[c] += sum_g ws[g][c]: 32 columns per workgroup as eight float4 lanes x 32 row lanes (16-B loads, G / 32 of them per

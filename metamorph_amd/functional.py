@@ -24,6 +24,9 @@ _DW_TN = os.environ.get("MM355_DW_TN", "0") == "1"
 # layer go out as ONE launch when that saves a wave of workgroups (LLaMA-3-8B: 896 + 384 tiles = 5 waves of 256 CUs instead
 # of 4 + 2).
 _DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
+# MM355_NORM_T=0: recompute the RMSNorm outputs in the backward pass and transpose them (two passes each) instead of rebuilding them
+# contraction-major from the saved rstd in one (rmsnorm_apply_t); A/B switch.
+_NORM_T = os.environ.get("MM355_NORM_T", "1") != "0"
 _CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
 
 
@@ -252,19 +255,20 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     att, mlp = layer.self_attn, layer.mlp
     wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
     wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
-    n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps)
+    n1, rstd1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps, want_rstd=True)
     qkv = ops.gemm(n1, wqkv)
     del n1
     ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)
     nq, nk = m.Hq * m.d, m.Hkv * m.d
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
-    n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps)
+    n2, rstd2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps, want_rstd=True)
     gu = ops.gemm(n2, wgu)
     del n2
     act = ops.swiglu_fwd(gu, m.I)
     y = ops.gemm(act, mlp.down_proj.weight, residual=x2)
-    return y, (qkv, o, lse, x2, gu)
+    # rstd1 / rstd2 (fp32 [M] each): the backward pass rebuilds the TRANSPOSED norm outputs from them in one pass (rmsnorm_apply_t)
+    return y, (qkv, o, lse, x2, gu, rstd1, rstd2)
 
 
 def _rmsnorm_backward(dn, x, w, eps, dres):
@@ -295,9 +299,9 @@ class DecoderLayerFn(Function):
         params_ready(layer, backward=True)                                     # sharded parameters (ZeRO-3): gather before use
         if len(ctx.saved_tensors) == 1:                                        # checkpointed: same kernels, same inputs => same bits
             (x,) = ctx.saved_tensors
-            _, (qkv, o, lse, x2, gu) = decoder_layer_forward(x, layer, m)
+            _, (qkv, o, lse, x2, gu, rstd1, rstd2) = decoder_layer_forward(x, layer, m)
         else:
-            x, qkv, o, lse, x2, gu = ctx.saved_tensors
+            x, qkv, o, lse, x2, gu, rstd1, rstd2 = ctx.saved_tensors
         att, mlp = layer.self_attn, layer.mlp
         dy = dy.contiguous()
         h = x.shape[1]
@@ -332,11 +336,15 @@ class DecoderLayerFn(Function):
         wgu = fused_weight(gu_params)
         dn2 = input_grad_gemm(dgu, wgu)                                         # [M, h]
         if any(p.requires_grad for p in gu_params):
-            n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps)
             fb, acc, bufs = fused_grad_target(gu_params)
-            weight_grad_gemm(dgu, n2, fb, bool(acc), dyT=dguT)
+            if _DW_TN or not _NORM_T:
+                weight_grad_gemm(dgu, ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps), fb, bool(acc), dyT=dguT)
+            else:                                                              # norm output, contraction-major, from the saved rstd
+                rp = dguT.shape[1] if dguT is not None else _padded_rows(x2.shape[0], long_k=True)
+                n2T = ops.rmsnorm_apply_t(x2, layer.post_attention_layernorm.weight, rstd2, rp)
+                weight_grad_gemm(dgu, None, fb, bool(acc), dyT=dguT, xT=n2T)
+                del n2T
             commit_fused_grad(gu_params, fb, acc, bufs)
-            del n2
         del dgu, dguT
         dx2 = _rmsnorm_backward(dn2, x2, layer.post_attention_layernorm.weight, m.eps, dy)     # dy + d rmsnorm
         del dn2
@@ -355,10 +363,13 @@ class DecoderLayerFn(Function):
         wqkv = fused_weight(qkv_params)
         dn1 = input_grad_gemm(dqkv, wqkv)
         if any(p.requires_grad for p in qkv_params):
-            n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps)
             fb, acc, bufs = fused_grad_target(qkv_params)
+            if _DW_TN or not _NORM_T:
+                n1, n1T = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps), None
+            else:
+                n1, n1T = None, ops.rmsnorm_apply_t(x, layer.input_layernorm.weight, rstd1, _padded_rows(x.shape[0], long_k=True))
             if held is not None:
-                a1, b1 = _dw_operands(dqkv, n1)
+                a1, b1 = _dw_operands(dqkv, n1, xT=n1T)
                 if ops.gemm_pair_supported(held[0], held[1], a1, b1):
                     ops.gemm_pair(held[0], held[1], held[2], held[3], a1, b1, fb, bool(acc))
                 else:                                                          # e.g. an operand beyond 2 GiB
@@ -367,9 +378,9 @@ class DecoderLayerFn(Function):
                 held = None
                 del a1, b1
             else:
-                weight_grad_gemm(dqkv, n1, fb, bool(acc))
+                weight_grad_gemm(dqkv, n1, fb, bool(acc), xT=n1T)
             commit_fused_grad(qkv_params, fb, acc, bufs)
-            del n1
+            del n1, n1T
         del dqkv
         dx = _rmsnorm_backward(dn1, x, layer.input_layernorm.weight, m.eps, dx2)
         if _LAYER_GRAD_HOOK is not None:                                       # every gradient of this layer is final now

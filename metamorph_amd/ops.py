@@ -237,13 +237,35 @@ def colsum_f32(dy, out_f32):
 
 # ------------------------------------------------------------------------------------------------ norms
 
-def rmsnorm_fwd(x, w, eps, out=None):
+def rmsnorm_fwd(x, w, eps, out=None, want_rstd=False):
+    """y = w * bf16(x * rstd); want_rstd: returns (y, rstd fp32 [M]) -- what `rmsnorm_apply_t` needs in the backward pass"""
     _chk_dev(x, w)
     assert x.is_contiguous() and x.dtype == BF16 and w.dtype == BF16
     h = x.shape[-1]
     M = x.numel() // h
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_L().mm355_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, h, eps, _stream()), "mm355_rmsnorm_fwd")
+    if not want_rstd:
+        _lib.check(_L().mm355_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, h, eps, _stream()), "mm355_rmsnorm_fwd")
+        return out
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _lib.check(_L().mm355_rmsnorm_fwd_rstd(x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, h, eps, _stream()),
+               "mm355_rmsnorm_fwd_rstd")
+    return out, rstd
+
+
+def rmsnorm_apply_t(x, w, rstd, Rp=None):
+    """(w * bf16(x * rstd))^T as [h, Rp] (Rp >= M, padding columns zeroed): the normalised activations, contraction-major"""
+    _chk_dev(x, w, rstd)
+    assert x.is_contiguous() and x.dtype == BF16 and w.dtype == BF16 and rstd.dtype == torch.float32 and x.dim() == 2
+    M, h = x.shape
+    assert rstd.numel() == M
+    Rp = (M + 7) // 8 * 8 if Rp is None else Rp
+    assert Rp >= M and Rp % 8 == 0
+    out = torch.empty((h, Rp), device=x.device, dtype=BF16)
+    if Rp != M:
+        out[:, M:].zero_()
+    _lib.check(_L().mm355_rmsnorm_apply_t(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), M, h, out.data_ptr(), Rp, _stream()),
+               "mm355_rmsnorm_apply_t")
     return out
 
 

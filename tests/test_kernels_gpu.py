@@ -251,6 +251,21 @@ def test_gemm_tn_rejects_ragged_k(ops):
         ops.gemm_tn(at, bt, torch.empty(64, 64, device=DEV, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,h,Rp", [(300, 512, 304), (1024, 4096, 1024), (777, 1152, 896)])
+def test_rmsnorm_apply_t_equals_transposed_forward(ops, M, h, Rp):
+    """y^T from the saved rstd in one pass == transpose(rmsnorm_fwd(x)) bit for bit; padding columns are zero; rstd vs oracle."""
+    x = rnd(M, h, seed=21, scale=1.5).to(DEV)
+    w = (1.0 + 0.1 * rnd(h, seed=22)).bfloat16().to(DEV)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5, want_rstd=True)
+    assert torch.equal(y, ops.rmsnorm_fwd(x, w, 1e-5))
+    ref_rstd = torch.rsqrt((x.float() ** 2).mean(-1) + 1e-5)
+    close(rstd.cpu(), ref_rstd.cpu(), 1e-5, 1e-6, "rstd")
+    yt = ops.rmsnorm_apply_t(x, w, rstd, Rp)
+    assert yt.shape == (h, Rp)
+    assert torch.equal(yt[:, :M], y.t())
+    assert not yt[:, M:].any()
+
+
 def test_grad_norm_and_bias_grad_sums_are_deterministic(ops):
     """mm355_sumsq_bf16 / mm355_colsum_bf16 use no atomics: repeated launches give the same bits, and both ACCUMULATE into `out`."""
     x = (torch.randn(37_000_003, device=DEV) * 0.3).bfloat16()          # > MM355_SUMSQ_PARTIALS workgroups, ragged tail
