@@ -263,6 +263,15 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         pd = self._plan_for(inputs_embeds, attention_mask, labels, image_positions)
         plan = pd["host"]
         dev = inputs_embeds.device
+        if position_ids is not None:
+            # The kernels rotate row l of a sample by l (+ the sample's left-padding offset); RoPE only sees position DIFFERENCES, so any
+            # position_ids that advance by one over a sample's valid rows (what the reference builds, metamorph_arch.py:362-399, and
+            # what HF's default arange is) give the same attention.  Anything else (packed sequences, gaps) is refused, not ignored.
+            pid = position_ids.detach().cpu().numpy().reshape(B, L)
+            for b in range(B):
+                rows = np.flatnonzero(plan.attention_mask[b])
+                if rows.size > 1 and not (np.diff(pid[b, rows]) == 1).all():
+                    raise NotImplementedError("position_ids must advance by one over each sample's valid rows (custom positions are not supported)")
         Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
         d = h // Hq
         # Left padding (tokenizer_padding_side = "left", reference metamorph_arch.py:362-386): the attention kernels take per-sample

@@ -190,6 +190,28 @@ def test_logits_eval_mode():
     assert e_hip <= max(2.0 * e_ref, 2e-2)
 
 
+def test_explicit_position_ids_are_checked_not_ignored():
+    """The reference hands position_ids through to HF; this build rotates by the row index, which is the same attention for any
+    positions that advance by one over a sample's valid rows -- and refuses anything else instead of ignoring it."""
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+    model.eval()
+    ids, msk, img = T(g["input_ids"]).to(DEV), T(g["attention_mask"]).to(DEV), T(g["images"]).to(DEV).bfloat16()
+    with torch.no_grad():
+        # (forward(input_ids=...) rebuilds position_ids itself, like the reference; the check guards callers that bring inputs_embeds)
+        _, _, amask, _, emb, _, _, _ = model.prepare_inputs_labels_for_multimodal(ids, None, msk, None, None, img, None, None)
+        B, L = emb.shape[:2]
+        pos = torch.arange(L, device=DEV)[None].expand(B, -1).contiguous()
+        base = model(inputs_embeds=emb, attention_mask=amask, labels=None)
+        same = model(inputs_embeds=emb, attention_mask=amask, position_ids=pos + 7, labels=None)     # a constant offset is fine
+        assert torch.equal(base.logits, same.logits)
+        bad = pos.clone()
+        bad[:, 5:] += 3                                              # a gap inside every sample
+        with pytest.raises(NotImplementedError):
+            model(inputs_embeds=emb, attention_mask=amask, position_ids=bad, labels=None)
+
+
 def test_grad_accumulation_doubles():
     g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
     cfg = tiny_cfg(num_image_tokens=4)
