@@ -12,6 +12,8 @@ attention-pool head that the reference computes and discards are simply not comp
 """
 from __future__ import annotations
 
+import re
+
 import math
 
 import numpy as np
@@ -27,28 +29,24 @@ SO400M_14_384 = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers
                      image_size=384, patch_size=14, layer_norm_eps=1e-6)
 
 
+_TOWER_NAME = re.compile(r"(siglip/CLIP-ViT-SO400M-14|timm/ViT-SO400M-14-SigLIP)(-384)?")
+_NAME_FIELD = re.compile(r"(res|interp)(.*)")
+
+
 def extract_res_interp(model_name):
-    """Same name grammar as the reference (siglip_encoder.py:34-59)."""
-    valid = {
-        "siglip/CLIP-ViT-SO400M-14-384": "hf-hub:timm/ViT-SO400M-14-SigLIP-384",
-        "timm/ViT-SO400M-14-SigLIP-384": "hf-hub:timm/ViT-SO400M-14-SigLIP-384",
-        "siglip/CLIP-ViT-SO400M-14": "hf-hub:timm/ViT-SO400M-14-SigLIP",
-        "timm/ViT-SO400M-14-SigLIP": "hf-hub:timm/ViT-SO400M-14-SigLIP",
-    }
-    res = 384 if "384" in model_name else 224
-    interp = None
-    for prefix, base in valid.items():
-        if model_name.startswith(prefix):
-            base_model_name = base
-            break
-    else:
+    """`--vision_tower` name grammar of the reference (siglip_encoder.py:34-59): one of two spellings of SigLIP-SO400M/14, optionally
+    the 384-pixel checkpoint, then `-res<N>` (input resolution; default 384 if "384" occurs anywhere in the name, else 224) and
+    `-interp<N>` (token count after interpolation) in any order.  Returns (timm hub name, resolution, interp or None); unknown towers and
+    malformed fields raise ValueError."""
+    m = _TOWER_NAME.match(model_name)
+    if m is None:
         raise ValueError(f"Unknown vision tower: {model_name}")
-    for part in model_name.split("-"):
-        if part.startswith("res"):
-            res = int(part[3:])
-        elif part.startswith("interp"):
-            interp = int(part[6:])
-    return base_model_name, res, interp
+    fields = {"res": 384 if "384" in model_name else 224, "interp": None}
+    for token in model_name.split("-"):
+        f = _NAME_FIELD.fullmatch(token)
+        if f:
+            fields[f.group(1)] = int(f.group(2))           # "-res" / "-resnet": ValueError, as in the reference
+    return "hf-hub:timm/ViT-SO400M-14-SigLIP" + (m.group(2) or ""), fields["res"], fields["interp"]
 
 
 class _PatchEmbedding(nn.Module):

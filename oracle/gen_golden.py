@@ -668,6 +668,25 @@ def gen_decode():
               f"pred_z bf16-vs-f32 rel {float((emb16 - emb).norm() / emb.norm()):.3e}")
 
 
+def gen_names():
+    """A10: the `--vision_tower` name grammar (reference siglip_encoder.py:34-59), outputs and errors."""
+    from metamorph.model.multimodal_encoder.siglip_encoder import extract_res_interp
+    cases = ["siglip/CLIP-ViT-SO400M-14-384", "timm/ViT-SO400M-14-SigLIP-384-res512", "siglip/CLIP-ViT-SO400M-14-res384-interp144",
+             "timm/ViT-SO400M-14-SigLIP-interp64-res224", "siglip/CLIP-ViT-SO400M-14", "siglip/CLIP-ViT-SO400M-14-384-interp256",
+             "siglip/CLIP-ViT-SO400M-14-res12-res34", "openai/clip-vit-large", "siglip/CLIP-ViT-SO400M-14-resnet",
+             "timm/ViT-SO400M-14-SigLIP-interp"]
+    out = []
+    for n in cases:
+        try:
+            r = list(extract_res_interp(n))
+        except ValueError:
+            r = "ValueError"
+        out.append([n, r])
+    with open(os.path.join(OUT, "a10_tower_names.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"    {len(out)} names")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

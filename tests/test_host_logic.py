@@ -400,3 +400,14 @@ def test_splice_plan_refuses_what_the_reference_refuses():
     with pytest.raises(IndexError):
         build_splice_plan(np.array([[A, -7, 5]]), None, None, 1, 4, 64, vocab_size=128258)
     build_splice_plan(np.array([[A, 5, 128257]]), None, None, 1, 4, 64, vocab_size=128258)
+
+
+def test_vision_tower_name_grammar_matches_reference():
+    """`extract_res_interp` against outputs recorded from the reference function (siglip_encoder.py:34-59), errors included."""
+    from metamorph_amd.model.multimodal_encoder.siglip_encoder import extract_res_interp
+    for name, want in json.load(open(os.path.join(GOLDEN, "a10_tower_names.json"))):
+        if want == "ValueError":
+            with pytest.raises(ValueError):
+                extract_res_interp(name)
+        else:
+            assert list(extract_res_interp(name)) == want, name
