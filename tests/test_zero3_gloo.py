@@ -96,6 +96,20 @@ def _worker(rank, world, port, tmp):
         full = opt.gather_full_parameters()
         flat = torch.cat([(full[p] if p in full else p.data).reshape(-1) for p in params])
         torch.save(flat, os.path.join(tmp, f"z3_rank{rank}.pt"))
+        # this rank's shard checkpoint restored into a FRESH optimizer over differently initialised weights: every parameter -- the
+        # other ranks' slices of the resident tensors included -- must come back (load_state_dict all-gathers the resident segments)
+        st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+        model2 = _build()
+        with torch.no_grad():
+            for p in model2.parameters():
+                p.add_(0.5)
+        params2 = [p for p in model2.parameters() if p.requires_grad]
+        opt2 = Zero3AdamW(params2, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0, shard_update=_oracle_update,
+                          sumsq=_oracle_sumsq, clip_coef=_oracle_clip, accumulate=_accum, param_slots=2, grad_slots=1, min_shard_numel=1)
+        opt2.load_state_dict(st)
+        full2 = opt2.gather_full_parameters()
+        flat2 = torch.cat([(full2[p] if p in full2 else p.data).reshape(-1) for p in params2])
+        assert torch.equal(flat2, flat) and opt2._step == opt._step
         # fused q/k/v block adjacency survives the re-pointing into a slot
         F.params_ready(layers[1])
         att = layers[1].self_attn
