@@ -400,3 +400,10 @@ class Zero2AdamW(torch.optim.Optimizer):
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+        # the bf16 parameters follow the restored master weights, on every rank (like load_consolidated_optimizer_state)
+        for sg in self.segs:
+            sg["my_param"].copy_(self.master[sg["so"]:sg["so"] + sg["m"]].to(sg["my_param"].dtype))
+        self._all_gather_params()
+        if self.flat_param.is_cuda:
+            from . import functional as F
+            F.bump_param_generation()

@@ -138,6 +138,7 @@ def test_single_process_world1(tmp_path):
     opt2 = Zero2AdamW(_make_params(torch.float32), lr=1e-2, shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.master, opt.master) and opt2._step == 1
+    assert all(torch.equal(a.data, b.data) for a, b in zip(opt2.params, opt.params))       # parameters follow the restored master copy
 
 
 # ------------------------------------------------------------------ row N3: world-size independent optimizer checkpoints
