@@ -1,225 +1,9 @@
-// Attention, d == 128 fast path (gfx950): launchers + the non-template kernels (ping-pong forward experiment, dK/dV).
+// Attention, d == 128 fast path (gfx950): launchers + the dK/dV kernel.
 // The forward / dQ kernel templates live in attn3_kernels.h.
 #include "attn3_kernels.h"
 
 namespace attn3 {
 using namespace attn2;
-
-// ================================================================================================
-// forward, ping-pong form: workgroup = 256 query rows (8 waves x 32) = two groups (wave w and w + 4 share a SIMD) running ONE
-// BARRIER APART.  Per KV tile a wave alternates an M phase -- the 32 PV MFMAs of tile t-1 and the 32 QK^T MFMAs of tile t,
-// with their fragment reads -- and a V phase -- the softmax of tile t (all VALU: exponentials, running max / sum, packing
-// P^T), its four LDS-DMA pieces of tile t+2 and the counted wait for tile t+1; while one group is in M the other is in V, so
-// the matrix pipe and the VALU of every SIMD are fed by different waves instead of fighting inside one.
-// K / V tiles live in four-slot rings (128 KiB, 1 workgroup per CU); K(t+3) and V(t+2) are issued in V(t), the counted wait
-// for K(t+1) / V(t) sits at the end of M(t) so that BOTH groups have retired their pieces one barrier before anyone reads them.
-// EXPERIMENT (MM355_ATTN_PP=1), parity-green but 10 % SLOWER than fwd_kernel at B=8, L=2048 (0.52 vs 0.47 ms): unlike the GEMM,
-// the M phase still carries its fragment reads and 256-row causal blocks idle more waves per tile; kept for A/B only.
-// ================================================================================================
-__global__ __launch_bounds__(512) void fwd_pp_kernel(Args a) {
-    constexpr int KS = 4, NF = 8, RQ = 2, ROWS = 32, BQ = 256, NSLOT = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // K ring [4] | V ring [4]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int fr = lane & 15, fq = lane >> 4;
-    int xb, hq, b;
-    block_coords((a.L + BQ - 1) / BQ, a.Hq, inner_heads(a.Hq, a.Hq / a.Hkv), true, xb, hq, b);
-    const int q0 = xb * BQ;
-    const int hk = hq / (a.Hq / a.Hkv);
-    const int L = a.L;
-    const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
-    const int64_t row_base = (int64_t)b * L;
-    uint16_t* o_base = a.o + row_base * a.ld_o + (int64_t)hq * DP;
-    float* lse_base = a.lse + ((int64_t)b * a.Hq + hq) * L;
-
-    if (q0 >= seqlen) {                                      // whole block is padding: o = 0, lse = 0
-        for (int v = tid; v < BQ * (DP / 8); v += 512) {
-            const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
-            if (q0 + r < L) *(u32x4*)(o_base + (int64_t)(q0 + r) * a.ld_o + c) = u32x4{0u, 0u, 0u, 0u};
-        }
-        for (int r = tid; r < BQ; r += 512)
-            if (q0 + r < L) lse_base[q0 + r] = 0.f;
-        return;
-    }
-    const int kv_end = a.causal ? min(seqlen, q0 + BQ) : seqlen;
-    const int ntiles = (kv_end + 63) >> 6;
-    const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * DP;
-    const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * DP;
-    // LDS-DMA duty: 16 K pieces + 16 V pieces per tile over 8 waves: wave w moves K pieces 2w, 2w+1 and the same of V
-    uint32_t soff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 4 + (lane >> 4);
-        soff[i] = (uint32_t)(row * a.ld_k * 2 + (((lane & 15) ^ swzN<DS>(row)) << 4));
-    }
-    auto issue = [&](const uint16_t* base, int t, int ring) {   // rows of tile t of K (ring 0) or V (ring 1) -> slot t & 3
-        const int row0 = t * 64;
-        unsigned char* dst = smem + (ring * NSLOT + (t & 3)) * TILE + wave * 2048;
-        if (row0 + 64 <= L) {
-            const unsigned char* tb = (const unsigned char*)(base + (int64_t)row0 * a.ld_k);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(tb + soff[i]), (lptr_t)(dst + i * 1024), 16, 0, 0);
-        } else {                                             // ragged last tile: clamp the rows (masked below)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (wave * 2 + i) * 4 + (lane >> 4);
-                const int64_t off = (int64_t)min(row0 + row, L - 1) * a.ld_k + (((lane & 15) ^ swzN<DS>(row)) << 3);
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(dst + i * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto wait_pieces = [&](int n) {                          // at most n of my LDS-DMA pieces may still be in flight
-        if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // K runs three tiles ahead of its use, V two (V(t) is consumed one phase later than K(t)); issue order = need order
-    issue(kbase, 0, 0);
-    if (1 < ntiles) issue(kbase, 1, 0);
-    issue(vbase, 0, 1);
-    if (2 < ntiles) issue(kbase, 2, 0);
-    if (1 < ntiles) issue(vbase, 1, 1);
-
-    const int qw0 = q0 + wave * ROWS;                        // first query row of this wave
-    bf16x8 qf[RQ][KS];                                       // B operand: Q[q = fr][d chunk]
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-        const uint16_t* qp = a.q + (row_base + min(qw0 + rq * 16 + fr, L - 1)) * a.ld_q + (int64_t)hq * DP;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) qf[rq][kk] = *(const bf16x8*)(qp + kk * 32 + fq * 8);
-    }
-    f32x4 ot[RQ][NF];                                        // O^T[d = j*16 + fq*4 + r][q = fr]
-    float m_run[RQ], l_part[RQ];
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-        m_run[rq] = M_INIT; l_part[rq] = 0.f;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) ot[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    int k_off[4];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) k_off[kk] = offN<DS>(fr, kk * 4 + fq);
-    const float sl2 = a.scale * LOG2E;
-    constexpr float RESCALE_THR = 6.0f;
-    // a wave has work on tile t iff some of its rows may see it
-    auto active = [&](int t) { return t >= 0 && t < ntiles && !(a.causal && t * 64 > qw0 + ROWS - 1); };
-
-    f32x4 st[RQ][4];                                         // S^T of the tile between its M and V phase
-    bf16x8 pb[RQ][2];                                        // P^T (packed) between V(t) and M(t+1)
-
-    wait_pieces(2 * ((1 < ntiles) + 1 + (2 < ntiles) + (1 < ntiles)));   // everything but K(0) may still fly (Q loads drain too)
-    __builtin_amdgcn_s_barrier();                            // K(0) is in LDS for everybody
-    if (grp == 1) __builtin_amdgcn_s_barrier();              // the second group runs one barrier behind
-
-    for (int t = 0; t <= ntiles; ++t) {
-        // ---------------- M phase: PV of tile t-1, then QK^T of tile t
-        __builtin_amdgcn_s_setprio(1);
-        if (active(t - 1)) {
-            const unsigned char* sV = smem + (NSLOT + ((t - 1) & 3)) * TILE;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const bf16x8 va = read_nat_perm<DS>(sV, kk * 32, j, fr, fq);      // V^T[d][keys perm]
-#pragma unroll
-                    for (int rq = 0; rq < RQ; ++rq) ot[rq][j] = mfma16(va, pb[rq][kk], ot[rq][j]);
-                }
-        }
-        if (active(t)) {
-            const unsigned char* sK = smem + (t & 3) * TILE;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) st[rq][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + j * 4096 + k_off[kk]);
-#pragma unroll
-                    for (int rq = 0; rq < RQ; ++rq) st[rq][j] = mfma16(kf, qf[rq][kk], st[rq][j]);
-                }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        // my reads of this phase are done before anybody restages those slots; K(t+1) and V(t), which the next M phase of
-        // EITHER group reads, have landed (only the batch issued in V(t-1) -- K(t+2), V(t+1) -- may still fly)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_pieces(2 * ((t + 2 < ntiles) + (t + 1 < ntiles)));
-        __builtin_amdgcn_s_barrier();
-        // ---------------- V phase: stage K(t+3), V(t+2); softmax of tile t
-        if (t + 3 < ntiles) issue(kbase, t + 3, 0);
-        if (t + 2 < ntiles) issue(vbase, t + 2, 1);
-        if (active(t)) {
-            const int kv0 = t * 64;
-            const bool need_mask = (kv0 + 64 > seqlen) || (a.causal && kv0 + 63 > qw0);
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-                if (need_mask) {
-                    const int qg = qw0 + rq * 16 + fr;
-                    const int lim = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - kv0 - fq * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) st[rq][j][r] = (j * 16 + r > lim) ? -INFINITY : st[rq][j][r];
-                }
-                float mx = fmaxf(fmaxf(st[rq][0][0], st[rq][0][1]), fmaxf(st[rq][0][2], st[rq][0][3]));
-#pragma unroll
-                for (int j = 1; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(st[rq][j][0], st[rq][j][1]), fmaxf(st[rq][j][2], st[rq][j][3])));
-                mx = quad_max(mx) * sl2;
-                if (__any(mx > m_run[rq] + RESCALE_THR)) {   // deferred rescale (covers the PV of tile t-1 just accumulated)
-                    const float mn = fmaxf(m_run[rq], mx);
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[rq] - mn);
-                    l_part[rq] *= alpha;
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) ot[rq][j] *= alpha;
-                    m_run[rq] = mn;
-                }
-                const float mref = m_run[rq];
-                float rs = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(st[rq][j][r], sl2, -mref));
-                        st[rq][j][r] = p;
-                        rs += p;
-                    }
-                l_part[rq] += rs;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) pb[rq][kk] = pack_acc(st[rq][2 * kk], st[rq][2 * kk + 1]);
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();              // the first group catches the barrier count up
-    __syncthreads();                                         // ring is free: reuse it as the output staging area
-
-    unsigned char* so = smem + wave * (ROWS * DP * 2);
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-        const int qg = qw0 + rq * 16 + fr;
-        const bool valid = qg < seqlen;
-        const float l_run = quad_sum(l_part[rq]);
-        const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            u32x2 w;
-            w.x = pack2bf(ot[rq][j][0] * inv, ot[rq][j][1] * inv);
-            w.y = pack2bf(ot[rq][j][2] * inv, ot[rq][j][3] * inv);
-            *(u32x2*)(so + (rq * 16 + fr) * (DP * 2) + (j * 16 + fq * 4) * 2) = w;
-        }
-        if (fq == 0 && qg < L) lse_base[qg] = valid ? (m_run[rq] + log2f(l_run)) * 0.6931471805599453f : 0.f;
-    }
-    __syncthreads();
-    for (int v = lane; v < ROWS * (DP / 8); v += 64) {
-        const int r = v / (DP / 8), c = (v % (DP / 8)) * 8;
-        const int qg = qw0 + r;
-        if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + c) = *(const u32x4*)(so + r * (DP * 2) + c * 2);
-    }
-}
 
 // ================================================================================================
 // dK / dV: workgroup = (KV tile of 64 keys, KV head); wave owns 16 keys (K / V fragments in registers) and walks the 64-row
@@ -235,10 +19,7 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
     const int fr = lane & 15, fq = lane >> 4;
     const int group = a.Hq / a.Hkv;
     int xb, hk, b;
-#ifndef MM355_DKDV_INNER
-#define MM355_DKDV_INNER inner_heads(a.Hkv, 1)
-#endif
-    block_coords((a.L + 63) / 64, a.Hkv, MM355_DKDV_INNER, false, xb, hk, b);   // one block per KV head: it walks the query heads of its group
+    block_coords((a.L + 63) / 64, a.Hkv, inner_heads(a.Hkv, 1), false, xb, hk, b);   // one block per KV head: it walks the query heads of its group
     const int kv0 = xb * 64;
     const int L = a.L;
     const int seqlen = a.seqlens ? min(a.seqlens[b], L) : L;
@@ -390,27 +171,10 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
 
 }  // namespace attn3
 
-static int fwd_pp_launch(const attn2::Args& a, hipStream_t s) {
-    constexpr int LDS = 8 * attn3::TILE;                     // 128 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn3::fwd_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
-    const int64_t nblk = (int64_t)((a.L + 255) / 256) * a.Hq * a.B;
-    if (nblk > 0x7fffffff) return MM355_EINVAL;
-    hipLaunchKernelGGL(attn3::fwd_pp_kernel, dim3((unsigned)nblk), dim3(512), LDS, s, a);
-    return mm_launch_status();
-}
-
-// RQ = 4 instantiations (one wave per SIMD, accumulators in AGPRs): attn3_wide.hip
 int mm355_attn3_fwd_wide_launch(const attn2::Args& a, hipStream_t s);
 int mm355_attn3_dq_wide_launch(const attn2::Args& a, hipStream_t s);
 
 int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
-    static const bool pp = [] { const char* e = std::getenv("MM355_ATTN_PP"); return e && e[0] == '1'; }();
-    if (pp) return fwd_pp_launch(a, s);
     // MM355_ATTN_RQ=4: the 64-rows-per-wave experiment (attn3_wide.hip); default: 32 rows per wave, two workgroups per CU
     static const int rq = [] { const char* e = std::getenv("MM355_ATTN_RQ"); return (e && e[0] == '4') ? 4 : 2; }();
     if (rq == 4) return mm355_attn3_fwd_wide_launch(a, s);
