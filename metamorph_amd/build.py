@@ -10,13 +10,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn3_wide.hip", "decode.hip", "losses.hip"]
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "decode.hip", "losses.hip"]
 HEADERS = ["mm355_common.h", "attn2.h", "attn3_kernels.h"]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
-# MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD) everywhere except the one-wave-per-SIMD kernels of
-# attn3_wide.hip, which need the accumulator half of the unified 512-entry file
+# MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD): no accumulator <-> VGPR moves around the VALU phases
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-FLAGS_OF = {"attn3_wide.hip": BASE_FLAGS}
+FLAGS_OF = {}                                                # per-file overrides
 
 
 def _hipcc():

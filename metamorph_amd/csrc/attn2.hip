@@ -567,9 +567,7 @@ static int fwd_launch_rq(const attn2::Args& a, int dp, hipStream_t s) {
 }
 
 int mm355_attn2_fwd_launch(const attn2::Args& a, int dp, hipStream_t s) {
-    const char* e = std::getenv("MM355_ATTN_RQ");           // A/B knob: query row-fragments per wave
-    if (e && e[0] == '2') return fwd_launch_rq<2>(a, dp, s);
-    return fwd_launch_rq<1>(a, dp, s);
+    return fwd_launch_rq<1>(a, dp, s);                       // one 16-row fragment per wave (two measured no faster on the tower shapes)
 }
 
 int mm355_attn2_dq_launch(const attn2::Args& a, int dp, hipStream_t s) {

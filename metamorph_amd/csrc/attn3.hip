@@ -171,13 +171,8 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
 
 }  // namespace attn3
 
-int mm355_attn3_fwd_wide_launch(const attn2::Args& a, hipStream_t s);
-int mm355_attn3_dq_wide_launch(const attn2::Args& a, hipStream_t s);
 
 int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
-    // MM355_ATTN_RQ=4: the 64-rows-per-wave experiment (attn3_wide.hip); default: 32 rows per wave, two workgroups per CU
-    static const int rq = [] { const char* e = std::getenv("MM355_ATTN_RQ"); return (e && e[0] == '4') ? 4 : 2; }();
-    if (rq == 4) return mm355_attn3_fwd_wide_launch(a, s);
     const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL(attn3::fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
@@ -185,8 +180,6 @@ int mm355_attn3_fwd_launch(const attn2::Args& a, hipStream_t s) {
 }
 
 int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
-    static const int rq = [] { const char* e = std::getenv("MM355_ATTN_RQ_DQ"); return (e && e[0] == '4') ? 4 : 2; }();
-    if (rq == 4) return mm355_attn3_dq_wide_launch(a, s);
     const int64_t nblk = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL(attn3::dq_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);

@@ -1,6 +1,6 @@
-// Kernel templates of the d == 128 attention path shared by attn3.hip (RQ = 2: two waves per SIMD) and attn3_wide.hip (RQ = 4: one wave
-// per SIMD with the whole 512-register file; that translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form so that the accumulators
-// can live in AGPRs).
+// Kernel templates of the d == 128 attention path (instantiated in attn3.hip with RQ = 2: 32 query rows per wave, two waves per SIMD).
+// RQ = 4 (64 rows per wave, one wave per SIMD, accumulators in AGPRs: its own translation unit without -amdgpu-mfma-vgpr-form) was built
+// and measured in round 2 -- 1.06 vs 0.69 ms forward -- and removed again; numbers in DESIGN.md section 4, profiles/r2_attn_rq_ab.log.
 #pragma once
 // Attention, d == 128 fast path (gfx950): the formulation of attn2.hip (swapped products on natural [rows][128] tiles, P^T / dS^T
 // never leave registers) with the staging rebuilt around the LDS-DMA engine:
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void fwd_kernel(Args a) {
     // instead of two, half the LDS traffic per flop (not the limiter: LDS is 20 % busy, tools/probes/lds_throughput_probe).
     // Measured (B = 12, L = 2048, 32/8 heads): RQ = 4 is SLOWER, 1.06 vs 0.69 ms forward and +0.5 ms in dQ -- with one wave per SIMD
     // nothing overlaps the softmax VALU phase with the MFMA phases, and a compiler-scheduled in-wave pipeline (S(h+1) || softmax(h) ||
-    // PV(h-1) in one basic block) was slower still (1.34 ms: ~1 300 accumulator<->VGPR moves).  Kept as an opt-in A/B (MM355_ATTN_RQ=4).
+    // PV(h-1) in one basic block) was slower still (1.34 ms: ~1 300 accumulator<->VGPR moves).  (Not instantiated any more.)
     constexpr int KS = 4, NF = 8, ROWS = 16 * RQ, BQ = 4 * ROWS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];       // K ring [2] | V ring [2]
 #ifdef MM355_ATTN_TIMING                                     // TIMING-ONLY build: phase timestamps of wave 0 overwrite the block's lse rows

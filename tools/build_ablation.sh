@@ -9,6 +9,5 @@ for f in gemm_bf16 rowwise elementwise attn attn2 attn3 decode losses; do
   if [ -f ../lib/$f.o ] && [ $f != attn3 ] && [ $f != attn2 ] && [ $f != attn ]; then cp ../lib/$f.o ../../$OUT/$f.o; else
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c $f.hip -o ../../$OUT/$f.o & fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c attn3_wide.hip -o ../../$OUT/attn3_wide.o &
 wait
 cd ../../$OUT && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libmm355.so *.o
