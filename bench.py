@@ -81,6 +81,19 @@ def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
     return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
 
 
+def build_bench_model(dev, layers=32, vit_layers=27, image_tokens=256, seed=1234):
+    """The model this benchmark times: LLaMA-3-8B geometry + SO400M tower, random weights from torch's device generator under a
+    fixed seed (identical on every rank; the BATCH is seeded per rank).  tests/test_fulldepth_gpu.py builds the same model with the
+    same seed and compares its step-0 forward / backward with the fp32 oracle at full depth."""
+    from metamorph_amd.factory import LLAMA3_8B, build_model
+    llm = dict(LLAMA3_8B, num_hidden_layers=layers)
+    geo = dict(num_hidden_layers=vit_layers)
+    torch.manual_seed(seed)
+    model = build_model(llm, geo, num_image_tokens=image_tokens, max_length=4096, device=dev, init_on_device=True)
+    model.train()
+    return model
+
+
 class GemmTimer:
     """HIP-event timing of every GEMM launch (torch.cuda.Event == hipEvent on the stream the kernels are launched on)."""
 
@@ -295,15 +308,10 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    from metamorph_amd.factory import LLAMA3_8B, build_model
     from metamorph_amd.zero2 import Zero2AdamW, tag_segments
 
-    llm = dict(LLAMA3_8B, num_hidden_layers=args.layers)
-    geo = dict(num_hidden_layers=args.vit_layers)
-    torch.manual_seed(1234)                                      # identical initial weights on every rank (data parallel); the BATCH is seeded per rank
     t_build = time.time()
-    model = build_model(llm, geo, num_image_tokens=args.image_tokens, max_length=4096, device=dev, init_on_device=True)
-    model.train()
+    model = build_bench_model(dev, layers=args.layers, vit_layers=args.vit_layers, image_tokens=args.image_tokens)
     if args.train_vision:                                        # reference: freeze_vision=False + `vision_lr` parameter group
         tower = model.get_model().vision_tower
         tower.freeze_vision = False
@@ -347,8 +355,10 @@ def main():
         opt.step()
         return out.loss
 
+    loss_first = None                                            # loss of the very first step: the model as built, before any update
     for _ in range(args.warmup):
         loss = step()
+        loss_first = loss.detach() if loss_first is None else loss_first
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -357,6 +367,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        loss_first = loss.detach() if loss_first is None else loss_first
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -411,7 +422,7 @@ def main():
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
-            "loss": round(loss_val, 4), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
+            "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }

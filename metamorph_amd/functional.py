@@ -883,15 +883,18 @@ class MeanAbsLossFn(Function):
     normalize_vision nor apply_softmax is set -- the constructor default)."""
 
     @staticmethod
-    def forward(ctx, pred, target):
+    def forward(ctx, pred, target, denom_rows=None):
+        """denom_rows: the row count the reference divides by (len(target), :217) when it differs from the rows compared."""
         abs_sum, dpred = ops.mean_abs_loss(pred, target, want_grad=True)
         ctx.save_for_backward(dpred)
-        return (abs_sum * (1.0 / pred.numel())).reshape(())
+        R = pred.shape[0]
+        ctx.scale = 1.0 if denom_rows in (None, R) else R / float(denom_rows)       # the kernel's gradient carries 1 / (R C)
+        return (abs_sum * (ctx.scale / pred.numel())).reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return _scaled_copy(dpred, g), None
+        return _scaled_copy(dpred, g * ctx.scale if ctx.scale != 1.0 else g), None, None
 
 
 class SoftCELossFn(Function):

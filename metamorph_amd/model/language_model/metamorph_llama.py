@@ -107,6 +107,10 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         # set by PreTrainedModel.gradient_checkpointing_enable() (HF looks for this attribute on the sub-modules): per-layer
         # recompute in DecoderLayerFn / SiglipLayerFn instead of torch.utils.checkpoint
         self.gradient_checkpointing = False
+        # optional fn(layer_index, rows [B*L, h]) called with every decoder layer's output (what the reference's forced
+        # `output_hidden_states=True`, metamorph_llama.py:345, would collect); rows of a left-padded batch are in the moved
+        # (right-padded) layout.  Used by the full-depth parity test; None costs nothing.
+        self.layer_output_hook = None
 
     def rope_tables(self, L, device):
         d = self.config.hidden_size // self.config.num_attention_heads
@@ -248,8 +252,8 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                     return_dict=None, cache_position=None, image_positions=None, decoding=False, image_features=None):
         """Reference metamorph_llama.py:285-498."""
         if past_key_values is not None or use_cache:
-            raise NotImplementedError("KV-cache decoding is a 'next' row (SURVEY.md section 8f N1); the reference itself "
-                                      "forces use_cache=False in greedy_decode")
+            raise NotImplementedError("llm_forward is the training / prefill pass and takes no past_key_values; cached decoding runs "
+                                      "through greedy_decode / generate (functional.KVCache + the decode-shape kernels)")
         if output_attentions:
             raise NotImplementedError("output_attentions: attention probabilities are never materialised by the flash kernel")
         return_dict = True if return_dict is None else return_dict
@@ -293,8 +297,11 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
             x = x.contiguous()
         if shift:
             x = F.RowsPermuteFn.apply(x, to_right_d, to_left_d)
-        for layer in self.model.layers:
+        tap = self.model.layer_output_hook
+        for li, layer in enumerate(self.model.layers):
             x = F.decoder_layer(x, layer, meta)
+            if tap is not None:                                         # the reference's output_hidden_states tuple, one entry at a time
+                tap(li, x)
         if shift:
             x = F.RowsPermuteFn.apply(x, to_left_d, to_right_d)
         hid = self.model.norm(x)                                       # [B*L, h]
@@ -316,6 +323,14 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
 
         loss = None
         logits = None
+        tp = int(getattr(cfg, "pretraining_tp", 1) or 1)
+        if tp > 1 and self.lm_head.weight.shape[0] % tp:
+            # reference :393-396: `weight.split(vocab_size // tp)` yields tp + 1 slices when tp does not divide the vocabulary and the
+            # loop over range(tp) silently drops the tail rows (for V = 128258 and tp = 4: <image_start> / <image_end>); not reproduced
+            raise NotImplementedError(f"pretraining_tp={tp} does not divide the vocabulary ({self.lm_head.weight.shape[0]} rows)")
+        # pretraining_tp > 1 (reference :393-396) computes the logits in `tp` vocabulary slices and concatenates them: every logit is
+        # the same K-long dot product either way, and the kernels below tile the vocabulary anyway (the fused CE walks row chunks x
+        # 256-column tiles), so the sliced and the unsliced form are one computation here (golden: tests/golden/r3_pretraining_tp2_*)
         if labels is None or getattr(cfg, "mm355_return_logits", False) or not torch.is_grad_enabled():
             # inference / evaluation: the full fp32 logits tensor of the reference (metamorph_llama.py:398-399)
             logits = ops.gemm(hid.detach(), self.lm_head.weight.data, out_f32=True).view(B, L, -1)
@@ -338,10 +353,15 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                         # F.cosine_similarity raises on a row-count mismatch -- or, under 'concat_interpolation', on the width mismatch
                         # between the 1152-wide head and the 4 x 1152 targets -- and the reference's try/except (:451-455) substitutes CE
                         l_img = ce
-                    elif R != Rt or R == 0:
-                        # soft-CE: broadcasting error; mean-abs (`mse_loss_fn`): a Python float has no .item() / division by len 0
-                        raise RuntimeError(f"image-AR head ({'soft-CE' if self.apply_softmax else 'mean-abs'}): {R} prediction rows vs "
-                                           f"{Rt} target rows -- the reference raises here as well (metamorph_llama.py:445,459-466)")
+                    elif self.apply_softmax and (R != Rt or R == 0):
+                        # soft-CE: `target * log(pred)` with different row counts is a broadcasting error in the reference (:445)
+                        raise RuntimeError(f"image-AR head (soft-CE): {R} prediction rows vs {Rt} target rows -- the reference raises here "
+                                           f"as well (metamorph_llama.py:445)")
+                    elif R == 0 or Rt == 0:
+                        # mean-abs (`mse_loss_fn`, :211-219): no target rows -> division by len(z) = 0; no prediction rows -> the Python
+                        # float 0.0 has no .item() (:466)
+                        raise RuntimeError(f"image-AR head (mean-abs): {R} prediction rows vs {Rt} target rows -- the reference raises here "
+                                           f"as well (metamorph_llama.py:211-219,466)")
                     else:
                         pred_in = F.RowsGatherFn.apply(hid, pd["pred_rows"])
                         pred = self.vision_head(pred_in).contiguous()
@@ -350,8 +370,14 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                             l_img = F.SoftCELossFn.apply(pred, tgt, self.normalize_vision)
                         elif self.normalize_vision:                      # -mean cos (:449-455)
                             l_img = F.CosineLossFn.apply(pred, tgt, True)
-                        else:                                            # mean |t - p| (`mse_loss_fn`, :459) -- the constructor default
-                            l_img = F.MeanAbsLossFn.apply(pred, tgt)
+                        else:
+                            # mean |t - p| (`mse_loss_fn`, :459) -- the constructor default.  The reference walks zip(target rows,
+                            # prediction rows) and divides by len(target): with R != Rt it silently uses the first min(R, Rt) row pairs
+                            # and still divides by Rt (:215-217)
+                            n = min(R, Rt)
+                            if n != R:
+                                pred = pred[:n].contiguous()
+                            l_img = F.MeanAbsLossFn.apply(pred, tgt[:n].contiguous() if n != Rt else tgt, Rt)
                 else:
                     l_img = ce                                          # metamorph_llama.py:461-462
                 self._loss_language_t = ce.detach()

@@ -173,10 +173,28 @@ class MetaMorphTrainer(Trainer):
             with warnings.catch_warnings(record=True):
                 self.lr_scheduler.load_state_dict(torch.load(sched, map_location="cpu", weights_only=True))
 
+    def save_model(self, output_dir=None, _internal_call=False):
+        """HF's `save_model` calls `_save` on the `should_save` rank only; under ZeRO-3 the model's decoder layers exist as per-rank
+        shards, so the gather behind `_save` is a collective EVERY rank must enter (HF does the same in its DeepSpeed / FSDP branches,
+        transformers Trainer.save_model).  All ranks gather layer by layer; only the saving rank keeps (host copies of) the tensors."""
+        z = self._zero2()
+        if not isinstance(z, Zero3AdamW) or getattr(self.args, "tune_mm_mlp_adapter", False):
+            return super().save_model(output_dir, _internal_call=_internal_call)
+        if output_dir is None:
+            output_dir = self.args.output_dir
+        z.synchronize()
+        state_dict = z.full_state_dict(self.model, device="cpu", keep=bool(self.args.should_save))
+        if self.args.should_save:
+            self._save(output_dir, state_dict=state_dict)
+        if self.args.push_to_hub and not _internal_call:
+            self.push_to_hub(commit_message="Model save", revision=getattr(self.args, "hub_revision", None))
+
     def _save(self, output_dir=None, state_dict=None):
         if getattr(self.args, "tune_mm_mlp_adapter", False):
             return
         z = self._zero2()
-        if state_dict is None and isinstance(z, Zero3AdamW):    # the module tree holds no decoder-layer weights between steps: gather
-            state_dict = {k: v.cpu() for k, v in z.full_state_dict(self.model).items()}
+        if state_dict is None and isinstance(z, Zero3AdamW):
+            if z.world > 1:
+                raise RuntimeError("_save under ZeRO-3 needs the gathered state dict: call save_model() (a collective every rank enters)")
+            state_dict = z.full_state_dict(self.model, device="cpu")
         super()._save(output_dir, state_dict)

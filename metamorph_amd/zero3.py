@@ -422,25 +422,45 @@ class Zero3AdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ full parameters (model save, evaluation without hooks)
     @torch.no_grad()
-    def gather_full_parameters(self):
-        """name-less {parameter: full bf16 tensor} of the sharded layers (`stage3_gather_16bit_weights_on_model_save`,
-        reference scripts/zero3.json:26): every rank receives the complete tensors."""
-        out = {}
+    def iter_full_layers(self):
+        """Yields (segment, full) for every sharded layer segment in order, `full` a flat bf16 view holding the complete layer.  ONE
+        layer-sized buffer is reused for all layers (peak = a single 1.7 GB slot at LLaMA-3-70B, not 80 of them): the consumer must copy
+        what it keeps before advancing.  Collective -- every rank of the group must iterate."""
+        buf = None
         for i in self.layer_order:
             sg = self.segs[i]
-            full = torch.empty(sg["n"], device=sg["p_shard"].device, dtype=sg["p_shard"].dtype)
+            if buf is None or buf.numel() < sg["n"]:
+                buf = torch.empty(max(self.segs[j]["n"] for j in self.layer_order), device=sg["p_shard"].device, dtype=sg["p_shard"].dtype)
+            full = buf[:sg["n"]]
             if self._coll:
-                parts = [torch.empty_like(sg["p_shard"]) for _ in range(self.world)]
-                dist.all_gather(parts, sg["p_shard"], group=self.pg)
-                for r, t in enumerate(parts):
-                    full[r * sg["m"]:(r + 1) * sg["m"]].copy_(t)
+                if dist.get_backend(self.pg) == "nccl":
+                    dist.all_gather_into_tensor(full, sg["p_shard"], group=self.pg)
+                else:
+                    parts = [torch.empty_like(sg["p_shard"]) for _ in range(self.world)]
+                    dist.all_gather(parts, sg["p_shard"], group=self.pg)
+                    for r, t in enumerate(parts):
+                        full[r * sg["m"]:(r + 1) * sg["m"]].copy_(t)
+                    del parts
             else:
                 full[:sg["m"]].copy_(sg["p_shard"])
+            yield sg, full
+
+    @torch.no_grad()
+    def gather_full_parameters(self, device=None, keep=True):
+        """{parameter: full bf16 tensor} of the sharded layers (`stage3_gather_16bit_weights_on_model_save`, reference
+        scripts/zero3.json:26).  Gathered ONE LAYER AT A TIME through a single reusable buffer; every tensor is copied out to `device`
+        (default: the shard's device; "cpu" for a model save) before the next layer is gathered.  keep=False: take part in the
+        collectives but keep nothing (the ranks that do not write the checkpoint)."""
+        out = {}
+        for sg, full in self.iter_full_layers():
+            if not keep:
+                continue
             for p, o, shp in zip(sg["params"], sg["offs"], sg["shapes"]):
                 n = 1
                 for d in shp:
                     n *= d
-                out[p] = full[o:o + n].view(shp)
+                t = full[o:o + n].view(shp)
+                out[p] = t.to(device) if (device is not None and torch.device(device) != t.device) else t.clone()
         return out
 
     # ------------------------------------------------------------------ checkpointing of the rank's shard
@@ -469,15 +489,20 @@ class Zero3AdamW(torch.optim.Optimizer):
             from . import functional as F
             F.bump_param_generation()
 
-    def full_state_dict(self, model):
+    def full_state_dict(self, model, device=None, keep=True):
         """model.state_dict() with the sharded decoder layers gathered (`stage3_gather_16bit_weights_on_model_save`): what
-        `save_pretrained` must be given under ZeRO-3, where the module tree itself holds no layer weights between steps."""
-        full = self.gather_full_parameters()
+        `save_pretrained` must be given under ZeRO-3, where the module tree itself holds no layer weights between steps.
+        COLLECTIVE: every rank must call it (one all-gather per sharded layer); ranks with keep=False get None.  device="cpu" moves
+        each layer to the host as it arrives, so the device peak is one layer, not the model."""
+        full = self.gather_full_parameters(device=device, keep=keep)
+        if not keep:
+            return None
         by_id = {id(p): t for p, t in full.items()}
         out = {}
         names = {id(p): n for n, p in model.named_parameters()}
         for name, t in model.state_dict(keep_vars=True).items():
-            out[name] = by_id.get(id(t), t).detach()
+            t = by_id.get(id(t), t).detach()
+            out[name] = t.to(device) if device is not None else t
         assert all(names[i] in out for i in by_id)
         return out
 

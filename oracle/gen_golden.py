@@ -687,6 +687,159 @@ def gen_names():
     print(f"    {len(out)} names")
 
 
+# ----------------------------------------------------------------------------- round 3: N3 layouts, image_embeds, pretraining_tp, mean-abs rows
+
+def _import_train():
+    import transformers
+    import transformers.pytorch_utils
+    import transformers.trainer as tr
+    if not hasattr(tr, "ALL_LAYERNORM_LAYERS"):
+        tr.ALL_LAYERNORM_LAYERS = transformers.pytorch_utils.ALL_LAYERNORM_LAYERS
+    import metamorph.train.train as T
+    import metamorph.train.metamorph_trainer as MT
+    return T, MT
+
+
+def gen_n3():
+    """Row N3 pinned to the reference: runs the reference's own `safe_save_model_for_hf_trainer` (train.py:186-222) and
+    `MetaMorphTrainer._save_checkpoint` / `_save` (metamorph_trainer.py:273-298) on a tiny model through a stub trainer object and
+    records WHAT THEY WRITE: relative file paths, the key list / dtypes / shapes inside every `.bin`, and a checksum of each tensor;
+    then `initialize_vision_modules(pretrain_mm_mlp_adapter=...)` (metamorph_arch.py:91-96) loading the adapter back into a fresh
+    model (which keys it consumes).  `deepspeed` is an import-only shim (maybe_zero_3 takes its plain-tensor branch)."""
+    import tempfile
+    from types import SimpleNamespace
+    T, MT = _import_train()
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=47)
+    out = {"seed": 47, "cases": []}
+
+    def listing(root):
+        files = {}
+        for d, _, fs in os.walk(root):
+            for f in fs:
+                rel = os.path.relpath(os.path.join(d, f), root)
+                entry = {"bytes_nonzero": os.path.getsize(os.path.join(d, f)) > 0}
+                if f.endswith(".bin"):
+                    blob = torch.load(os.path.join(d, f), map_location="cpu", weights_only=True)
+                    entry["keys"] = list(blob.keys())
+                    entry["dtypes"] = [str(v.dtype) for v in blob.values()]
+                    entry["shapes"] = [list(v.shape) for v in blob.values()]
+                    entry["sums"] = [float(v.double().sum()) for v in blob.values()]
+                files[rel] = entry
+        return dict(sorted(files.items()))
+
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        for use_se in (False, True):
+            model = build_reference(cfg, sd, dt)
+            # stage-1 freeze policy (train.py:1515-1519): only the projector (+ embeddings with start/end tokens) trains
+            for n, p in model.named_parameters():
+                p.requires_grad_("mm_projector" in n or (use_se and "embed_tokens" in n))
+            for folder in ("final_model", "checkpoint-7"):
+                with tempfile.TemporaryDirectory() as tmp:
+                    outdir = os.path.join(tmp, "run", folder)
+                    args = SimpleNamespace(tune_mm_mlp_adapter=True, use_im_start_end=use_se, local_rank=0, should_save=True, output_dir=os.path.join(tmp, "run"))
+                    trainer = SimpleNamespace(args=args, model=model, deepspeed=None)
+                    T.safe_save_model_for_hf_trainer(trainer, outdir)
+                    out["cases"].append({"fn": "safe_save_model_for_hf_trainer", "dtype": tag, "use_im_start_end": use_se,
+                                         "output_dir": f"run/{folder}", "files": listing(tmp)})
+            with tempfile.TemporaryDirectory() as tmp:
+                run = os.path.join(tmp, "run")
+                args = SimpleNamespace(tune_mm_mlp_adapter=True, use_im_start_end=use_se, local_rank=-1, should_save=True, output_dir=run)
+                stub = SimpleNamespace(args=args, model=model, state=SimpleNamespace(global_step=12), _get_output_dir=lambda trial=None: run)
+                MT.MetaMorphTrainer._save_checkpoint(stub, model, None)
+                MT.MetaMorphTrainer._save(stub, os.path.join(run, "ignored"))      # adapter runs: `_save` writes nothing (:294-298)
+                out["cases"].append({"fn": "MetaMorphTrainer._save_checkpoint", "dtype": tag, "use_im_start_end": use_se,
+                                     "global_step": 12, "files": listing(tmp)})
+        # full model (stage 2): the non-deepspeed branch hands a CPU state dict to trainer._save (train.py:213-222)
+        model = build_reference(cfg, sd, dt)
+        captured = {}
+        args = SimpleNamespace(tune_mm_mlp_adapter=False, should_save=True, local_rank=0)
+        trainer = SimpleNamespace(args=args, model=model, deepspeed=None,
+                                  _save=lambda output_dir, state_dict=None: captured.update(dir=output_dir, sd=state_dict))
+        T.safe_save_model_for_hf_trainer(trainer, "some/dir")
+        keys = list(captured["sd"].keys())
+        out["cases"].append({"fn": "safe_save_model_for_hf_trainer(full)", "dtype": tag, "n_keys": len(keys),
+                             "keys_without_tower": [k for k in keys if "vision_tower" not in k],
+                             "all_cpu": all(v.device.type == "cpu" for v in captured["sd"].values()),
+                             "dtypes": sorted({str(v.dtype) for v in captured["sd"].values()})})
+    # re-load: pretrain_mm_mlp_adapter consumed by initialize_vision_modules (metamorph_arch.py:91-96)
+    import tempfile as _tf
+    with _tf.TemporaryDirectory() as tmp:
+        donor = build_reference(cfg, init_state_dict(cfg, seed=48), torch.float32)
+        blob = T.get_mm_adapter_state_maybe_zero_3(donor.named_parameters(), ["mm_projector", "embed_tokens"])
+        path = os.path.join(tmp, "mm_projector.bin")
+        torch.save(blob, path)
+        fresh = build_reference(cfg, sd, torch.float32)
+        margs = SimpleNamespace(vision_tower="siglip/CLIP-ViT-SO400M-14-384", mm_vision_select_layer=-1, mm_vision_select_feature="patch",
+                                pretrain_mm_mlp_adapter=path, mm_projector_type="mlp2x_gelu", mm_patch_merge_type="flat",
+                                image_token_reduction="interpolation", num_image_tokens=4, freeze_vision=True, normalize_vision=True,
+                                apply_softmax=False, vision_coef=1.0)
+        before = {k: v.detach().clone() for k, v in fresh.state_dict().items()}
+        fresh.get_model().vision_tower.load_model = lambda *a, **k: None      # the hub download inside (:63) cannot run offline; the tower is built
+        try:
+            fresh.get_model().initialize_vision_modules(margs, fsdp=None)
+            err = None
+        except Exception as e:                                      # recorded, not hidden
+            err = f"{type(e).__name__}: {e}"
+        after = fresh.state_dict()
+        changed = sorted(k for k in before if k in after and not torch.equal(before[k], after[k]))
+        from_blob = sorted(k for k in changed if k in blob and torch.equal(after[k], blob[k].to(after[k].dtype)))
+        out["reload"] = {"adapter_keys": list(blob.keys()), "error": err, "changed_keys": changed, "changed_to_adapter_values": from_blob}
+    with open(os.path.join(OUT, "n3_checkpoint_layouts.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"  wrote n3_checkpoint_layouts.json ({len(out['cases'])} cases; reload changed {out['reload']['changed_keys']} error={out['reload']['error']})")
+
+
+def gen_r3():
+    """(i) `mse_loss_fn` (metamorph_llama.py:211-219) with equal and unequal row counts; (ii) forward(image_embeds=...) /
+    `encode_imagesembed` (metamorph_arch.py:166-173, metamorph_llama.py:603-660); (iii) `pretraining_tp = 2` lm_head slicing
+    (metamorph_llama.py:393-396): loss / logits / hidden / gradient summaries like the e2e fixtures."""
+    from metamorph.model.language_model.metamorph_llama import mse_loss_fn
+    import torch.nn.functional as F
+    rng = np.random.default_rng(77)
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s, dtype=np.float32))
+    out = {}
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        for name, (rt, rp) in {"eq": (6, 6), "fewer_pred": (6, 4), "fewer_tgt": (4, 6)}.items():
+            t, p = r(rt, 32).to(dt), r(rp, 32).to(dt)
+            out[f"l1_{name}_t_{tag}"], out[f"l1_{name}_p_{tag}"] = t, p
+            out[f"l1_{name}_loss_{tag}"] = mse_loss_fn(t, p).float()
+    save_npz("ops_r3.npz", **out)
+
+    shared = np.random.default_rng(4177)
+    for kind, extra_cfg, ctor in (("image_embeds", {}, {}), ("pretraining_tp2", {}, {})):
+        cfg = tiny_cfg(num_image_tokens=4, **extra_cfg)
+        sd = init_state_dict(cfg, seed=43)
+        ids, lab = e2e_batch("mixed")
+        ids_t, lab_t = torch.tensor(pad_rows(ids, 128001)), torch.tensor(pad_rows(lab, -100))
+        msk_t = ids_t.ne(128001)
+        n_img = sum(max(1, sum(1 for t in r_ if t == IM)) for r_ in ids)
+        images = torch.from_numpy(shared.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+        embeds = F.normalize(torch.from_numpy(shared.standard_normal((n_img, 4, cfg.v_hidden), dtype=np.float32)), dim=-1)
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            model = build_reference(cfg, sd, dt)
+            if kind == "pretraining_tp2":
+                model.config.pretraining_tp = 2
+            for n, p in model.named_parameters():
+                p.requires_grad_("vision_tower" not in n)
+            if kind == "image_embeds":
+                outp = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, image_embeds=embeds.to(dt))
+                tf = model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, None, image_embeds=embeds.to(dt))[7]
+            else:
+                outp = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images.to(dt))
+                tf = model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images.to(dt))[7]
+            rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, images=images, image_embeds=embeds, seed=np.int64(43),
+                       rows_per_image=np.int64(4), pretraining_tp=np.int64(getattr(model.config, "pretraining_tp", 1)),
+                       target_features=tf.float(), loss=outp.loss.detach().float(), loss_language=np.float64(model.loss_language),
+                       loss_image_ar=np.float64(model.loss_image_ar), logits_sub=outp.logits[:, :, ::997], hidden=outp.hidden_states)
+            outp.loss.backward()
+            for n, p in model.named_parameters():
+                if p.grad is not None and "vision_proj" not in n:
+                    rec["grad::" + n] = grad_summary(p.grad)
+            save_npz(f"r3_{kind}_{tag}.npz", **rec)
+            print(f"    {kind} {tag}: loss {float(outp.loss):.6f} lang {model.loss_language:.6f} img {model.loss_image_ar:.6f}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

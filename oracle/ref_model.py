@@ -57,6 +57,7 @@ class OracleConfig:
     tokenizer_padding_side: str = "right"
     image_start_id: int = IMAGE_START_ID
     image_token_reduction: str = "interpolation"       # | "mlpmixer" | "concat_interpolation" (siglip_encoder.py:151-204)
+    pretraining_tp: int = 1                            # > 1: lm_head applied in vocabulary slices (metamorph_llama.py:393-396)
 
     @property
     def head_dim(self):
@@ -91,30 +92,34 @@ def siglip_hidden(sd, cfg: OracleConfig, images: torch.Tensor, prefix="model.vis
     return x
 
 
+def reduce_features(sd, cfg: OracleConfig, f: torch.Tensor):
+    """hidden_states[-1] of the tower [N, P, hv] -> [N, T, hv]: token reduction, L2 normalisation, softmax (siglip_encoder.py:151-211)."""
+    if f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "mlpmixer":
+        # token_mixer = Linear(P, T) over the patch axis, then channel_mixer = Linear(hv, hv)  (siglip_encoder.py:164-168)
+        p = "model.vision_tower."
+        f = ops.linear(f.transpose(1, 2), sd[p + "token_mixer.0.weight"], sd[p + "token_mixer.0.bias"]).transpose(1, 2)
+        f = ops.linear(f, sd[p + "channel_mixer.0.weight"], sd[p + "channel_mixer.0.bias"])
+    elif f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "concat_interpolation":
+        # bilinear to 4 T tokens, then every 2 x 2 block of the grid concatenated along the channels (siglip_encoder.py:169-199)
+        N, _, C = f.shape
+        s = int(math.isqrt(cfg.num_image_tokens))
+        g = ops.bilinear_reduce(f, 4 * cfg.num_image_tokens).view(N, 2 * s, 2 * s, C)
+        g = g.view(N, s, 2, s, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, s * s, 4 * C)
+        f = g
+    else:
+        f = ops.bilinear_reduce(f, cfg.num_image_tokens)
+    if cfg.normalize_vision:
+        f = ops.l2_normalize(f)
+    if cfg.apply_softmax:
+        f = torch.softmax(f / 0.07, dim=-1)
+    return f
+
+
 def vision_features(sd, cfg: OracleConfig, images: torch.Tensor, train_vision: bool = False):
     """SiglipVisionTower.forward: tower -> cast to images.dtype -> reduce -> normalise, under
     torch.set_grad_enabled(not freeze_vision) (reference siglip_encoder.py:138-139)."""
     with torch.set_grad_enabled(train_vision):
-        f = siglip_hidden(sd, cfg, images).to(images.dtype)
-        if f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "mlpmixer":
-            # token_mixer = Linear(P, T) over the patch axis, then channel_mixer = Linear(hv, hv)  (siglip_encoder.py:164-168)
-            p = "model.vision_tower."
-            f = ops.linear(f.transpose(1, 2), sd[p + "token_mixer.0.weight"], sd[p + "token_mixer.0.bias"]).transpose(1, 2)
-            f = ops.linear(f, sd[p + "channel_mixer.0.weight"], sd[p + "channel_mixer.0.bias"])
-        elif f.shape[1] != cfg.num_image_tokens and cfg.image_token_reduction == "concat_interpolation":
-            # bilinear to 4 T tokens, then every 2 x 2 block of the grid concatenated along the channels (siglip_encoder.py:169-199)
-            N, _, C = f.shape
-            s = int(math.isqrt(cfg.num_image_tokens))
-            g = ops.bilinear_reduce(f, 4 * cfg.num_image_tokens).view(N, 2 * s, 2 * s, C)
-            g = g.view(N, s, 2, s, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, s * s, 4 * C)
-            f = g
-        else:
-            f = ops.bilinear_reduce(f, cfg.num_image_tokens)
-        if cfg.normalize_vision:
-            f = ops.l2_normalize(f)
-        if cfg.apply_softmax:
-            f = torch.softmax(f / 0.07, dim=-1)
-    return f
+        return reduce_features(sd, cfg, siglip_hidden(sd, cfg, images).to(images.dtype))
 
 
 # ------------------------------------------------------------------ projector / heads
@@ -153,26 +158,33 @@ def vision_head(sd, cfg: OracleConfig, x):
 
 # ------------------------------------------------------------------ LLaMA decoder (A6)
 
-def llama_decoder(sd, cfg: OracleConfig, x, key_valid, position_ids=None):
+def llama_layer(sd, cfg: OracleConfig, i: int, x, key_valid, cos, sin):
+    """One HF LlamaDecoderLayer (index i): RMSNorm -> q/k/v -> RoPE -> causal SDPA (+ key padding) -> o_proj -> + residual ->
+    RMSNorm -> SwiGLU -> + residual.  x [B, L, h]; cos / sin [B, L, d] from ref_ops.rope_tables."""
     B, L, h = x.shape
     Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    p = f"model.layers.{i}."
+    n = ops.rmsnorm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+    q = ops.linear(n, sd[p + "self_attn.q_proj.weight"]).view(B, L, Hq, d).transpose(1, 2)
+    k = ops.linear(n, sd[p + "self_attn.k_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
+    v = ops.linear(n, sd[p + "self_attn.v_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
+    q, k = ops.rope_apply(q, cos, sin), ops.rope_apply(k, cos, sin)
+    a = ops.attention(q, k, v, key_valid, causal=True)
+    a = a.transpose(1, 2).reshape(B, L, Hq * d)
+    x = x + ops.linear(a, sd[p + "self_attn.o_proj.weight"])
+    n = ops.rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+    g = ops.linear(n, sd[p + "mlp.gate_proj.weight"])
+    u = ops.linear(n, sd[p + "mlp.up_proj.weight"])
+    return x + ops.linear(ops.swiglu(g, u), sd[p + "mlp.down_proj.weight"])
+
+
+def llama_decoder(sd, cfg: OracleConfig, x, key_valid, position_ids=None):
+    B, L, h = x.shape
     if position_ids is None:
         position_ids = torch.arange(L)[None].expand(B, L)
-    cos, sin = ops.rope_tables(position_ids, d, cfg.rope_theta, x.dtype)
+    cos, sin = ops.rope_tables(position_ids, cfg.head_dim, cfg.rope_theta, x.dtype)
     for i in range(cfg.num_hidden_layers):
-        p = f"model.layers.{i}."
-        n = ops.rmsnorm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps)
-        q = ops.linear(n, sd[p + "self_attn.q_proj.weight"]).view(B, L, Hq, d).transpose(1, 2)
-        k = ops.linear(n, sd[p + "self_attn.k_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
-        v = ops.linear(n, sd[p + "self_attn.v_proj.weight"]).view(B, L, Hkv, d).transpose(1, 2)
-        q, k = ops.rope_apply(q, cos, sin), ops.rope_apply(k, cos, sin)
-        a = ops.attention(q, k, v, key_valid, causal=True)
-        a = a.transpose(1, 2).reshape(B, L, Hq * d)
-        x = x + ops.linear(a, sd[p + "self_attn.o_proj.weight"])
-        n = ops.rmsnorm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-        g = ops.linear(n, sd[p + "mlp.gate_proj.weight"])
-        u = ops.linear(n, sd[p + "mlp.up_proj.weight"])
-        x = x + ops.linear(ops.swiglu(g, u), sd[p + "mlp.down_proj.weight"])
+        x = llama_layer(sd, cfg, i, x, key_valid, cos, sin)
     return ops.rmsnorm(x, sd["model.norm.weight"], cfg.rms_norm_eps)
 
 
@@ -219,26 +231,28 @@ def splice(sd, cfg: OracleConfig, input_ids, labels, attention_mask, proj_feat, 
 
 # ------------------------------------------------------------------ full forward
 
-def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False,
-            ce_rows_only=False):
-    feat = vision_features(sd, cfg, images, train_vision)      # [N,T,hv]; no grad unless the tower trains (row N4)
-    proj = mm_projector(sd, cfg, feat)                         # [N,T,h]
-    target = feat.detach().clone()
-    x, lab, key_valid, img_pos, target, _pid = splice(sd, cfg, input_ids, labels, attention_mask, proj, target)
-    # position_ids stays None in the reference when the caller passes None (metamorph_arch.py:411-412)
-    hid = llama_decoder(sd, cfg, x, key_valid, None)
-    out = {"hidden_states": hid, "labels": lab, "attention_mask": key_valid,
-           "image_positions": img_pos, "target_features": target, "inputs_embeds": x}
+def heads(sd, cfg: OracleConfig, hid, lab, img_pos, target, return_logits=True, ce_rows_only=False):
+    """Everything after the decoder's final norm: lm_head + shifted CE (A7), vision_head + image-AR loss (A8), combine (A9).
+    hid [B, L, h]; lab [B, L] | None; img_pos [B, L]; target [Na, T, hv].  Returns the loss entries of `forward`'s dict."""
+    out = {}
+
+    def lm_head(x):
+        w = sd["lm_head.weight"]
+        if cfg.pretraining_tp > 1:                              # :393-396: split along the vocabulary, one matmul per slice, concatenate
+            slices = w.split(cfg.vocab_size // cfg.pretraining_tp, dim=0)
+            return torch.cat([ops.linear(x, slices[i]) for i in range(cfg.pretraining_tp)], dim=-1)
+        return ops.linear(x, w)
+
     if ce_rows_only and lab is not None and not return_logits:
         # full-size cases: logits only for the rows whose NEXT label is live -- the same mean NLL as below, without the
         # [B, L, V] fp32 tensor the reference materialises
         nxt = torch.full_like(lab, IGNORE_INDEX)
         nxt[:, :-1] = lab[:, 1:]
         keep = nxt != IGNORE_INDEX
-        lg = ops.linear(hid[keep], sd["lm_head.weight"]).float()
+        lg = lm_head(hid[keep]).float()
         ce = (torch.logsumexp(lg, -1) - lg.gather(1, nxt[keep][:, None])[:, 0]).sum() / keep.sum()
     else:
-        logits = ops.linear(hid, sd["lm_head.weight"]).float()
+        logits = lm_head(hid).float()
         if return_logits:
             out["logits"] = logits
         if lab is None:
@@ -270,6 +284,23 @@ def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, re
         loss = ce + cfg.vision_coef * l_img
     out["loss"] = loss
     out["pred"] = pred
+    return out
+
+
+def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False,
+            ce_rows_only=False, image_embeds=None):
+    if image_embeds is not None:                               # `encode_imagesembed` (metamorph_arch.py:166-173): features given, no tower
+        feat = image_embeds
+    else:
+        feat = vision_features(sd, cfg, images, train_vision)  # [N,T,hv]; no grad unless the tower trains (row N4)
+    proj = mm_projector(sd, cfg, feat)                         # [N,T,h]
+    target = feat.detach().clone()
+    x, lab, key_valid, img_pos, target, _pid = splice(sd, cfg, input_ids, labels, attention_mask, proj, target)
+    # position_ids stays None in the reference when the caller passes None (metamorph_arch.py:411-412)
+    hid = llama_decoder(sd, cfg, x, key_valid, None)
+    out = {"hidden_states": hid, "labels": lab, "attention_mask": key_valid,
+           "image_positions": img_pos, "target_features": target, "inputs_embeds": x}
+    out.update(heads(sd, cfg, hid, lab, img_pos, target, return_logits, ce_rows_only))
     return out
 
 

@@ -324,6 +324,94 @@ def test_adapter_checkpoint_layout(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(m.get_model().mm_projector.state_dict().values(), m2.get_model().mm_projector.state_dict().values()))
 
 
+def _listing(root):
+    files = {}
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            rel = os.path.relpath(os.path.join(d, f), root)
+            entry = {"bytes_nonzero": os.path.getsize(os.path.join(d, f)) > 0}
+            if f.endswith(".bin"):
+                blob = torch.load(os.path.join(d, f), map_location="cpu", weights_only=True)
+                entry["keys"] = list(blob.keys())
+                entry["dtypes"] = [str(v.dtype) for v in blob.values()]
+                entry["shapes"] = [list(v.shape) for v in blob.values()]
+                entry["sums"] = [float(v.double().sum()) for v in blob.values()]
+            files[rel] = entry
+    return dict(sorted(files.items()))
+
+
+def _n3_model(seed, dtype):
+    from metamorph_amd.factory import build_model
+    from oracle.ref_model import OracleConfig, init_state_dict
+    cfg = OracleConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                       vocab_size=128258, v_layers=2, v_intermediate=144, v_image=56, num_image_tokens=4, tokenizer_model_max_length=64)
+    llm = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+               vocab_size=128258, rms_norm_eps=1e-5, rope_theta=500000.0)
+    geo = dict(hidden_size=1152, intermediate_size=144, num_hidden_layers=2, num_attention_heads=16, image_size=56, patch_size=14)
+    return build_model(llm, geo, num_image_tokens=4, max_length=64, state_dict=init_state_dict(cfg, seed=seed), dtype=dtype)
+
+
+def test_checkpoint_layouts_match_reference_recorded(tmp_path):
+    """Row N3 PINNED: tests/golden/n3_checkpoint_layouts.json records what the reference's own `safe_save_model_for_hf_trainer`
+    (train.py:186-222) and `MetaMorphTrainer._save_checkpoint` / `_save` (metamorph_trainer.py:273-298) wrote for a tiny model
+    (oracle/gen_golden.py n3): relative paths, key ORDER, dtypes, shapes and a checksum per tensor of every `.bin`.  The same seeded
+    weights in this build's model through `checkpoint.py` / `MetaMorphTrainer` must produce the same listing."""
+    from types import SimpleNamespace
+    from metamorph_amd.checkpoint import safe_save_model, save_trainer_adapter_checkpoint
+    from metamorph_amd.trainer import MetaMorphTrainer
+    g = json.load(open(os.path.join(GOLDEN, "n3_checkpoint_layouts.json")))
+    models = {"bf16": _n3_model(g["seed"], torch.bfloat16), "f32": _n3_model(g["seed"], torch.float32)}
+    n = 0
+    for i, c in enumerate(g["cases"]):
+        m = models[c["dtype"]]
+        root = tmp_path / f"case{i}"
+        if c["fn"] == "safe_save_model_for_hf_trainer":
+            safe_save_model(m, str(root / c["output_dir"]), tune_mm_mlp_adapter=True, use_im_start_end=c["use_im_start_end"])
+        elif c["fn"] == "MetaMorphTrainer._save_checkpoint":
+            run = str(root / "run")
+            args = SimpleNamespace(tune_mm_mlp_adapter=True, use_im_start_end=c["use_im_start_end"], local_rank=-1, should_save=True, output_dir=run)
+            stub = SimpleNamespace(args=args, model=m, state=SimpleNamespace(global_step=c["global_step"]), _get_output_dir=lambda trial=None, run=run: run)
+            MetaMorphTrainer._save_checkpoint(stub, m, None)
+            MetaMorphTrainer._save(stub, os.path.join(run, "ignored"))           # adapter runs: `_save` writes nothing
+        else:                                                                    # full model: a CPU state dict under the reference's keys
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            keys = list(sd.keys())
+            assert [k for k in keys if "vision_tower" not in k] == c["keys_without_tower"]
+            assert sorted({str(v.dtype) for v in sd.values()}) == c["dtypes"]
+            n += 1
+            continue
+        got = _listing(root)
+        want = c["files"]
+        assert list(got) == list(want), (c, list(got))
+        for rel in want:
+            for field in ("keys", "dtypes", "shapes"):
+                assert got[rel].get(field) == want[rel].get(field), (c["fn"], rel, field)
+            if "sums" in want[rel]:
+                assert got[rel]["sums"] == pytest.approx(want[rel]["sums"], rel=1e-6, abs=1e-6), (c["fn"], rel)
+        n += 1
+    assert n == len(g["cases"]) == 14
+    # re-load (metamorph_arch.py:91-96): an adapter file written with embed_tokens in it changes the projector only
+    from metamorph_amd.checkpoint import get_mm_adapter_state
+    donor = _n3_model(48, torch.float32)
+    blob = get_mm_adapter_state(donor.named_parameters(), ["mm_projector", "embed_tokens"])
+    assert list(blob) == g["reload"]["adapter_keys"]
+    path = str(tmp_path / "mm_projector.bin")
+    torch.save(blob, path)
+    fresh = models["f32"]
+    before = {k: v.detach().clone() for k, v in fresh.state_dict().items()}
+    margs = SimpleNamespace(vision_tower="siglip/CLIP-ViT-SO400M-14-384", mm_vision_select_layer=-1, mm_vision_select_feature="patch",
+                            pretrain_mm_mlp_adapter=path, mm_projector_type="mlp2x_gelu", mm_patch_merge_type="flat",
+                            image_token_reduction="interpolation", num_image_tokens=4, freeze_vision=True, normalize_vision=True,
+                            apply_softmax=False, vision_coef=1.0)
+    fresh.get_model().initialize_vision_modules(margs, fsdp=None)
+    after = fresh.state_dict()
+    changed = sorted(k for k in before if k in after and not torch.equal(before[k], after[k]))
+    from_blob = sorted(k for k in changed if k in blob and torch.equal(after[k], blob[k].to(after[k].dtype)))
+    assert from_blob == g["reload"]["changed_to_adapter_values"]
+    # the reference also re-creates the dead `vision_proj` Linear with fresh random weights (:86); nothing else may change
+    assert set(changed) - set(g["reload"]["changed_keys"]) == set() and set(from_blob) <= set(changed)
+
+
 # ------------------------------------------------------------------ N2: image pre-processing (caller side, CPU)
 def test_process_images_matches_reference_golden():
     """mm_utils.process_images / expand2square + the hub-free SigLIP image processor against outputs recorded from the

@@ -405,6 +405,7 @@ ATT_CASES = [  # B, L, Hq, Hkv, d, causal, seqlens
     (1, 300, 6, 3, 128, True, None),                    # block order: groups of 2 heads walked fastest; dK/dV: odd KV-head count
     (1, 260, 5, 5, 128, True, None),                    # no GQA, odd head count: one head at a time
     (2, 384, 12, 4, 128, True, [300, 384]),             # groups of 3
+    (2, 320, 16, 2, 128, True, [320, 191]),             # GQA 8:1 at d = 128 (LLaMA-3-70B: 64 query / 8 KV heads), ragged
 ]
 
 
@@ -470,12 +471,13 @@ def test_attn_bwd(ops, case):
     close(dqkv[:, (Hq + Hkv) * d:].view(B, L, Hkv, d), vf.grad.transpose(1, 2), what=f"dv {case}", **tol)
 
 
-@pytest.mark.parametrize("L", [2048, 4096])
-def test_attn3_full_length_against_oracle_slice(ops, L):
+@pytest.mark.parametrize("L,Hq", [(2048, 32), (4096, 32), (4096, 64)])
+def test_attn3_full_length_against_oracle_slice(ops, L, Hq):
     """The d = 128 LDS-DMA kernels at BASELINE sequence lengths (configs[1] L = 2048, configs[2] L = 4096), LLaMA-3-8B head
-    geometry (32 query / 8 KV heads), per-sample lengths: forward output, lse and all three gradients of ONE (sample, KV group)
-    slice against the fp32 oracle (4 query heads x L x L scores on the CPU), for a full-length and a ragged sample."""
-    B, Hq, Hkv, d = 2, 32, 8, 128
+    geometry (32 query / 8 KV heads) and configs[4]'s LLaMA-3-70B geometry (64 query / 8 KV heads: eight query heads per KV group,
+    L = 4096), per-sample lengths: forward output, lse and all three gradients of ONE (sample, KV group) slice against the fp32
+    oracle (4 or 8 query heads x L x L scores on the CPU), for a full-length and a ragged sample."""
+    B, Hkv, d = 2, 8, 128
     seqlens = [L, L - 333]
     ld = (Hq + 2 * Hkv) * d
     qkv = rnd(B * L, ld, seed=11 + L, scale=0.7)

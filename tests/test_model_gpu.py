@@ -3,8 +3,9 @@ reference itself and (b) the CPU oracle on the same seeded weights.  Needs an MI
 
 Tolerance (north_star: "within 1e-3 bf16 tolerance"): the reference's own bf16 run differs from its fp32 run by
 a data-dependent amount; we require the HIP bf16 result to be as close to the fp32 truth as the reference's bf16
-result is, up to a factor, and the loss to agree with the reference-bf16 loss to 1e-3 relative (x3 for the tiny
-2-layer model whose loss is ~ln(V) with ~100 target tokens).  Integer outputs are compared bit-exactly.
+result is, up to a factor of 1.5, and every loss to agree with the reference-bf16 loss AND the fp32 truth to 1e-3 relative.
+Floors next to the factors are 1.5 x the value measured on MI355X in round 3 (profiles/r3_parity_measured.log), so a 2 x
+regression of any of them fails.  Integer outputs are compared bit-exactly.
 """
 import glob
 import os
@@ -122,15 +123,15 @@ def test_e2e_forward_backward(path):
     if np.isnan(ref_loss):
         assert np.isnan(got)
     else:
-        assert abs(got - ref_loss) <= 3e-3 * max(1.0, abs(ref_loss)), (got, ref_loss)
-        assert abs(got - truth) <= max(3e-3 * abs(truth), 3 * abs(ref_loss - truth)), (got, truth, ref_loss)
-    assert abs(model.loss_language - float(g["loss_language"])) <= 3e-3 * max(1.0, abs(ref_loss if not np.isnan(ref_loss) else 12.0))
+        assert abs(got - ref_loss) <= 1e-3 * abs(ref_loss), (got, ref_loss)
+        assert abs(got - truth) <= 1e-3 * abs(truth), (got, truth, ref_loss)
+    assert abs(model.loss_language - float(g["loss_language"])) <= 1e-3 * abs(float(g["loss_language"]))
     if np.isnan(float(g["loss_image_ar"])):
         assert np.isnan(model.loss_image_ar)          # no answer-side image rows -> NaN
     else:
         # image-AR head (cosine / mean-abs / soft-CE): as close to the fp32 truth as the reference's own bf16 run (x2), floor 1e-3
         li, li_ref, li_true = model.loss_image_ar, float(g["loss_image_ar"]), float(g32["loss_image_ar"])
-        assert abs(li - li_true) <= max(2.0 * abs(li_ref - li_true), 1e-3 * max(1.0, abs(li_true))), (li, li_ref, li_true)
+        assert abs(li - li_true) <= max(1.5 * abs(li_ref - li_true), 1e-3 * max(1.0, abs(li_true))), (li, li_ref, li_true)
     # hidden states: as close to fp32 truth as the reference's own bf16 run (x2) -- valid rows only
     valid = T(np.asarray(out.hidden_states.shape[:2]))  # noqa
     hs = out.hidden_states.float().cpu()
@@ -144,7 +145,7 @@ def test_e2e_forward_backward(path):
     e_hip = rel(hs[mask], T(g32["hidden"])[mask])
     e_ref = rel(T(g["hidden"])[mask], T(g32["hidden"])[mask])
     print(f"   hidden rel err vs fp32: hip={e_hip:.4e} reference-bf16={e_ref:.4e}")
-    assert e_hip <= max(2.0 * e_ref, 2e-2)
+    assert e_hip <= max(1.5 * e_ref, 1.3e-2)                       # measured 8.0e-3 .. 8.4e-3 (reference-bf16: 8.4e-3 .. 8.9e-3)
     if np.isnan(ref_loss):
         return
     out.loss.backward()
@@ -161,13 +162,110 @@ def test_e2e_forward_backward(path):
         e_r = rel(T(g[k])[1:], T(g32[k])[1:]) if k in g.files else 0.0
         nerr = abs(float(got_g[0]) - float(g32[k][0])) / max(float(g32[k][0]), 1e-12)
         worst = max(worst, e_h)
-        if e_h > 3e-2:
+        if e_h > 2e-2:
             print(f"      {name}: rel err vs fp32 hip={e_h:.3e} reference-bf16={e_r:.3e} norm err={nerr:.3e}")
-        assert e_h <= max(3.0 * e_r, 5e-2), (name, e_h, e_r)
-        assert nerr <= max(5e-2, 3 * abs(float(g[k][0]) - float(g32[k][0])) / max(float(g32[k][0]), 1e-12)), (name, nerr)
+        # tensors whose gradient is near-noise in the reference's own bf16 run (embed_tokens rows, the l1 / soft-CE heads) are held to
+        # 3 x that run's distance from fp32; everything else to 3.3e-2 = 1.5 x the worst measured (2.2e-2)
+        assert e_h <= max(3.0 * e_r, 3.3e-2), (name, e_h, e_r)
+        assert nerr <= max(3e-2, 3 * abs(float(g[k][0]) - float(g32[k][0])) / max(float(g32[k][0]), 1e-12)), (name, nerr)
         n += 1
     print(f"   {n} gradient tensors checked, worst rel err vs fp32 truth {worst:.3e}")
     assert n >= 20
+
+
+@pytest.mark.parametrize("kind", ["image_embeds", "pretraining_tp2"])
+def test_image_embeds_and_pretraining_tp_match_reference_recorded(kind):
+    """`forward(image_embeds=...)` -> `encode_imagesembed` (reference metamorph_arch.py:166-173, metamorph_llama.py:603-660: tower
+    skipped, the given [N, T, 1152] features go through mm_projector and are the regression targets) and `pretraining_tp = 2`
+    (metamorph_llama.py:393-396) against runs of the reference itself (tests/golden/r3_*.npz, oracle/gen_golden.py r3)."""
+    g, g32 = np.load(os.path.join(GOLDEN, f"r3_{kind}_bf16.npz")), np.load(os.path.join(GOLDEN, f"r3_{kind}_f32.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+    model.config.pretraining_tp = int(g["pretraining_tp"])
+    model.train()
+    ids, lab, msk = T(g["input_ids"]).to(DEV), T(g["labels"]).to(DEV), T(g["attention_mask"]).to(DEV)
+    kw = dict(image_embeds=T(g["image_embeds"]).to(DEV).bfloat16()) if kind == "image_embeds" else dict(images=T(g["images"]).to(DEV).bfloat16())
+    out = model(input_ids=ids, attention_mask=msk, labels=lab, **kw)
+    got, ref_loss, truth = float(out.loss.detach()), float(g["loss"]), float(g32["loss"])
+    print(f"\n   [{kind}] loss hip={got:.6f} ref_bf16={ref_loss:.6f} ref_fp32={truth:.6f} img={model.loss_image_ar:.6f}/{float(g32['loss_image_ar']):.6f}")
+    assert abs(got - ref_loss) <= 1e-3 * abs(ref_loss) and abs(got - truth) <= 1e-3 * abs(truth)
+    assert abs(model.loss_language - float(g32["loss_language"])) <= 1e-3 * abs(truth)
+    assert abs(model.loss_image_ar - float(g32["loss_image_ar"])) <= 1e-3
+    plan = model.prepare_inputs_labels_for_multimodal(ids, None, msk, None, lab, kw.get("images"), image_embeds=kw.get("image_embeds"))
+    mask = plan[2].bool().cpu()
+    if kind == "image_embeds":                                  # the targets ARE the given features (answer images only), bit for bit
+        assert torch.equal(plan[7].float().cpu(), T(g["target_features"]))
+        proj, tgt = model.encode_imagesembed(kw["image_embeds"])
+        assert torch.equal(tgt, kw["image_embeds"]) and proj.shape == (tgt.shape[0], 4, cfg.hidden_size)
+    e_hip, e_ref = rel(out.hidden_states.float().cpu()[mask], T(g32["hidden"])[mask]), rel(T(g["hidden"])[mask], T(g32["hidden"])[mask])
+    assert e_hip <= max(1.5 * e_ref, 1.3e-2), (e_hip, e_ref)
+    out.loss.backward()
+    params, n = dict(model.named_parameters()), 0
+    for k in g32.files:
+        if k.startswith("grad::"):
+            gs = grad_summary(params[k[6:]].grad)
+            e_h, e_r = rel(gs[1:], T(g32[k])[1:]), rel(T(g[k])[1:], T(g32[k])[1:])
+            assert e_h <= max(3.0 * e_r, 3.3e-2), (k, e_h, e_r)
+            n += 1
+    assert n >= 25
+    model.eval()
+    with torch.no_grad():                                       # the full fp32 logits (sliced or not: the same numbers)
+        lo = model(input_ids=ids, attention_mask=msk, labels=None, **kw).logits[:, :, ::997].cpu()
+    e_hip, e_ref = rel(lo[mask], T(g32["logits_sub"])[mask]), rel(T(g["logits_sub"])[mask], T(g32["logits_sub"])[mask])
+    assert e_hip <= max(1.5 * e_ref, 1.4e-2), (e_hip, e_ref)
+    if kind == "pretraining_tp2":
+        model.config.pretraining_tp = 4                         # 128258 % 4 != 0: the reference would silently drop the last two rows
+        with pytest.raises(NotImplementedError):
+            model(input_ids=ids, attention_mask=msk, labels=None, **kw)
+
+
+def test_generate_with_image_embeds_equals_generate_with_images():
+    """`generate(image_embeds=tower(images))` (reference metamorph_llama.py:672-700) walks the same loop as `generate(images=...)`."""
+    from oracle.ref_model import decode_fixture_state_dict
+    g = np.load(os.path.join(GOLDEN, "n1_decode_image_prompt.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, decode_fixture_state_dict(g, cfg, torch.bfloat16)).eval()
+    images = T(g["images"]).to(DEV).bfloat16()
+    with torch.no_grad():
+        feats = model.get_model().get_vision_tower()(images)
+    a, ea = model.generate(inputs=T(g["input_ids"]).to(DEV), images=images, output_image=True, max_new_tokens=int(g["max_new_tokens"]))
+    b, eb = model.generate(inputs=T(g["input_ids"]).to(DEV), image_embeds=feats, output_image=True, max_new_tokens=int(g["max_new_tokens"]))
+    assert a[0].tolist() == b[0].tolist() == g["tokens"].tolist() and torch.equal(ea, eb)
+
+
+def test_mean_abs_head_with_unequal_row_counts_follows_reference():
+    """`mse_loss_fn` (reference metamorph_llama.py:211-219) zips target and prediction rows and divides by len(target): with R != Rt
+    it uses the first min(R, Rt) pairs (oracle pinned to the reference by tests/golden/ops_r3.npz).  Driven through llm_forward with a
+    target tensor shorter / longer than the prediction rows; value and gradient against the oracle on the device model's own rows."""
+    from oracle import ref_ops as R
+    gg = np.load(os.path.join(GOLDEN, "e2e_generation_only_T4_ar1_l1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4, normalize_vision=False)
+    sd16 = init_state_dict(cfg, seed=int(gg["seed"]), dtype=torch.bfloat16)
+    model = hip_model(cfg, sd16)
+    model.train()
+    ids, lab, msk = T(gg["input_ids"]).to(DEV), T(gg["labels"]).to(DEV), T(gg["attention_mask"]).to(DEV)
+    images = T(gg["images"]).to(DEV).bfloat16()
+    for rows in (6, 8, 11):                                     # R = 8 prediction rows; fewer, equal, more target rows
+        (_, _, amask, _, emb, nlab, ipos, tgt) = model.prepare_inputs_labels_for_multimodal(ids, None, msk, None, lab, images)
+        flat = tgt.reshape(-1, tgt.shape[-1])
+        assert flat.shape[0] == 8
+        t_in = torch.cat([flat, flat[:3]], 0)[:rows].contiguous().view(1, rows, -1)
+        model.zero_grad(set_to_none=True)
+        out = model.llm_forward(inputs_embeds=emb, attention_mask=amask, labels=nlab, image_positions=ipos, image_features=t_in)
+        out.loss.backward()
+        hid = out.hidden_states.detach()
+        sel = ipos[:, 1:].bool()
+        pred_in = hid[:, :-1][sel].float().cpu().requires_grad_(True)
+        w = {k: v.float() for k, v in sd16.items() if k.startswith("vision_head.")}
+        from oracle.ref_model import vision_head
+        want = R.mean_abs_loss(t_in.view(rows, -1).float().cpu(), vision_head(w, cfg, pred_in))
+        assert abs(model.loss_image_ar - float(want)) <= 2e-3 * abs(float(want)), (rows, model.loss_image_ar, float(want))
+        for k, v in w.items():
+            v.requires_grad_(True)
+        want2 = R.mean_abs_loss(t_in.view(rows, -1).float().cpu(), vision_head(w, cfg, pred_in.detach()))
+        want2.backward()
+        e = rel(dict(model.named_parameters())["vision_head.2.bias"].grad, w["vision_head.2.bias"].grad)
+        assert e <= 6e-2, (rows, e)                               # sign gradients scaled by min(R, Rt) / (Rt C): scale errors would be >= 25 %
 
 
 def test_logits_eval_mode():
@@ -187,7 +285,7 @@ def test_logits_eval_mode():
     sub = out.logits[:, :, ::997].cpu()
     e_hip, e_ref = rel(sub[mask], T(g32["logits_sub"])[mask]), rel(T(g["logits_sub"])[mask], T(g32["logits_sub"])[mask])
     print(f"\n   logits rel err vs fp32: hip={e_hip:.4e} reference-bf16={e_ref:.4e}")
-    assert e_hip <= max(2.0 * e_ref, 2e-2)
+    assert e_hip <= max(1.5 * e_ref, 1.4e-2)                       # measured 9.0e-3 (reference-bf16 9.4e-3)
 
 
 def test_explicit_position_ids_are_checked_not_ignored():
@@ -371,12 +469,15 @@ def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
     assert emb.shape == tuple(g["pred_z"].shape)
     e_hip, e_ref = rel(emb, T(g["pred_z"])), rel(T(g["pred_z_bf16"]), T(g["pred_z"]))
     print(f"\n   [{name} use_cache={use_cache}] pred_z rel err vs reference fp32: hip={e_hip:.3e} reference-bf16={e_ref:.3e}")
-    assert e_hip <= max(2.0 * e_ref, 1e-2)
+    assert e_hip <= max(1.5 * e_ref, 1.2e-2)                       # measured 7.6e-3 .. 8.3e-3 (reference-bf16 7.9e-3 .. 8.2e-3)
     for r in range(emb.shape[0]):                                   # every image-mode step, not only the average
         assert rel(emb[r], T(g["pred_z"])[r]) <= max(3.0 * e_ref, 2e-2), r
 
 
 # ------------------------------------------------------------------ BASELINE configs[0] geometry class (TinyLlama: d = 64, GQA 8:1)
+D64_HIDDEN_TOL, D64_GRAD_TOL = 1.3e-2, 4e-2
+
+
 def test_e2e_head_dim_64_gqa8_against_oracle():
     """TinyLlama-style attention geometry (head size 64, eight query heads per KV head) goes through the generic attention
     kernels (attn2) instead of the d = 128 LDS-DMA ones; loss and gradients against the CPU oracle on the same weights (fp32)."""
@@ -394,23 +495,30 @@ def test_e2e_head_dim_64_gqa8_against_oracle():
     ref = oracle_forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"], return_logits=False)
     got, want = float(out.loss.detach()), float(ref["loss"].detach())
     print(f"\n   d=64 GQA8 loss hip={got:.5f} oracle={want:.5f}")
-    assert abs(got - want) <= 3e-3 * abs(want)
+    assert abs(got - want) <= 1e-3 * abs(want)
     mask = ref["attention_mask"]
-    assert rel(out.hidden_states.float().cpu()[mask], ref["hidden_states"].detach()[mask]) <= 3e-2
+    e_hid = rel(out.hidden_states.float().cpu()[mask], ref["hidden_states"].detach()[mask])
+    print(f"   hidden rel err {e_hid:.3e}")
+    assert e_hid <= D64_HIDDEN_TOL
     out.loss.backward()
     ref["loss"].backward()
     params = dict(model.named_parameters())
-    n = 0
+    n, worst = 0, (0.0, "")
     for k, v in sd.items():
         if v.grad is None or k not in params:
             continue
         e = rel(params[k].grad, v.grad)
-        assert e <= 6e-2, (k, e)
+        worst = max(worst, (e, k))
+        assert e <= D64_GRAD_TOL, (k, e)
         n += 1
+    print(f"   {n} gradient tensors, worst rel err {worst[0]:.3e} ({worst[1]})")
     assert n >= 20
 
 
 # ------------------------------------------------------------------ row N4: trainable vision tower (freeze_vision=False)
+TOWER_GRAD_TOL = 8e-2
+
+
 def test_trainable_vision_tower_gradients_against_oracle():
     """reference siglip_encoder.py:138-139 (`torch.set_grad_enabled(not self.freeze_vision)`): with the tower unfrozen the loss
     back-propagates through mm_projector, the 729 -> T reduction + L2 norm and every SigLIP encoder layer; gradients of all tower
@@ -433,11 +541,11 @@ def test_trainable_vision_tower_gradients_against_oracle():
     ref = oracle_forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["labels"], batch["images"], return_logits=False,
                          train_vision=True)
     got, want = float(out.loss.detach()), float(ref["loss"].detach())
-    assert abs(got - want) <= 3e-3 * abs(want), (got, want)
+    assert abs(got - want) <= 1e-3 * abs(want), (got, want)
     out.loss.backward()
     ref["loss"].backward()
     params = dict(model.named_parameters())
-    n_tower = 0
+    n_tower, worst = 0, (0.0, "")
     for k, v in sd.items():
         if "vision_tower" not in k or v.grad is None:
             continue
@@ -449,9 +557,10 @@ def test_trainable_vision_tower_gradients_against_oracle():
             assert float(v.grad.norm()) <= 1e-4 * max(qb, 1e-12) and float(params[k].grad.float().norm()) <= 5e-2 * qb, k
         else:
             e = rel(params[k].grad, v.grad)
-            assert e <= 8e-2, (k, e)
+            worst = max(worst, (e, k))
+            assert e <= TOWER_GRAD_TOL, (k, e)
         n_tower += 1
-    print(f"\\n   trainable tower: loss hip={got:.5f} oracle={want:.5f}; {n_tower} tower gradient tensors checked")
+    print(f"\n   trainable tower: loss hip={got:.5f} oracle={want:.5f}; {n_tower} tower gradient tensors checked, worst rel err {worst[0]:.3e} ({worst[1]})")
     assert n_tower == 3 + 16 * cfg.v_layers
     # the frozen default still refuses nothing and produces no tower gradients
     model2 = hip_model(cfg, init_state_dict(cfg, seed=seed, dtype=torch.bfloat16))
@@ -480,7 +589,7 @@ def test_tower_output_matches_reference_recorded(Timg):
         e_hip, e_ref = rel(got, T(g32[key])), rel(T(g16[key]), T(g32[key]))
         print(f"\n   tower T={Timg} {name}: rel err vs reference fp32 hip={e_hip:.3e} reference-bf16={e_ref:.3e}")
         assert got.shape == tuple(g32[key].shape)
-        assert e_hip <= max(2.0 * e_ref, 5e-3), (name, e_hip, e_ref)
+        assert e_hip <= max(1.5 * e_ref, 4e-3), (name, e_hip, e_ref)   # measured: at or below the reference's own bf16 distance
     assert torch.equal(tgt, feat)                                  # the regression target is the detached tower output (A4)
     n = feat.float().norm(dim=-1)
     assert float((n - 1).abs().max()) < 1e-2                       # normalize_vision
@@ -507,9 +616,9 @@ def _fullwidth_check(cfg, ids, labels, mask, images, seed, *, grad_tol, hidden_t
     got, want = float(out.loss.detach()), float(ref["loss"].detach())
     print(f"\n   {what}: loss hip={got:.5f} oracle-fp32={want:.5f} lang={model.loss_language:.5f}/{ref['loss_language']:.5f} "
           f"img={model.loss_image_ar:.5f}/{ref['loss_image_ar']:.5f}")
-    assert abs(got - want) <= 2e-3 * abs(want), (got, want)
-    assert abs(model.loss_language - ref["loss_language"]) <= 2e-3 * abs(want)
-    assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 2e-3
+    assert abs(got - want) <= 1e-3 * abs(want), (got, want)
+    assert abs(model.loss_language - ref["loss_language"]) <= 1e-3 * abs(want)
+    assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 1e-3
     valid = ref["attention_mask"]
     e = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"].detach()[valid])
     print(f"   hidden rel err {e:.3e}")
@@ -557,7 +666,8 @@ def test_configs0_tinyllama_real_widths_against_oracle():
     labels[1, 22] = -200
     mask = torch.ones_like(ids, dtype=torch.bool)
     images = torch.randn(2, 3, 384, 384, generator=g)
-    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=31, grad_tol=6e-2, hidden_tol=3e-2, what="configs[0] TinyLlama widths")
+    # measured (round 3): hidden 7.5e-3, worst gradient 1.7e-2 (layers.1.q_proj) -> 1.5 x
+    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=31, grad_tol=2.6e-2, hidden_tol=1.2e-2, what="configs[0] TinyLlama widths")
     assert n >= 20
 
 
@@ -594,12 +704,45 @@ def test_configs2_shape_8_frames_seq4096_against_oracle():
     mask = ids.ne(128001)
     n_img = 8 + 3
     images = torch.randn(n_img, 3, 384, 384, generator=g)
-    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=77, grad_tol=6e-2, hidden_tol=3e-2, what="configs[2] shape (8 frames, L=4096)",
+    # measured (round 3): hidden 8.5e-3, worst gradient 2.1e-2 (layers.1.q_proj) -> 1.5 x
+    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=77, grad_tol=3.2e-2, hidden_tol=1.3e-2, what="configs[2] shape (8 frames, L=4096)",
                          check_embed_grad=False)
     assert n >= 20
 
 
+# ------------------------------------------------------------------ BASELINE configs[3]: generation-mode finetune (all samples regress an image)
+def test_configs3_all_generation_8b_widths_against_oracle():
+    """BASELINE configs[3] (text -> visual-embedding regression, MetaCLIP-style pairs): every sample is
+    [BOS, BOS, prompt text, assistant text, <image_start>, <image>, <image_end>, <|eot_id|>] with the labels live from the assistant
+    part on, so R = B * 256 regression rows feed vision_head + the cosine loss and NO prompt-side image exists; LLaMA-3-8B widths,
+    two decoder and two tower layers, three samples of different lengths (ragged right padding)."""
+    cfg = OracleConfig(num_hidden_layers=2, v_layers=2, num_image_tokens=256, tokenizer_model_max_length=4096)
+    g = torch.Generator().manual_seed(3303)
+    B, n_ids = 3, 72
+    ids = torch.full((B, n_ids), 128001, dtype=torch.long)
+    labels = torch.full((B, n_ids), -100, dtype=torch.long)
+    for b, (n_prompt, n_answer) in enumerate(((32, 16), (20, 8), (40, 20))):
+        n = 2 + n_prompt + n_answer + 4
+        row = torch.randint(0, 127999, (n,), generator=g)
+        row[0] = row[1] = 128000
+        row[-4], row[-3], row[-2], row[-1] = 128256, -200, 128257, 128009
+        ids[b, :n] = row
+        labels[b, 2 + n_prompt:n] = row[2 + n_prompt:]
+        labels[b, n - 3] = -200
+    mask = ids.ne(128001)
+    images = torch.randn(B, 3, 384, 384, generator=g)
+    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=53, grad_tol=C3_GRAD_TOL, hidden_tol=1.3e-2,
+                         what="configs[3] all-generation (3 x 256 regression rows)")
+    assert n >= 20
+
+
+C3_GRAD_TOL = 4e-2
+
+
 # ------------------------------------------------------------------ BASELINE configs[4] shape: LLaMA-3-70B widths under ZeRO-3 + recompute
+C4_GRAD_TOL = 6e-2
+
+
 def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
     """BASELINE configs[4] (LLaMA-3-70B + SigLIP-SO400M, seq 4096, mixed understanding + generation batch, ZeRO-3): the 70B LAYER
     geometry (h 8192, 64 query / 8 KV heads of 128 -- eight query heads per KV group --, I 28672, V 128258) with two decoder and two tower
@@ -655,15 +798,15 @@ def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
         ref = oracle_forward(sd, cfg, ids, mask, labels, images.bfloat16().float(), return_logits=False, ce_rows_only=True)
         got, want = float(out.loss.detach()), float(ref["loss"].detach())
         print(f"\n   configs[4] shape: loss hip={got:.5f} oracle-fp32={want:.5f} img={model.loss_image_ar:.5f}/{ref['loss_image_ar']:.5f}")
-        assert abs(got - want) <= 2e-3 * abs(want)
-        assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 2e-3
+        assert abs(got - want) <= 1e-3 * abs(want)
+        assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 1e-3
         valid = ref["attention_mask"]
         e = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"].detach()[valid])
         print(f"   hidden rel err {e:.3e}")
-        assert e <= 3e-2
+        assert e <= 3e-2                                          # measured 2.0e-2 at h = 8192 / I = 28672
         ref["loss"].backward()
         # gradients: resident tensors in p.grad / the flat resident buffers, sharded layers in the gradient shards (world 1: whole segment)
-        n, worst = 0, (0.0, "")
+        n, worst, worst_rest = 0, (0.0, ""), (0.0, "")
         for sg in opt.segs:
             for p, o, shp in zip(sg["params"], sg["offs"], sg["shapes"]):
                 numel = 1
@@ -676,10 +819,12 @@ def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
                 name = names[id(p)]
                 e = rel(gr, sd[name].grad)
                 worst = max(worst, (e, name))
-                # q / k projections of a random-weight model receive near-noise gradients (scores ~ uniform): 8e-2 there, 6e-2 elsewhere
-                assert e <= (8e-2 if ("q_proj" in name or "k_proj" in name) else 6e-2), (name, e)
+                qk = "q_proj" in name or "k_proj" in name
+                worst_rest = max(worst_rest, (0.0, "") if qk else (e, name))
+                # q / k projections of a random-weight model receive near-noise gradients (scores ~ uniform): measured 5.7e-2 there
+                assert e <= (8.5e-2 if qk else C4_GRAD_TOL), (name, e)
                 n += 1
-        print(f"   {n} gradient tensors (ZeRO-3 shards + resident), worst rel err {worst[0]:.3e} ({worst[1]})")
+        print(f"   {n} gradient tensors (ZeRO-3 shards + resident), worst rel err {worst[0]:.3e} ({worst[1]}); outside q/k {worst_rest[0]:.3e} ({worst_rest[1]})")
         assert n >= 20
     finally:
         F.set_layer_grad_hook(None)

@@ -206,3 +206,49 @@ def test_n1_greedy_decode_matches_reference_loop(name):
     torch.testing.assert_close(pz, T(g["pred_z"]), rtol=1e-4, atol=1e-6)
     act = g["active"].tolist()
     torch.testing.assert_close(torch.stack([l[act] for l in logits]), T(g["active_logits"]), rtol=1e-4, atol=2e-5)
+
+
+def test_mean_abs_loss_row_mismatch_matches_reference():
+    """`mse_loss_fn` of the reference with equal / fewer prediction / fewer target rows (oracle/gen_golden.py r3 -> ops_r3.npz)."""
+    g = np.load(os.path.join(GOLDEN, "ops_r3.npz"))
+    for name in ("eq", "fewer_pred", "fewer_tgt"):
+        t, p = torch.from_numpy(g[f"l1_{name}_t_f32"]), torch.from_numpy(g[f"l1_{name}_p_f32"])
+        want = float(g[f"l1_{name}_loss_f32"])
+        assert abs(float(ops.mean_abs_loss(t, p)) - want) <= 2e-6 * abs(want), name
+        # the reference's bf16 run accumulates the per-row means in bf16: three significant digits
+        t16, p16 = torch.from_numpy(g[f"l1_{name}_t_bf16"]), torch.from_numpy(g[f"l1_{name}_p_bf16"])
+        assert abs(float(ops.mean_abs_loss(t16, p16)) - float(g[f"l1_{name}_loss_bf16"])) <= 1e-2 * abs(want), name
+
+
+@pytest.mark.parametrize("kind", ["image_embeds", "pretraining_tp2"])
+def test_oracle_image_embeds_and_pretraining_tp_match_reference(kind):
+    """forward(image_embeds=...) -> `encode_imagesembed` (metamorph_arch.py:166-173) and `pretraining_tp = 2` (metamorph_llama.py:393-396)
+    recorded from the reference (oracle/gen_golden.py r3)."""
+    g = np.load(os.path.join(GOLDEN, f"r3_{kind}_f32.npz"))
+    cfg = OracleConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                       vocab_size=128258, v_layers=2, v_intermediate=144, v_image=56, num_image_tokens=4, tokenizer_model_max_length=64,
+                       pretraining_tp=int(g["pretraining_tp"]))
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    for k, v in sd.items():
+        v.requires_grad_("vision_tower" not in k and "vision_proj" not in k)
+    T = lambda k: torch.from_numpy(g[k])
+    out = forward(sd, cfg, T("input_ids"), T("attention_mask"), T("labels"), T("images"),
+                  image_embeds=T("image_embeds") if kind == "image_embeds" else None)
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(out["loss_language"] - float(g["loss_language"])) <= 2e-5 * abs(float(g["loss_language"]))
+    assert abs(out["loss_image_ar"] - float(g["loss_image_ar"])) <= 2e-5
+    assert torch.allclose(out["target_features"], T("target_features"), atol=1e-6)
+    assert torch.allclose(out["logits"][:, :, ::997].detach(), T("logits_sub"), atol=2e-4, rtol=2e-4)
+    assert torch.allclose(out["hidden_states"].detach(), T("hidden"), atol=2e-4, rtol=2e-4)
+    out["loss"].backward()
+    n = 0
+    for k in g.files:
+        if k.startswith("grad::"):
+            gr = sd[k[6:]].grad
+            f = gr.flatten()
+            m = min(256, f.numel())
+            idx = (torch.arange(m, dtype=torch.long) * (f.numel() - 1)) // max(m - 1, 1)
+            got = torch.cat([f.norm()[None], f[idx]])
+            assert torch.allclose(got, T(k), atol=1e-6, rtol=2e-3), k
+            n += 1
+    assert n >= 25

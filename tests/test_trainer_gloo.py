@@ -123,3 +123,73 @@ def test_trainer_two_ranks_no_ddp_equals_one_rank(tmp_path):
     finally:
         os.environ.pop("ACCELERATE_USE_CPU", None)
     torch.testing.assert_close(a, one, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ ZeRO-3: model save is a collective
+def _accum(dst, src, first):
+    if first:
+        dst.copy_(src)
+    else:
+        dst.add_(src)
+
+
+def _zero3_save_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      ACCELERATE_USE_CPU="true")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from transformers import TrainingArguments
+        from metamorph_amd.trainer import MetaMorphTrainer
+        from metamorph_amd.zero3 import Zero3AdamW
+        out = os.path.join(tmp, "run")
+        args = TrainingArguments(output_dir=out, per_device_train_batch_size=2, max_steps=3, learning_rate=1e-2, use_cpu=True, report_to=[],
+                                 save_strategy="no", remove_unused_columns=False, dataloader_pin_memory=False, seed=3)
+        model = Toy()
+        want = {k: v.clone() for k, v in model.state_dict().items()}
+        tr = MetaMorphTrainer(model=model, args=args, train_dataset=_DS(16), zero_stage=3, zero2_kwargs=dict(
+            shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip, accumulate=_accum, min_shard_numel=1, param_slots=2,
+            grad_slots=1))
+        tr.create_optimizer_and_scheduler(num_training_steps=3)
+        z = tr._zero2()
+        assert isinstance(z, Zero3AdamW) and z.world == 2
+        assert all(p.data.numel() == 0 for l in model.layers for p in l.parameters())        # sharded: the tree holds no layer weights
+        # (1) the user-facing save: HF calls _save on the should_save rank only -- the gather behind it must be entered by EVERY rank
+        tr.save_model(os.path.join(tmp, "final"))
+        dist.barrier()
+        # (2) a save_steps checkpoint (model + optimizer shards + scheduler + trainer state) goes through the same path
+        tr.state.global_step = 2
+        tr._save_checkpoint(model, trial=None)
+        dist.barrier()
+        # (3) the next collective pairs up correctly (a stray all_gather from a one-rank save would be consumed here)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        assert float(t) == 3.0
+        if rank == 0:
+            import glob
+            for d in (os.path.join(tmp, "final"), os.path.join(out, "checkpoint-2")):
+                files = glob.glob(os.path.join(d, "*.safetensors")) + glob.glob(os.path.join(d, "pytorch_model*.bin"))
+                assert files, os.listdir(d)
+                if files[0].endswith(".bin"):
+                    got = torch.load(files[0], weights_only=True)
+                else:
+                    from safetensors.torch import load_file
+                    got = load_file(files[0])
+                assert set(got) == set(want)
+                for k in want:
+                    assert torch.equal(got[k], want[k]), k                                   # the complete tensors, not one rank's slice
+            ck = os.path.join(out, "checkpoint-2")
+            assert os.path.isfile(os.path.join(ck, "zero3_rank0-of-2-optimizer.pt")) and os.path.isfile(os.path.join(ck, "zero3_rank1-of-2-optimizer.pt"))
+        # the direct _save without a gathered state dict refuses instead of hanging the other ranks
+        with pytest.raises(RuntimeError):
+            tr._save(os.path.join(tmp, "bad"))
+        torch.save(torch.ones(1), os.path.join(tmp, f"ok{rank}.pt"))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_zero3_trainer_save_model_is_collective(tmp_path):
+    port = _free_port()
+    mp.spawn(_zero3_save_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0.pt").exists() and (tmp_path / "ok1.pt").exists()

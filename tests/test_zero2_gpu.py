@@ -112,6 +112,104 @@ def test_loss_curve_matches_oracle_training():
         assert abs(a - b) <= 1.5e-2 * abs(b), f"step {s}: hip {a} vs oracle {b}"
 
 
+def _curve_batches(n, seed, V, start_id):
+    """`n` micro-batches of two samples each: an image-QA sample (prompt-side image) and a generation sample (answer-side image)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        L = 40
+        ids = torch.randint(3, V - 10, (2, L), generator=g)
+        ids[:, 0] = ids[:, 1] = 1
+        ids[0, 6], ids[0, 7], ids[0, 8] = start_id, -200, start_id + 1
+        lab = torch.full_like(ids, -100)
+        lab[0, 20:] = ids[0, 20:]
+        n1 = int(torch.randint(24, 36, (1,), generator=g))
+        ids[1, n1 - 4], ids[1, n1 - 3], ids[1, n1 - 2], ids[1, n1 - 1] = start_id, -200, start_id + 1, 2
+        ids[1, n1:] = 0                                              # pad id 0
+        lab[1, 10:n1] = ids[1, 10:n1]
+        lab[1, n1 - 3] = -200
+        mask = torch.ones_like(ids, dtype=torch.bool)
+        mask[1, n1:] = False
+        images = torch.randn(2, 3, 56, 56, generator=g)
+        out.append(dict(input_ids=ids, attention_mask=mask, labels=lab, images=images))
+    return out
+
+
+def test_long_loss_curve_matches_oracle_training():
+    """Row LC ("loss curves matching reference within tolerance"): 50 optimizer steps of a 4-layer, h = 1024 model (8 query / 2 KV
+    heads of 128, I = 2816, V = 32002) with BOTH heads live in every micro-batch, the reference's finetune recipe in miniature
+    (scripts/debug_finetune_1node.sh:47-49: AdamW, weight decay 0, cosine schedule with warm-up ratio 0.03, HF's
+    `get_cosine_schedule_with_warmup`; gradient accumulation 2; global-norm clipping 1.0; bf16 weights + fp32 master) over a pool of
+    sixteen micro-batches (loss 10.6 -> ~3.1): HIP `Zero2AdamW` against the oracle trained the same way on the host (fp32 math on bf16-rounded working
+    weights, fp32 master / moments, oracle.ref_ops.adamw_step).  Asserts the per-step relative gap and the final-loss gap."""
+    import math
+    from transformers import get_cosine_schedule_with_warmup
+    from test_model_gpu import hip_model
+    from oracle.ref_model import OracleConfig, forward as oracle_forward, init_state_dict
+    from metamorph_amd.zero2 import Zero2AdamW
+    V, START = 32002, 32000
+    cfg = OracleConfig(hidden_size=1024, intermediate_size=2816, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=2,
+                       vocab_size=V, rope_theta=10000.0, v_layers=2, v_intermediate=144, v_image=56, num_image_tokens=4,
+                       tokenizer_model_max_length=256, image_start_id=START)
+    seed, peak_lr, steps, accum = 9, 1e-4, 50, 2
+    warm = math.ceil(steps * 0.03)
+    pool = _curve_batches(16, seed=12, V=V, start_id=START)
+
+    # ---- HIP
+    model = hip_model(cfg, init_state_dict(cfg, seed=seed, dtype=torch.bfloat16, fast_big=True))
+    model.train()
+    opt = Zero2AdamW([p for p in model.parameters() if p.requires_grad], lr=peak_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                     max_grad_norm=1.0)
+    sched = get_cosine_schedule_with_warmup(opt, warm, steps)
+    dev_pool = [{k: (v.cuda().bfloat16() if k == "images" else v.cuda()) for k, v in b.items()} for b in pool]
+    hip_losses, hip_lr = [], []
+    for s in range(steps):
+        opt.zero_grad()
+        tot = 0.0
+        for a in range(accum):
+            out = model(**dev_pool[(s * accum + a) % len(pool)])
+            (out.loss / accum).backward()
+            tot += float(out.loss.detach()) / accum
+        hip_lr.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+        hip_losses.append(tot)
+
+    # ---- oracle
+    master = init_state_dict(cfg, seed=seed, fast_big=True)
+    train = [k for k in master if "vision_tower" not in k and "vision_proj" not in k]
+    mom = {k: (torch.zeros_like(master[k]), torch.zeros_like(master[k])) for k in train}
+    ora_losses = []
+    for s in range(steps):
+        lr = peak_lr * (s / max(1, warm) if s < warm else max(0.0, 0.5 * (1.0 + math.cos(math.pi * (s - warm) / max(1, steps - warm)))))
+        assert abs(lr - hip_lr[s]) <= 1e-12 + 1e-9 * peak_lr, (s, lr, hip_lr[s])
+        sd = {k: v.bfloat16().float() for k, v in master.items()}
+        for k in train:
+            sd[k].requires_grad_(True)
+        tot = 0.0
+        for a in range(accum):
+            b = pool[(s * accum + a) % len(pool)]
+            o = oracle_forward(sd, cfg, b["input_ids"], b["attention_mask"], b["labels"], b["images"].bfloat16().float(), return_logits=False,
+                               ce_rows_only=True)
+            (o["loss"] / accum).backward()
+            tot += float(o["loss"].detach()) / accum
+        ora_losses.append(tot)
+        grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in train}
+        norm = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads.values())))
+        coef = min(1.0, 1.0 / (norm + 1e-6))
+        for k in train:
+            R.adamw_step(master[k], grads[k], mom[k][0], mom[k][1], s + 1, lr, 0.9, 0.999, 1e-8, 0.0, grad_scale=coef)
+    gaps = [abs(a - b) / max(abs(b), 1.0) for a, b in zip(hip_losses, ora_losses)]
+    print("\n   long loss curve (every 5th step)  hip:", " ".join(f"{x:.4f}" for x in hip_losses[::5]), f"... {hip_losses[-1]:.4f}",
+          "\n                                 oracle:", " ".join(f"{x:.4f}" for x in ora_losses[::5]), f"... {ora_losses[-1]:.4f}",
+          f"\n   max per-step gap {max(gaps):.3e} (step {gaps.index(max(gaps))}), final gap {gaps[-1]:.3e}")
+    assert ora_losses[-1] < ora_losses[0] - 1.0, ora_losses
+    assert max(gaps) <= LC_STEP_TOL and gaps[-1] <= LC_FINAL_TOL, (max(gaps), gaps[-1])
+
+
+LC_STEP_TOL, LC_FINAL_TOL = 2e-2, 2e-2
+
+
 def test_async_update_equals_synchronous_update():
     """The update kernels of step() run per segment on a side stream and the next forward pass waits segment by segment
     (functional.params_ready): four training steps of the tiny model must give the same parameters with and without it."""
