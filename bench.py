@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--grad-checkpointing", action="store_true", help="per-layer recompute (reference --gradient_checkpointing True); NOT the headline config")
     ap.add_argument("--host-inputs", action="store_true", help="ids / labels / mask / fp32 pixels start every step in pinned HOST memory (PCIe-inclusive "
                     "rate for DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
+    ap.add_argument("--zero2-async", type=int, default=None, choices=(0, 1), help="1: AdamW shard update + parameter all-gather per segment on a side "
+                    "stream, the next forward waits segment by segment (hides the all-gather at world > 1); default: MM355_ZERO2_ASYNC or 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -153,25 +155,27 @@ def _cpu_threads():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, 64))
+    return max(1, min(avail, 32))          # 32 threads beat 64 / 128 / 256 on the GPU box host (profiles/r3_host_threads.log)
 
 
 def cpu_baseline(args):
     """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: ONE sample built like the bench's
-    (one 256-token image + text, labels as in make_batch) cut to 1024 spliced tokens, LLaMA-3-8B / SO400M layer geometry with 1 of 32 decoder
-    layers and 1 of 27 tower layers actually run plus the full 128258-entry lm_head and both loss heads, fp32, forward+backward with
-    the stage-2 freeze policy; per-stage times are scaled to the full depth to quote tokens/s."""
+    (one 256-token image + text, labels as in make_batch) at the workload's own length (2048 spliced tokens), LLaMA-3-8B / SO400M layer
+    geometry with TWO of 32 decoder layers and TWO of 27 tower layers actually run plus the full 128258-entry lm_head and both loss
+    heads, fp32, forward+backward with the stage-2 freeze policy.  Every stage is timed on its own -- each decoder layer's forward
+    separately (so the per-layer cost is measured twice, not assumed), the heads' forward, the heads' backward and the decoder's
+    backward as two separate autograd passes -- and the per-layer figures are scaled to the full depth to quote tokens/s."""
     from oracle.ref_model import OracleConfig, init_state_dict
     from oracle import ref_model as RM, ref_ops as R
     threads = _cpu_threads()
     torch.set_num_threads(threads)
-    NL = 1                                           # decoder / tower layers actually run (scaled to 32 / 27 below)
+    NL = 2                                           # decoder / tower layers actually run (scaled to 32 / 27 below)
     cfg = OracleConfig(num_hidden_layers=NL, v_layers=NL, num_image_tokens=args.image_tokens, tokenizer_model_max_length=4096)
     sd = init_state_dict(cfg, seed=1, fast_big=True)
     for k, v in sd.items():
         if "vision_tower" not in k and "vision_proj" not in k:
             v.requires_grad_(True)
-    L = min(args.seq, 1024)                          # bounded: 256 image + 768 text rows (the workload's samples are 2048 rows)
+    L = args.seq
     ids, labels, mask, images = make_batch(1, L, args.image_tokens, "cpu", seed=0, frames=1, all_generation=True)
     images = images.float()
     t0 = time.time()
@@ -181,31 +185,40 @@ def cpu_baseline(args):
     t0 = time.time()
     proj = RM.mm_projector(sd, cfg, feat)
     x, lab, valid, pos, tgt, _ = RM.splice(sd, cfg, ids, labels, mask, proj, feat)
-    hid = RM.llama_decoder(sd, cfg, x, valid)
-    t_dec_f = time.time() - t0
+    t_splice = time.time() - t0
+    cos, sin = R.rope_tables(torch.arange(L)[None], cfg.head_dim, cfg.rope_theta, x.dtype)
+    t_layers = []
+    x_leaf = x.detach().requires_grad_(True)         # the embedding / projector backward is a per-step constant: timed on its own below
+    h = x_leaf
+    for i in range(NL):                              # each layer's forward on its own clock
+        t0 = time.time()
+        h = RM.llama_layer(sd, cfg, i, h, valid, cos, sin)
+        t_layers.append(time.time() - t0)
     t0 = time.time()
-    nxt = torch.full_like(lab, -100)
-    nxt[:, :-1] = lab[:, 1:]
-    keep = nxt != -100
-    lg = R.linear(hid[keep], sd["lm_head.weight"]).float()
-    ce = (torch.logsumexp(lg, -1) - lg.gather(1, nxt[keep][:, None])[:, 0]).sum() / keep.sum()
-    pred = R.l2_normalize(RM.vision_head(sd, cfg, hid[:, :-1][pos[:, 1:].bool()]))
-    loss = ce + R.cosine_loss(tgt.reshape(-1, tgt.shape[-1]), pred)
+    hid_leaf = R.rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps).detach().requires_grad_(True)
+    res = RM.heads(sd, cfg, hid_leaf, lab, pos, tgt, return_logits=False, ce_rows_only=True)
     t_head_f = time.time() - t0
     t0 = time.time()
-    loss.backward()
-    t_bwd = time.time() - t0
-    # backward splits ~ like forward between decoder and head
-    frac_dec = t_dec_f / (t_dec_f + t_head_f)
-    t_dec = t_dec_f + t_bwd * frac_dec
-    t_head = t_head_f + t_bwd * (1 - frac_dec)
-    full = t_dec * (32 / NL) + t_head + t_vit * (27 / NL)
+    res["loss"].backward()                           # lm_head / vision_head gradients + d loss / d hidden
+    t_head_b = time.time() - t0
+    t0 = time.time()
+    R.rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps).backward(hid_leaf.grad)      # final norm + NL decoder layers
+    t_dec_b = time.time() - t0
+    t0 = time.time()
+    x.backward(x_leaf.grad)                          # splice: dense [V, h] embedding gradient (as torch's nn.Embedding produces) + projector
+    t_emb_b = time.time() - t0
+    n_ce = int((lab[:, 1:] != -100).sum())
+    per_layer = (sum(t_layers) + t_dec_b) / NL
+    t_head = t_head_f + t_head_b + t_splice + t_emb_b
+    full = per_layer * 32 + t_head + t_vit * (27 / NL)
     return {"value": round(L / full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens ({args.image_tokens} image + {L - args.image_tokens} text; "
-                       f"{int(keep.sum())} CE rows, {args.image_tokens} regression rows), LLaMA-3-8B + SO400M layer geometry with {NL}/32 decoder and "
-                       f"{NL}/27 tower layers + full lm_head; measured {t_dec:.2f}s ({NL} dec layer) {t_head:.2f}s (heads) {t_vit:.2f}s "
-                       f"({NL} tower layer), scaled to full depth = {full:.1f}s per {L} tokens"),
-            "measured_seconds": round(t_dec + t_head + t_vit, 2)}
+                       f"{n_ce} CE rows, {args.image_tokens} regression rows), LLaMA-3-8B + SO400M layer geometry with {NL}/32 decoder and "
+                       f"{NL}/27 tower layers + full lm_head; measured per stage: decoder layer forward " + " / ".join(f"{t:.2f}s" for t in t_layers)
+                       + f", decoder backward ({NL} layers) {t_dec_b:.2f}s, heads fwd {t_head_f:.2f}s bwd {t_head_b:.2f}s, embedding + projector bwd {t_emb_b:.2f}s, tower ({NL} layers) {t_vit:.2f}s; "
+                       f"per-layer cost {per_layer:.2f}s x 32 + heads + tower x 27/{NL} = {full:.1f}s per {L} tokens"),
+            "measured_seconds": round(sum(t_layers) + t_dec_b + t_head + t_vit, 2),
+            "decoder_layer_forward_seconds": [round(t, 3) for t in t_layers]}
 
 
 def cpu_baseline_c1(budget_s=40.0):
@@ -332,7 +345,8 @@ def main():
         from metamorph_amd.zero3 import Zero3AdamW
         opt = Zero3AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_hooks()
     else:
-        opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_overlap()
+        opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                         async_update=None if args.zero2_async is None else bool(args.zero2_async)).enable_overlap()
     t_build = time.time() - t_build
 
     ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank,
@@ -364,6 +378,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    dist_run = world > 1 or force_dist
+    if dist_run and hasattr(opt, "comm_timing"):
+        opt.comm_timing = True                                   # HIP events around the parts of step() that wait for RCCL
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -379,6 +396,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(loss.detach())
+    comm = opt.comm_summary(args.steps) if (dist_run and hasattr(opt, "comm_summary")) else None
+    if comm is not None:
+        opt.comm_timing = False
+    # ---- multi-rank hygiene, outside the timed region: every rank must hold the same parameters after the same updates
+    params_equal = None
+    ab_async = None
+    if dist_run:
+        if hasattr(opt, "synchronize"):
+            opt.synchronize()
+        chk = torch.zeros(2, device=dev, dtype=torch.float64)
+        for p in model.parameters():
+            if p.numel():
+                f = p.data.view(-1)
+                chk[0] += f.double().sum()
+                chk[1] += (f[:: max(1, f.numel() // 4096)].double() ** 2).sum()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_equal = bool(torch.equal(lo, hi))
+        # same-job A/B of the asynchronous update / all-gather (hidden behind the next forward pass) against the synchronous one:
+        # 3 steps each AFTER the headline measurement
+        # (opt-in, MM355_BENCH_AB_ASYNC=1: the default run does nothing after its timed region that could disturb the record)
+        if args.zero == 2 and os.environ.get("MM355_BENCH_AB_ASYNC", "0") == "1":
+            ab_async = {}
+            for tag, on in (("sync_ms_per_step", False), ("async_ms_per_step", True)):
+                opt.set_async_update(on)
+                step()
+                torch.cuda.synchronize()
+                dist.barrier()
+                ta = time.perf_counter()
+                for _ in range(3):
+                    step()
+                opt.synchronize()
+                torch.cuda.synchronize()
+                dist.barrier()
+                tt = torch.tensor([(time.perf_counter() - ta) / 3 * 1e3], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ab_async[tag] = round(float(tt), 2)
+            opt.set_async_update(False)
     tokens_per_rank = args.batch * args.seq
     value = world * tokens_per_rank * args.steps / dt
 
@@ -421,7 +477,8 @@ def main():
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
-                       "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
+                       "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else "") + (
+                           " +async-update" if getattr(opt, "async_update", False) else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
             "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
@@ -429,6 +486,11 @@ def main():
         if roofline:
             rec["roofline"] = roofline
         rec["rccl_ranks"] = dist.get_world_size() if (world > 1 or force_dist) else 1
+        if dist_run:
+            rec["params_equal_across_ranks"] = params_equal
+            rec["comm_ms_per_step"] = comm                       # exposed (not overlapped) time per phase, rank 0's stream
+            if ab_async:
+                rec["zero2_async_ab"] = ab_async
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
             rec["cpu_baseline_c1"] = cpu_baseline_c1()

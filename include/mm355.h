@@ -176,8 +176,10 @@ int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o
                         int64_t B, int64_t L, int64_t Hq, int64_t d, void* stream);
 
 /* Backward: dq / dk / dv are written as bf16 column blocks (leading dimensions ld_dq / ld_dkv), no atomics.
- * workspace: 2*B*L*Hq*d floats, required when Hq > Hkv (GQA): the dK/dV kernel runs one workgroup per
- * (KV tile, query head) and the group is summed afterwards (NULL allowed when Hq == Hkv). */
+ * workspace: mm355_attn_bwd_ws_floats(...) floats; NULL allowed when that is 0.  It is 0 without GQA (Hq == Hkv) and for the
+ * d == 128 kernels (LLaMA-3: the dK/dV workgroup walks all query heads of its KV group and sums them in registers); only the
+ * generic-d kernels under GQA (e.g. TinyLlama, d = 64) run one workgroup per (KV tile, query head) and need 2*B*L*Hq*d floats
+ * for the per-head partials that are summed afterwards. */
 int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
                    const mm355_bf16* d_o, int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens,
                    mm355_bf16* dq, int64_t ld_dq, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,

@@ -188,12 +188,8 @@ int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s) {
 
 int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s) {
     constexpr int LDS = 4 * attn3::TILE + 2 * 512;           // 65 KiB > the default cap: raise it once
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attn3::dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};                  // per-device opt-in (mm355_common.h)
+    if (mm_ensure_dynamic_lds((const void*)attn3::dkdv_kernel, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     const int64_t nblk = (int64_t)((a.L + 63) / 64) * a.Hkv * a.B;
     if (nblk > 0x7fffffff) return MM355_EINVAL;
     dim3 grid((unsigned)nblk);

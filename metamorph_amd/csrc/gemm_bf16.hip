@@ -829,12 +829,8 @@ int64_t pp_prepare(GemmArgs& a) {
 
 template <bool TA, bool TB>
 int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};              // per-device opt-in to > 64 KiB of dynamic LDS
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_kernel<TA, TB>, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), dim3((unsigned)total), dim3(512), PP_LDS, s, a);
@@ -842,12 +838,8 @@ int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
 }
 
 int launch_gemm_pp_pair(GemmArgs a0, GemmArgs a1, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};              // per-device opt-in to > 64 KiB of dynamic LDS
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_pair_kernel, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     const int64_t n0 = pp_prepare(a0), n1 = pp_prepare(a1);
     if (n0 <= 0 || n1 <= 0 || n0 + n1 > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL(gemm_pp_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(512), PP_LDS, s, a0, a1, (int)n0);
@@ -873,12 +865,8 @@ int launch_gemm_pp(GemmArgs a, hipStream_t s) {
 int launch_gemm_ring(GemmArgs a, hipStream_t s) {
     if (a.K < 128) return launch_gemm<256, 256, 2, 4, true, 0, false>(a, s);
     constexpr int LDS = 4 * (256 + 256) * 64;               // 128 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};              // per-device opt-in to > 64 KiB of dynamic LDS
+    if (mm_ensure_dynamic_lds((const void*)gemm_nt_ring_kernel, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     a.ntm = (a.M + 255) / 256;
     a.ntn = (a.N + 255) / 256;
     const int64_t total = (int64_t)a.ntm * a.ntn;
@@ -892,12 +880,8 @@ int launch_gemm(GemmArgs a, hipStream_t s) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = 2 * STAGE;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, GLDS, PIPE, TNL>;
-    static bool attr_done = false;                       // idempotent one-time attribute (benign race)
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MM355_ELAUNCH;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};              // per-device opt-in to > 64 KiB of dynamic LDS
+    if (mm_ensure_dynamic_lds((const void*)kern, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     a.ntm = (a.M + BM - 1) / BM;
     a.ntn = (a.N + BN - 1) / BN;
     const int64_t total = (int64_t)a.ntm * a.ntn;
@@ -959,6 +943,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
     part[rp][cq] = s;
     __syncthreads();
     if (rp == 0 && c < N) out[c] += (part[0][cq] + part[1][cq]) + (part[2][cq] + part[3][cq]);
+}
+
+// The same sums with 16-byte loads and 128 row phases per workgroup (1024 threads = 8 column groups of 8 x 128 phases): the bias gradients
+// of the trainable tower (M = images x 729 rows, N = 1152 / 4304 columns) read M / 128 rows per thread instead of M / 4 two-byte loads.
+// Still one workgroup per 64 columns and a fixed-order sum over the phases: deterministic, no atomics, no workspace.
+__global__ __launch_bounds__(1024) void colsum8_kernel(const uint16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out) {
+    __shared__ float part[128][65];
+    const int cg = threadIdx.x & 7, rp = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cg * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < N)                                              // N % 8 == 0: a column group is valid as a whole
+        for (int r = rp; r < M; r += 128) {
+            float f[8];
+            unpack8(*(const u32x4*)(x + (int64_t)r * ld + c0), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[rp][cg * 8 + e] = s[e];
+    __syncthreads();
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && c < N) {
+        float t = 0.f;
+        for (int p = 0; p < 128; ++p) t += part[p][threadIdx.x];
+        out[c] += t;
+    }
 }
 
 }  // namespace
@@ -1076,6 +1086,10 @@ extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t
 extern "C" int mm355_colsum_bf16(const mm355_bf16* dY, int64_t ld, int64_t M, int64_t N, float* db_f32, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!dY || !db_f32 || M <= 0 || N <= 0) return MM355_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32);
+    if (M > 0x7fffffff || N > 0x7fffffff) return MM355_EINVAL;
+    if (!(N & 7) && !(ld & 7) && mm_aligned16(dY) && M >= 256)
+        hipLaunchKernelGGL(colsum8_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dY, ld, (int)M, (int)N, db_f32);
     return mm_launch_status();
 }

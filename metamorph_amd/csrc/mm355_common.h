@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/mm355.h"
@@ -100,5 +101,17 @@ MM_DEV float gelu_tanh_grad(float x) {
 static inline int mm_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MM355_OK : MM355_ELAUNCH;
+}
+// Dynamic-LDS opt-in of a kernel (> 64 KiB): hipFuncSetAttribute acts on the CURRENT device's copy of the function, so it is done once
+// per device (a bit per device ordinal in a per-kernel mask); a process driving several GPUs gets every device configured.
+static inline int mm_ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MM355_ELAUNCH;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return MM355_ELAUNCH;
+        done.fetch_or(bit, std::memory_order_release);       // idempotent: a concurrent first call just sets the attribute twice
+    }
+    return MM355_OK;
 }
 static inline bool mm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

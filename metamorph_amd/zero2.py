@@ -116,6 +116,51 @@ class Zero2AdamW(torch.optim.Optimizer):
         self._ready = {}                   # segment index -> event recorded on the update stream
         self._waited = set()
         self._async_hooked = False
+        # comm_timing = True: HIP events on the compute stream around the parts of step() that WAIT for collectives (bench.py at
+        # world > 1): what the step pays for communication after overlap, per phase
+        self.comm_timing = False
+        self._comm_events = {"reduce_scatter_exposed": [], "norm_all_reduce": [], "all_gather": []}
+
+    def set_async_update(self, on):
+        """Switch the asynchronous update / all-gather (see above) on an existing optimizer (bench.py's A/B at world > 1)."""
+        self.wait_all()
+        on = bool(on) and self.flat_param.is_cuda
+        if on and self._upd_stream is None:
+            self._upd_stream = torch.cuda.Stream(device=self.flat_param.device)
+        self.async_update = on
+        if on:
+            self.enable_async_wait()
+        elif self._async_hooked:
+            from . import functional as F
+            F.set_param_ready_hook(None)
+            self._async_hooked = False
+        return self
+
+    def _timed(self, phase):
+        """Context manager: HIP events around a phase on the current stream when comm_timing is on."""
+        opt = self
+
+        class _T:
+            def __enter__(self_):
+                if opt.comm_timing and opt.flat_param.is_cuda:
+                    self_.s = torch.cuda.Event(enable_timing=True)
+                    self_.s.record()
+                return self_
+
+            def __exit__(self_, *a):
+                if opt.comm_timing and opt.flat_param.is_cuda:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    opt._comm_events[phase].append((self_.s, e))
+        return _T()
+
+    def comm_summary(self, steps):
+        """{phase: ms per step} from the recorded events (syncs); clears them."""
+        if self.flat_param.is_cuda:
+            torch.cuda.synchronize()
+        out = {k: round(sum(s.elapsed_time(e) for s, e in v) / max(steps, 1), 3) for k, v in self._comm_events.items()}
+        self._comm_events = {k: [] for k in self._comm_events}
+        return out
 
     # ------------------------------------------------------------------ layout
     def _flatten(self, params):
@@ -231,11 +276,12 @@ class Zero2AdamW(torch.optim.Optimizer):
         if not self._coll:
             self._settle_grads(self.params)
             return
-        for i in range(len(self.segs)):
-            if i not in self._pending:
-                self._launch_reduce(i, async_op=False)
-        for pend in self._pending.values():
-            pend.wait()
+        with self._timed("reduce_scatter_exposed"):          # what is left of the reductions once backward has ended
+            for i in range(len(self.segs)):
+                if i not in self._pending:
+                    self._launch_reduce(i, async_op=False)
+            for pend in self._pending.values():
+                pend.wait()
         self._pending = {}
         self._armed = False
 
@@ -356,7 +402,8 @@ class Zero2AdamW(torch.optim.Optimizer):
         for _, _, g, _, _ in self._my_slices():
             self._sumsq(g, self._norm_buf)
         if self._coll:
-            dist.all_reduce(self._norm_buf, op=dist.ReduceOp.SUM, group=self.pg)
+            with self._timed("norm_all_reduce"):
+                dist.all_reduce(self._norm_buf, op=dist.ReduceOp.SUM, group=self.pg)
         # coef = min(1, max_norm / (||mean grad|| + 1e-6)) * (1/world), computed on the device (no host sync)
         self._clip_coef_scaled(inv_world)
         self._step += 1
@@ -367,7 +414,8 @@ class Zero2AdamW(torch.optim.Optimizer):
         else:
             for so, m, gs, ps, gi in self._my_slices():
                 self._shard_update(self.master[so:so + m], self.exp_avg[so:so + m], self.exp_avg_sq[so:so + m], gs, ps, *self._hyper(gi))
-            self._all_gather_params()
+            with self._timed("all_gather"):
+                self._all_gather_params()
         self.grad_norm = self._norm_buf        # sum of squares of the summed gradient (device scalar); see grad_norm_value()
         if self.flat_param.is_cuda:
             from . import functional as F

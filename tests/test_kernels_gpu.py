@@ -302,6 +302,17 @@ def test_transpose_and_colsum(ops):
     s = torch.zeros(264, device=DEV)
     ops.colsum_f32(x.to(DEV), s)
     close(s, x.float().sum(0), 1e-4, 1e-3, "colsum")
+    # the narrow-load form (few rows, or a column count that is not a multiple of 8) and a strided column block of a wider matrix
+    for (r, c) in [(100, 264), (600, 203)]:
+        x = rnd(r, c, seed=r + c)
+        s = torch.zeros(c, device=DEV)
+        ops.colsum_f32(x.to(DEV), s)
+        close(s, x.float().sum(0), 1e-4, 1e-3, f"colsum {r}x{c}")
+    wide = rnd(777, 3 * 1152, seed=5).to(DEV)
+    blk = wide[:, 1152:2 * 1152]
+    s = torch.zeros(1152, device=DEV)
+    ops.colsum_f32(blk, s)
+    close(s, blk.float().sum(0), 1e-4, 2e-3, "colsum of a column block")
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -475,7 +475,7 @@ def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
 
 
 # ------------------------------------------------------------------ BASELINE configs[0] geometry class (TinyLlama: d = 64, GQA 8:1)
-D64_HIDDEN_TOL, D64_GRAD_TOL = 1.3e-2, 4e-2
+D64_HIDDEN_TOL, D64_GRAD_TOL = 9.5e-3, 2.2e-2          # 1.5 x measured (6.3e-3, 1.44e-2)
 
 
 def test_e2e_head_dim_64_gqa8_against_oracle():
@@ -516,7 +516,7 @@ def test_e2e_head_dim_64_gqa8_against_oracle():
 
 
 # ------------------------------------------------------------------ row N4: trainable vision tower (freeze_vision=False)
-TOWER_GRAD_TOL = 8e-2
+TOWER_GRAD_TOL = 1.8e-2                                    # 1.5 x measured (1.15e-2, layers.1.q_proj)
 
 
 def test_trainable_vision_tower_gradients_against_oracle():
@@ -731,16 +731,16 @@ def test_configs3_all_generation_8b_widths_against_oracle():
         labels[b, n - 3] = -200
     mask = ids.ne(128001)
     images = torch.randn(B, 3, 384, 384, generator=g)
-    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=53, grad_tol=C3_GRAD_TOL, hidden_tol=1.3e-2,
+    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=53, grad_tol=C3_GRAD_TOL, hidden_tol=1.85e-2,
                          what="configs[3] all-generation (3 x 256 regression rows)")
     assert n >= 20
 
 
-C3_GRAD_TOL = 4e-2
+C3_GRAD_TOL = 4.6e-2                                       # 1.5 x measured (3.07e-2, layers.1.q_proj); hidden 1.23e-2 -> 1.85e-2
 
 
 # ------------------------------------------------------------------ BASELINE configs[4] shape: LLaMA-3-70B widths under ZeRO-3 + recompute
-C4_GRAD_TOL = 6e-2
+C4_GRAD_TOL = 6e-2                                         # measured 5.4e-2 outside q / k (layers.1.input_layernorm), 5.7e-2 on q / k
 
 
 def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():

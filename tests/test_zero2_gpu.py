@@ -207,7 +207,7 @@ def test_long_loss_curve_matches_oracle_training():
     assert max(gaps) <= LC_STEP_TOL and gaps[-1] <= LC_FINAL_TOL, (max(gaps), gaps[-1])
 
 
-LC_STEP_TOL, LC_FINAL_TOL = 2e-2, 2e-2
+LC_STEP_TOL, LC_FINAL_TOL = 1.4e-2, 3e-3                  # 1.5 x measured on MI355X (9.2e-3 at step 42, 1.8e-3 final)
 
 
 def test_async_update_equals_synchronous_update():
