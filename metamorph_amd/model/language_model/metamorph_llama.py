@@ -22,7 +22,8 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 import torch
 import torch.nn as nn
-from transformers import AutoConfig, AutoModelForCausalLM, LlamaConfig, PreTrainedModel
+from transformers import AutoConfig, AutoModelForCausalLM, GenerationMixin, LlamaConfig, PreTrainedModel
+from transformers.cache_utils import DynamicCache
 from transformers.modeling_outputs import CausalLMOutputWithPast
 
 from ... import functional as F
@@ -90,6 +91,34 @@ class _DecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
 
+class HipKVCache(DynamicCache):
+    """What `past_key_values` is under HF `generate()` (reference metamorph_llama.py:711-717, `use_customize_greedy=False`): a
+    `transformers` Cache whose payload is `functional.KVCache` -- post-RoPE keys / values of every decoder layer in the layout the
+    decode kernels read ([layers, 1, max_len, Hkv*d] bf16, write position on the device) -- plus the captured hipGraph of the
+    per-token step.  HF only asks a cache for its length; the tensors never leave the device or change layout."""
+
+    def __init__(self, capacity=None, **kw):
+        super().__init__(**kw)
+        self.capacity = capacity          # rows to allocate at the first (prompt) pass; None: prompt + 1024 + 2
+        self.kv = None                    # functional.KVCache
+        self.stepper = None               # functional.DecodeStepGraph
+        self.meta = None
+
+    def get_seq_length(self, layer_idx=0):
+        return 0 if self.kv is None else int(self.kv.length)
+
+    def get_max_cache_shape(self, layer_idx=0):
+        return -1 if self.kv is None else int(self.kv.max_len)
+
+    def reorder_cache(self, beam_idx):
+        if int(beam_idx.numel()) != 1 or int(beam_idx.reshape(-1)[0]) != 0:
+            raise NotImplementedError("beam search (num_beams > 1) needs one KV cache per beam; the decode kernels hold one sequence")
+
+    def crop(self, max_length):
+        if self.kv is not None and 0 <= max_length < self.kv.length:
+            self.kv.set_length(int(max_length))
+
+
 class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
     """`model.*` sub-tree: embed_tokens, layers, norm, vision_tower, mm_projector, vision_proj."""
     config_class = MetaMorphConfig
@@ -122,7 +151,7 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         return self._rope[1], self._rope[2]
 
 
-class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
+class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaForCausalLM):
     config_class = MetaMorphConfig
     base_model_prefix = "model"
     supports_gradient_checkpointing = True      # honoured as per-layer recompute (functional.LayerMeta.recompute)
@@ -252,8 +281,12 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
                     return_dict=None, cache_position=None, image_positions=None, decoding=False, image_features=None):
         """Reference metamorph_llama.py:285-498."""
         if past_key_values is not None or use_cache:
-            raise NotImplementedError("llm_forward is the training / prefill pass and takes no past_key_values; cached decoding runs "
-                                      "through greedy_decode / generate (functional.KVCache + the decode-shape kernels)")
+            # HF `generate()` (reference :711-717 -> GenerationMixin -> forward with a cache): prompt pass / one row per step on the
+            # decode-shape kernels
+            if labels is not None or decoding or image_positions is not None:
+                raise NotImplementedError("past_key_values / use_cache together with labels or the image-AR head: the cached path is the "
+                                          "generation path (no loss)")
+            return self._cached_forward(input_ids, inputs_embeds, attention_mask, past_key_values, return_dict)
         if output_attentions:
             raise NotImplementedError("output_attentions: attention probabilities are never materialised by the flash kernel")
         return_dict = True if return_dict is None else return_dict
@@ -399,7 +432,11 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         gradient-accumulation steps exactly as it does for the reference class)."""
         image_positions = None
         target = None
-        if inputs_embeds is None:
+        if inputs_embeds is None and past_key_values is not None and (images is None or past_key_values.get_seq_length() > 0):
+            # a decode step under HF generate(): token ids only, the prompt (with its images) already sits in the cache -- the
+            # reference reaches the same early return in prepare_inputs_labels_for_multimodal (`input_ids.shape[1] == 1`, :187-193)
+            pass
+        elif inputs_embeds is None:
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels, image_positions,
              target) = self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
                                                                  labels, images, image_sizes, image_embeds)
@@ -534,6 +571,76 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         output = [torch.tensor(generated, dtype=torch.int32, device=dev)]
         return (output, emb) if output_image else output
 
+    # ------------------------------------------------------------------ HF generate() on the decode kernels (reference :711-738)
+    def _prefill_rows(self, x2d, cache):
+        """[L0, h] prompt rows -> hidden rows [L0, h] (pre final norm); fills `cache` (allocating it on first use)."""
+        dev = x2d.device
+        L0, h = x2d.shape
+        _, meta = self._decode_meta(L0)
+        cap = cache.capacity if cache.capacity is not None else L0 + 1024 + 2
+        if cap < L0 + 1:
+            raise ValueError(f"HipKVCache capacity {cap} is smaller than the prompt ({L0} rows)")
+        cos, sin = self.model.rope_tables(cap, dev)
+        meta.cos, meta.sin = cos, sin
+        cache.kv = F.KVCache(len(self.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
+        cache.meta = meta
+        rows = F.decoder_prefill(x2d, self.model.layers, meta, cache.kv)
+        cache.stepper = F.DecodeStepGraph(self.model.layers, meta, cache.kv, cos, sin, h, dev)
+        return rows
+
+    def _decode_rows(self, x2d, cache):
+        """New rows (usually one) appended one at a time against the cache -> their hidden rows [n, h] (pre final norm)."""
+        outs = [cache.stepper.step(x2d[i:i + 1]).clone() for i in range(x2d.shape[0])]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def _rows_logits(self, rows):
+        """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399)."""
+        hid = self.model.norm(rows)
+        if hid.shape[0] <= 8:
+            return ops.gemv(hid.contiguous(), self.lm_head.weight.data,
+                            out=torch.empty((hid.shape[0], self.lm_head.weight.shape[0]), device=rows.device, dtype=torch.float32))
+        return ops.gemm(hid, self.lm_head.weight.data, out_f32=True)
+
+    @torch.no_grad()
+    def _cached_forward(self, input_ids, inputs_embeds, attention_mask, past_key_values, return_dict):
+        F.params_ready(None)
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        if inputs_embeds.dtype != BF16:
+            raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
+        B, n, h = inputs_embeds.shape
+        if B != 1:
+            raise NotImplementedError("cached decoding handles one sequence (batch 1, num_beams 1), like the reference's own loop")
+        if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
+            raise NotImplementedError("cached decoding takes an un-padded prompt (attention_mask all ones)")
+        cache = past_key_values
+        if cache is None:
+            cache = HipKVCache()
+        if not isinstance(cache, HipKVCache):
+            if cache.get_seq_length() != 0:
+                raise NotImplementedError("past_key_values must be a metamorph_amd HipKVCache (generate() creates one); a foreign, "
+                                          "already filled transformers Cache holds tensors in another layout")
+            fresh = HipKVCache()                              # an empty HF cache object: swap in ours
+            cache = fresh
+        x2d = inputs_embeds.reshape(n, h).contiguous()
+        rows = self._prefill_rows(x2d, cache) if cache.kv is None else self._decode_rows(x2d, cache)
+        logits = self._rows_logits(rows.contiguous()).view(1, n, -1)
+        hidden = self.model.norm(rows).view(1, n, h)
+        if return_dict is False:
+            return (logits, cache)
+        return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=hidden, attentions=None)
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        """Reference metamorph_llama.py:721-735: the HF default plus `images` / `image_sizes` handed through."""
+        images = kwargs.pop("images", None)
+        image_sizes = kwargs.pop("image_sizes", None)
+        inputs = super().prepare_inputs_for_generation(input_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds, **kwargs)
+        if images is not None:
+            inputs["images"] = images
+        if image_sizes is not None:
+            inputs["image_sizes"] = image_sizes
+        return inputs
+
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, output_image=False, use_customize_greedy=True,
                  image_embeds=None, **kwargs):
@@ -545,8 +652,21 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, MetaMorphMetaForCausalLM):
         else:
             inputs_embeds = self.get_model().embed_tokens(inputs)
         if not use_customize_greedy:
-            raise NotImplementedError("HF GenerationMixin sampling / beam search is out of scope; the reference's own path is the "
-                                      "custom greedy loop (use_customize_greedy=True)")
+            # reference :711-717: `super().generate(position_ids=..., attention_mask=..., inputs_embeds=..., **kwargs)` -- HF's sampling
+            # / greedy search driving forward() with a cache.  Here the cache is a HipKVCache (decode kernels + hipGraph replay).
+            if int(kwargs.get("num_beams", 1) or 1) != 1:
+                raise NotImplementedError("num_beams > 1: the decode kernels hold one sequence's KV cache")
+            if kwargs.get("past_key_values") is None and kwargs.get("use_cache", True):
+                L0 = int(inputs_embeds.shape[1])
+                new = kwargs.get("max_new_tokens")
+                if new is None and kwargs.get("max_length") is not None:
+                    new = max(int(kwargs["max_length"]) - 0, 1)          # with inputs_embeds HF counts max_length over NEW tokens
+                if new is None:
+                    gc = kwargs.get("generation_config") or self.generation_config
+                    new = getattr(gc, "max_new_tokens", None) or getattr(gc, "max_length", 20) or 20
+                kwargs["past_key_values"] = HipKVCache(capacity=L0 + int(new) + 2)
+            return GenerationMixin.generate(self, position_ids=position_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                                            **kwargs)
         return self.greedy_decode(position_ids=position_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
                                   output_image=output_image, **kwargs)
 
