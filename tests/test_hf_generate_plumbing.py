@@ -1,0 +1,88 @@
+"""HF `generate()` plumbing of the drop-in class on CPU (reference metamorph_llama.py:711-738, `use_customize_greedy=False`):
+GenerationMixin must drive `forward` -> `_cached_forward` with a `HipKVCache`, one prompt pass then one row per step, and emit the ids
+the REFERENCE's own HF-generate run emitted on the same weights (tests/golden/hfgen_text.npz, oracle/gen_golden.py hfgen).  The three
+compute hooks of the cached path (`_prefill_rows`, `_decode_rows`, `_rows_logits`; on the GPU: decode kernels + hipGraph replay, see
+tests/test_model_gpu.py::test_hf_generate_matches_reference_recorded) are replaced by the CPU oracle here -- this test is about the
+control flow between transformers and the class, which needs no GPU."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import ref_model as RM, ref_ops as R
+from oracle.ref_model import OracleConfig, decode_fixture_state_dict
+
+
+def _cpu_model(g):
+    from metamorph_amd.factory import build_model
+    cfg = OracleConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                       vocab_size=128258, v_layers=2, v_intermediate=144, v_image=56, num_image_tokens=4, tokenizer_model_max_length=64)
+    sd = decode_fixture_state_dict(g, cfg, torch.float32)
+    llm = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+               vocab_size=128258, rms_norm_eps=1e-5, rope_theta=500000.0)
+    geo = dict(hidden_size=1152, intermediate_size=144, num_hidden_layers=2, num_attention_heads=16, image_size=56, patch_size=14)
+    model = build_model(llm, geo, num_image_tokens=4, max_length=64, state_dict=sd, dtype=torch.bfloat16).eval()
+    calls = dict(prefill=0, decode=0)
+
+    def decoder_rows(x):                                          # [L, h] fp32 -> hidden rows before the final norm
+        L = x.shape[0]
+        cos, sin = R.rope_tables(torch.arange(L)[None], cfg.head_dim, cfg.rope_theta, x.dtype)
+        h = x[None]
+        for i in range(cfg.num_hidden_layers):
+            h = RM.llama_layer(sd, cfg, i, h, None, cos, sin)
+        return h[0]
+
+    def prefill(x2d, cache):
+        calls["prefill"] += 1
+        cache.rows = x2d.float()
+        cache.kv = SimpleNamespace(length=x2d.shape[0], max_len=cache.capacity)
+        return decoder_rows(cache.rows).bfloat16()
+
+    def decode(x2d, cache):
+        calls["decode"] += 1
+        assert x2d.shape[0] == 1                                  # one new row per step
+        cache.rows = torch.cat([cache.rows, x2d.float()], 0)
+        cache.kv.length += 1
+        assert cache.kv.length <= cache.kv.max_len
+        return decoder_rows(cache.rows)[-1:].bfloat16()
+
+    model._prefill_rows = prefill
+    model._decode_rows = decode
+    model._rows_logits = lambda rows: R.linear(R.rmsnorm(rows.float(), sd["model.norm.weight"], cfg.rms_norm_eps), sd["lm_head.weight"]).float()
+    model.model.norm.forward = lambda x: R.rmsnorm(x.float(), sd["model.norm.weight"], cfg.rms_norm_eps).bfloat16()
+    model.model.embed_tokens.forward = lambda ids: sd["model.embed_tokens.weight"][ids].bfloat16()
+    return model, calls
+
+
+def test_hf_generate_greedy_and_sampling_reproduce_reference_ids():
+    g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
+    model, calls = _cpu_model(g)
+    ids = torch.from_numpy(g["input_ids"])
+    want = g["tokens"].tolist()
+    out = model.generate(inputs=ids, use_customize_greedy=False, do_sample=False, max_new_tokens=int(g["max_new_tokens"]),
+                         eos_token_id=128009, pad_token_id=128001)
+    assert out[0].tolist() == want, (out[0].tolist(), want)
+    assert calls == dict(prefill=1, decode=len(want) - 1)         # ONE prompt pass, then one cached row per emitted token
+    # sampling: the planned token holds > 0.99 of the mass at T = 0.7, so the top-p = 0.9 nucleus is that token for any seed
+    for seed in (0, 5):
+        torch.manual_seed(seed)
+        out = model.generate(inputs=ids, use_customize_greedy=False, do_sample=True, temperature=0.7, top_p=0.9,
+                             max_new_tokens=int(g["max_new_tokens"]), eos_token_id=128009, pad_token_id=128001)
+        assert out[0].tolist() == g["sampled_tokens"].tolist() == want
+    # beam search is refused, not silently run as greedy
+    import pytest
+    with pytest.raises(NotImplementedError):
+        model.generate(inputs=ids, use_customize_greedy=False, num_beams=2, max_new_tokens=4)
+
+
+def test_hip_kv_cache_is_a_transformers_cache():
+    from transformers.cache_utils import Cache
+    from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
+    c = HipKVCache(capacity=32)
+    assert isinstance(c, Cache) and c.get_seq_length() == 0
+    c.kv = SimpleNamespace(length=7, max_len=32, set_length=lambda n: setattr(c.kv, "length", n))
+    assert c.get_seq_length() == 7 and c.get_max_cache_shape() == 32
+    c.crop(5)
+    assert c.get_seq_length() == 5
