@@ -581,7 +581,7 @@ template <int N> MM_DEV void wait_vmcnt() {
 
 // body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
 // in one grid)
-template <bool TA, bool TB>
+template <bool TA, bool TB, int ABL = 0>
 MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
@@ -663,7 +663,7 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(sb + dst[kd][h]), 16, src[kd][h],
-                                                     tile * (isA ? kstepA : kstepB), 0, 0);
+                                                     (ABL == 3 ? (tile & 1) : tile) * (isA ? kstepA : kstepB), 0, 0);   // ABL 3: K tiles 0 / 1 over and over
     };
 
     // ---- fragments: row-major operands by ds_read_b128, contraction-major ones by two ds_read_b64_tr_b16 (k rows j..j+3 and
@@ -729,12 +729,14 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
         constexpr int P = decltype(p_c)::value, VM = decltype(vm_c)::value;
         constexpr bool ISSUE = decltype(issue_c)::value, NEXTA = decltype(nexta_c)::value;
         constexpr int ah = P >> 1, bh = (P == 1 || P == 2) ? 1 : 0;
-        if constexpr (P == 0) rdB(0, tile);
-        if constexpr (P == 1) rdB(1, tile);
-        if constexpr (P == 2) rdA(1, tile);
-        if constexpr (P == 3 && NEXTA) rdA(0, tile + 1);
-        if constexpr (ISSUE) issue((P + 2) & 3, st);
-        wait_vmcnt<VM>();
+        if constexpr (ABL != 2) {
+            if constexpr (P == 0) rdB(0, tile);
+            if constexpr (P == 1) rdB(1, tile);
+            if constexpr (P == 2) rdA(1, tile);
+            if constexpr (P == 3 && NEXTA) rdA(0, tile + 1);
+        }
+        if constexpr (ISSUE && ABL != 1) issue((P + 2) & 3, st);
+        if constexpr (ABL != 1) wait_vmcnt<VM>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -793,10 +795,183 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
-template <bool TA, bool TB>
+// ------------------------------------------------------------------------------------------------
+// Two-phase form of the ping-pong tile (row-major operands): the same two wave groups one barrier apart, but a K tile is TWO phases of
+// 32 MFMAs instead of four of 16, i.e. half as many hand-overs between the groups per unit of matrix work:
+//        phase   quadrants                 fragments read in the load section          LDS-DMA issued in the load section
+//        X(t)    (a0,b0) (a0,b1)           B cols blocks 0, 1 of tile t (8 reads)      A rows block 0 of t+2, A rows block 1 of t+1
+//        Y(t)    (a1,b1) (a1,b0)           A rows block 1 of t, block 0 of t+1 (16)    B cols blocks 0, 1 of t+2
+// Ring = two K tiles as in gemm_pp_tile; a quarter is re-issued in the first load section after its last reader (of either group)
+// has passed, is waited for (counted vmcnt(8): the two quarters of this phase and of the one before stay in flight) at the end of
+// the load section that precedes its first read, and is published by the barrier that follows.  Same accumulation order per output
+// element as gemm_pp_tile: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+MM_DEV void gemm_pp2_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
+    constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr int A_BYTES = BM * 128;
+
+    const int total = a.ntm * a.ntn;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int GM = a.gm;
+    const int gsize = GM * a.ntn;
+    const int grp = logical / gsize;
+    const int first_m = grp * GM;
+    const int gm = min(a.ntm - first_m, GM);
+    const int in_g = logical - grp * gsize;
+    const int tm = first_m + in_g % gm;
+    const int tn = in_g / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_s >> 2, wn = wave_s & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, N = a.N;
+    const int nk = a.K >> 6;                                 // host guarantees K % 128 == 0, K >= 128
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // quarter kinds as in gemm_pp_tile: 0 = A rows block 0, 1 = B cols block 0, 2 = B cols block 1, 3 = A rows block 1
+    uint32_t src[4][2];
+    int dst[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = wave_s + 8 * h;
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd) {
+            const bool isA = kd == 0 || kd == 3;
+            const int blk = isA ? (kd == 3) : (kd - 1);
+            const int rin = lane >> 3, c = (lane & 7) ^ rin;
+            if (isA) {
+                const int row = h * 128 + blk * 64 + wave_s * 8;
+                src[kd][h] = (uint32_t)((int64_t)(min(m0 + row + rin, M - 1) - m0) * a.lda * 2 + c * 16);
+                dst[kd][h] = row * 128;
+            } else {
+                const int row = (q >> 2) * 64 + blk * 32 + (q & 3) * 8;
+                src[kd][h] = (uint32_t)((int64_t)(min(n0 + row + rin, N - 1) - n0) * a.ldb * 2 + c * 16);
+                dst[kd][h] = A_BYTES + row * 128;
+            }
+        }
+    }
+    const uint16_t* baseA = a.A + (int64_t)m0 * a.lda;
+    const uint16_t* baseB = a.B + (int64_t)n0 * a.ldb;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, 0x7fffffff, 0x00020000);
+    auto issue = [&](int kd, int tile) {
+        unsigned char* sb = smem + (tile & 1) * BUF;
+        const bool isA = kd == 0 || kd == 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(sb + dst[kd][h]), 16, src[kd][h], tile * 128, 0, 0);
+    };
+
+    const int sw0 = ((fq) ^ (fr & 7)) << 4;
+    const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    const int a_off = (wm * TM + fr) * 128;
+    const int b_off = A_BYTES + (wn * TN + fr) * 128;
+    bf16x8 A[2][4][2], B[2][2][2];
+    auto rdA = [&](int ah, int tile) {
+        const unsigned char* sb = smem + (tile & 1) * BUF + a_off + ah * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A[ah][i][0] = *(const bf16x8*)(sb + i * 2048 + sw0);
+            A[ah][i][1] = *(const bf16x8*)(sb + i * 2048 + sw1);
+        }
+    };
+    auto rdB = [&](int bh, int tile) {
+        const unsigned char* sb = smem + (tile & 1) * BUF + b_off + bh * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            B[bh][j][0] = *(const bf16x8*)(sb + j * 2048 + sw0);
+            B[bh][j][1] = *(const bf16x8*)(sb + j * 2048 + sw1);
+        }
+    };
+    // one phase.  YP: false = X, true = Y;  VM = vmcnt kept in flight;  I0 / I1: issue the phase's first / second quarter
+    // (X: A0 of t+2 / A1 of t+1;  Y: B0 / B1 of t+2);  NEXTA: tile t+1 exists (Y reads its A rows block 0)
+    auto phase = [&](auto y_c, auto vm_c, auto i0_c, auto i1_c, auto nexta_c, int t) {
+        constexpr bool YP = decltype(y_c)::value, I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value, NEXTA = decltype(nexta_c)::value;
+        constexpr int VM = decltype(vm_c)::value;
+        constexpr int ah = YP ? 1 : 0;
+        if constexpr (!YP) {
+            rdB(0, t);
+            rdB(1, t);
+            if constexpr (I0) issue(0, t + 2);
+            if constexpr (I1) issue(3, t + 1);
+        } else {
+            rdA(1, t);
+            if constexpr (NEXTA) rdA(0, t + 1);
+            if constexpr (I0) issue(1, t + 2);
+            if constexpr (I1) issue(2, t + 2);
+        }
+        wait_vmcnt<VM>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int bh = YP ? 1 - hb : hb;                 // X: (a0,b0) (a0,b1);  Y: (a1,b1) (a1,b0)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ah][i][kk], B[bh][j][kk], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0_ = std::integral_constant<int, 0>; using I2_ = std::integral_constant<int, 2>;
+    using I6_ = std::integral_constant<int, 6>; using I8_ = std::integral_constant<int, 8>;
+    using T = std::true_type; using F = std::false_type;
+
+    // prologue: tiles 0 and 1 in flight except A rows block 1 of tile 1 (issued by X(0)); first needed: A0, B0, B1 of tile 0
+    issue(0, 0); issue(1, 0); issue(2, 0);
+    issue(3, 0); issue(0, 1);
+    issue(1, 1); issue(2, 1);
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    rdA(0, 0);
+    // X(0) re-issues the A rows block 0 slot of buffer 0 (for tile 2) right away: every wave's read of it must have completed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // the second group runs one barrier behind the first
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) {                                // steady state
+        phase(F{}, I8_{}, T{}, T{}, T{}, t);
+        phase(T{}, I8_{}, T{}, T{}, T{}, t);
+    }
+    // t = nk - 2: only A rows block 1 of the last tile is still to be issued; then the ring drains
+    phase(F{}, I6_{}, F{}, T{}, T{}, t);
+    phase(T{}, I2_{}, F{}, F{}, T{}, t);
+    phase(F{}, I0_{}, F{}, F{}, F{}, t + 1);
+    phase(T{}, I0_{}, F{}, F{}, F{}, t + 1);
+    if (wm == 0) __builtin_amdgcn_s_barrier();               // the first group catches the barrier count up
+    __syncthreads();
+    gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+}
+
+__global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_pp2_tile(a, blockIdx.x, smem);
+}
+
+template <bool TA, bool TB, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemm_pp_tile<TA, TB>(a, blockIdx.x, smem);
+    gemm_pp_tile<TA, TB, ABL>(a, blockIdx.x, smem);
 }
 
 // Two independent row-major problems in ONE grid: workgroups [0, n0) work on a0, the rest on a1.  A launch is executed in
@@ -827,13 +1002,13 @@ int64_t pp_prepare(GemmArgs& a) {
     return (int64_t)a.ntm * a.ntn;
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int ABL = 0>
 int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
     static std::atomic<uint64_t> lds_ok{0};              // per-device opt-in to > 64 KiB of dynamic LDS
-    if (mm_ensure_dynamic_lds((const void*)gemm_pp_kernel<TA, TB>, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_kernel<TA, TB, ABL>, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
-    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB>), dim3((unsigned)total), dim3(512), PP_LDS, s, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, ABL>), dim3((unsigned)total), dim3(512), PP_LDS, s, a);
     return mm_launch_status();
 }
 
@@ -855,6 +1030,16 @@ bool pp_eligible(const GemmArgs& a, bool ta, bool tb) {
     if (ta && (a.M < 8 || (a.M & 7))) return false;
     if (tb && (a.N < 8 || (a.N & 7))) return false;
     return ea < 0x7fffffffLL && eb < 0x7fffffffLL;
+}
+
+int launch_gemm_pp2(GemmArgs a, hipStream_t s) {
+    if (!pp_eligible(a, false, false)) return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
+    static std::atomic<uint64_t> lds_ok{0};
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp2_kernel, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    const int64_t total = pp_prepare(a);
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_pp2_kernel, dim3((unsigned)total), dim3(512), PP_LDS, s, a);
+    return mm_launch_status();
 }
 
 int launch_gemm_pp(GemmArgs a, hipStream_t s) {
@@ -973,7 +1158,7 @@ __global__ __launch_bounds__(1024) void colsum8_kernel(const uint16_t* __restric
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 11; }
+extern "C" int mm355_gemm_num_variants(void) { return 12; }
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -1010,6 +1195,10 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
         case 10: return launch_gemm_ring(a, s);
         case 11: return launch_gemm_pp(a, s);
+        case 12: return launch_gemm_pp2(a, s);
+        case 91: return launch_gemm_pp_t<false, false, 1>(a, s);     // TIMING-ONLY ablations (wrong results): no DMA / no fragment reads
+        case 92: return launch_gemm_pp_t<false, false, 2>(a, s);
+        case 93: return launch_gemm_pp_t<false, false, 3>(a, s);     // every DMA issued, but always K tiles 0 / 1 (L2-resident sources)
         default: return MM355_EUNSUPPORTED;
     }
 }

@@ -48,13 +48,14 @@ def _layer_weights(fetch, i, requires_grad=False):
 
 
 def full_depth(fetch, cfg: RM.OracleConfig, input_ids, attention_mask, labels, images, probe_layers=(), grad_layers=(),
-               head_grads=True, backward=True, log=None):
+               head_grads=True, backward=True, log=None, embed_grad=False):
     """fp32 forward (and backward) of the whole model, layer-streamed.  Right padding only.
 
     Returns a dict: raw_hidden [N, P, hv] (tower, hidden_states[-1]), features, projected, labels / attention_mask /
     image_positions (spliced, as `ref_model.forward`), probes {n: [B, L, h] hidden rows after n decoder layers (zeros on padding)},
     hidden_states [B, L, h] (after the final norm), loss / loss_language / loss_image_ar, grads {name: tensor} for the tensors of
-    `grad_layers`, and -- head_grads -- model.norm, lm_head, vision_head.*, model.mm_projector.*, seconds {phase: s}."""
+    `grad_layers`, and -- head_grads -- model.norm, lm_head, vision_head.*, model.mm_projector.* (embed_grad: model.embed_tokens too),
+    seconds {phase: s}."""
     say = log or (lambda *_: None)
     sd = LazyStateDict(fetch)
     t_all = time.time()
@@ -68,9 +69,10 @@ def full_depth(fetch, cfg: RM.OracleConfig, input_ids, attention_mask, labels, i
     proj_names = [f"model.mm_projector.{2 * j}.{s}" for j in range(int(cfg.mm_projector_type[3:-6])) for s in ("weight", "bias")]
     proj_w = {k: fetch(k).requires_grad_(bool(backward and head_grads)) for k in proj_names}
     proj = RM.mm_projector(proj_w, cfg, feat)
-    emb = {"model.embed_tokens.weight": fetch("model.embed_tokens.weight")}
+    emb = {"model.embed_tokens.weight": fetch("model.embed_tokens.weight").requires_grad_(bool(backward and embed_grad))}
     x, lab, key_valid, img_pos, target, _ = RM.splice(emb, cfg, input_ids, labels, attention_mask, proj, feat.detach().clone())
-    del emb
+    if not (backward and embed_grad):
+        del emb
     B, L, h = x.shape
     n_rows = [int(key_valid[b].sum()) for b in range(B)]
     for b in range(B):
@@ -151,9 +153,12 @@ def full_depth(fetch, cfg: RM.OracleConfig, input_ids, attention_mask, labels, i
     for b in range(B):
         dx0[b, :n_rows[b]] = dx[b]
     out["d_inputs_embeds"] = dx0
-    if head_grads and x.requires_grad:
+    if (head_grads or embed_grad) and x.requires_grad:
         x.backward(dx0)
-        for k, v in proj_w.items():
-            out["grads"][k] = v.grad
+        if head_grads:
+            for k, v in proj_w.items():
+                out["grads"][k] = v.grad
+        if embed_grad:                                           # dense [V, h], as torch's embedding backward produces it
+            out["grads"]["model.embed_tokens.weight"] = emb["model.embed_tokens.weight"].grad
     secs["total"] = time.time() - t_all
     return out

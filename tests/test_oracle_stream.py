@@ -33,10 +33,10 @@ def test_streamed_oracle_equals_plain_oracle():
     sd = init_state_dict(cfg, seed=3)
     ids, msk, lab, images = _batch()
     for k, v in sd.items():
-        v.requires_grad_("vision_tower" not in k and "vision_proj" not in k and "embed_tokens" not in k)
+        v.requires_grad_("vision_tower" not in k and "vision_proj" not in k)
     ref = oracle_forward(sd, cfg, ids, msk, lab, images, return_logits=False)
     ref["loss"].backward()
-    got = full_depth(lambda k: sd[k].detach().clone(), cfg, ids, msk, lab, images, probe_layers=(1, 4), grad_layers=(0, 3))
+    got = full_depth(lambda k: sd[k].detach().clone(), cfg, ids, msk, lab, images, probe_layers=(1, 4), grad_layers=(0, 3), embed_grad=True)
     assert torch.equal(got["labels"], ref["labels"]) and torch.equal(got["image_positions"], ref["image_positions"])
     assert abs(got["loss"] - float(ref["loss"].detach())) <= 2e-6 * abs(got["loss"])
     assert abs(got["loss_language"] - ref["loss_language"]) <= 2e-6 * abs(ref["loss_language"])
@@ -51,7 +51,7 @@ def test_streamed_oracle_equals_plain_oracle():
         assert r is not None, k
         assert float((g - r).norm() / r.norm().clamp_min(1e-20)) < 2e-4, k
         n += 1
-    assert n == 2 * 9 + 2 + 4 + 4                                # two layers, norm + lm_head, vision_head, mm_projector
+    assert n == 2 * 9 + 2 + 4 + 4 + 1                            # two layers, norm + lm_head, vision_head, mm_projector, embed_tokens
     # layers outside grad_layers carry no gradient; forward-only mode returns none at all
     assert not any(k.startswith("model.layers.1.") for k in got["grads"])
     fwd = full_depth(lambda k: sd[k].detach().clone(), cfg, ids, msk, lab, images, backward=False)
