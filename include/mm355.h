@@ -65,6 +65,15 @@ int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64
                     uint32_t flags, int variant, void* stream);
 int mm355_gemm_num_variants(void);
 
+/* Fused gate|up projection + SwiGLU of the LLaMA MLP (reference: HF LlamaMLP `down_proj(act_fn(gate_proj(x)) * up_proj(x))`, reached at
+ * metamorph_llama.py:349-359):  gu[M][2 I] = X[M][K] . Wgu[2 I][K]^T  (gate columns 0..I-1, up columns I..2I-1, exactly what
+ * mm355_gemm_bf16 writes) AND act[M][I] = bf16(silu(gate)) * up from the bf16-rounded gu values (exactly what mm355_swiglu_fwd writes), in
+ * ONE launch: a workgroup's 256 tile columns are 128 gate channels and the same 128 up channels, so the product is formed in the epilogue
+ * registers and the separate read of gu disappears.  Requirements: I % 128 == 0, K % 128 == 0, leading dimensions % 8 == 0;
+ * MM355_EUNSUPPORTED otherwise (callers fall back to mm355_gemm_bf16 + mm355_swiglu_fwd: same bits). */
+int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* gu, int64_t ld_gu,
+                           mm355_bf16* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, void* stream);
+
 /* Two independent problems of the form above, C0 (+)= A0 . B0^T and C1 (+)= A1 . B1^T, in ONE launch of the 256x256 ping-pong
  * kernel.  A launch runs in waves of 256 workgroups (one tile per CU): the LLaMA-3-8B weight gradients of qkv (384 tiles) and
  * down_proj (896 tiles) cost 2 + 4 wave times launched separately and 5 as a pair.  The host side pairs them at the end of

@@ -149,6 +149,52 @@ MM_DEV void gemm_epilogue(f32x4 (&acc)[FM][FN], const GemmArgs& a, unsigned char
     }
 }
 
+// Epilogue of the fused gate|up GEMM (mm355_gemm_swiglu_bf16): a wave's 64 tile columns are 32 gate channels followed by the SAME 32
+// up channels (the B tile is staged from two row ranges of the fused weight, see gemm_pp_tile<.., SWI>), so after the staging slab a
+// lane finds gate and up of a channel 32 floats apart in its row: gu goes out as two 64-B runs per wave row (gate block at column ch,
+// up block at column I + ch) and act = bf(silu(bf(g))) * bf(u) -- the arithmetic of swiglu_fwd_kernel on the bf16-rounded values, bit
+// for bit -- as one 16-B store per lane.  a.C = gu [M][ldc], a.res = act [M][ldr], a.res_mod = I.
+MM_DEV void gemm_epilogue_swiglu(f32x4 (&acc)[8][4], const GemmArgs& a, unsigned char* smem, int m0, int tn, int wm, int wn, int wave, int lane) {
+    constexpr int TN = 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, I = (int)a.res_mod;
+    float* stg = (float*)smem + wave * (16 * TN);
+    const int row_l = lane >> 2, k4 = lane & 3;
+    uint16_t* gu = (uint16_t*)a.C;
+    uint16_t* act = (uint16_t*)a.res;
+    const int ch0 = tn * 128 + wn * 32;                       // first channel of this wave
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int grow = m0 + wm * 128 + i * 16 + row_l;
+        if (grow < M) {
+            // this lane: channels ch0 + k4*8 .. +7 -- gate from slab columns k4*8, up from 32 + k4*8
+            float g[8], u[8], o[8];
+            const f32x4 g0 = *(const f32x4*)(stg + row_l * TN + k4 * 8), g1 = *(const f32x4*)(stg + row_l * TN + k4 * 8 + 4);
+            const f32x4 u0 = *(const f32x4*)(stg + row_l * TN + 32 + k4 * 8), u1 = *(const f32x4*)(stg + row_l * TN + 32 + k4 * 8 + 4);
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            u[0] = u0.x; u[1] = u0.y; u[2] = u0.z; u[3] = u0.w; u[4] = u1.x; u[5] = u1.y; u[6] = u1.z; u[7] = u1.w;
+            const u32x4 gp = pack8(g), up = pack8(u);
+            const int ch = ch0 + k4 * 8;
+            *(u32x4*)(gu + (int64_t)grow * a.ldc + ch) = gp;
+            *(u32x4*)(gu + (int64_t)grow * a.ldc + I + ch) = up;
+            float gb[8], ub[8];
+            unpack8(gp, gb);
+            unpack8(up, ub);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = round_bf(gb[e] / (1.0f + __expf(-gb[e]))) * ub[e];
+            *(u32x4*)(act + (int64_t)grow * a.ldr + ch) = pack8(o);
+        }
+    }
+}
+
 // TNL = true: both operands are stored contraction-major ("TN": A = At[K][M], B = Bt[K][N], C = At^T Bt), which is the
 // weight-gradient form dW = dY^T X on the activations as they lie in memory -- no transposed copies.  LDS tiles are then
 // [64 k][256] with the MFMA fragments gathered by ds_read_b64_tr_b16 (hardware 4x16 transpose read).
@@ -581,8 +627,9 @@ template <int N> MM_DEV void wait_vmcnt() {
 
 // body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
 // in one grid)
-template <bool TA, bool TB, int ABL = 0>
+template <bool TA, bool TB, int ABL = 0, bool SWI = false>
 MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
+    static_assert(!SWI || (!TA && !TB), "fused SwiGLU epilogue: row-major operands");
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
     constexpr int A_BYTES = BM * 128;
@@ -638,7 +685,14 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             } else if (!TB) {                                // [256 n][64 k] image
                 const int rin = lane >> 3, c = (lane & 7) ^ rin;
                 const int row = (q >> 2) * 64 + blk * 32 + (q & 3) * 8;
-                src[kd][h] = (uint32_t)((int64_t)(min(n0 + row + rin, N - 1) - n0) * a.ldb * 2 + c * 16);   // from row n0
+                if constexpr (SWI) {
+                    // tile column block (wave column q >> 2, half blk) = channels tn*128 + (q >> 2)*32 + .. of the gate (blk 0) or
+                    // the up (blk 1) rows of the fused [2 I][K] weight; offsets from row 0 of the weight (host: 2 I ldb 2 < 2 GiB)
+                    const int wrow = blk * (int)a.res_mod + tn * 128 + (q >> 2) * 32 + (q & 3) * 8 + rin;
+                    src[kd][h] = (uint32_t)((int64_t)wrow * a.ldb * 2 + c * 16);
+                } else {
+                    src[kd][h] = (uint32_t)((int64_t)(min(n0 + row + rin, N - 1) - n0) * a.ldb * 2 + c * 16);   // from row n0
+                }
                 dst[kd][h] = A_BYTES + row * 128;
             } else {                                         // eight [64 k][32 n] images (64-B rows), piece = 16 k rows
                 const int krow = (q & 3) * 16 + (lane >> 2);
@@ -653,7 +707,7 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     // offsets only span 256 rows + the K extent and the operand itself may be of any size; contraction-major operands are
     // based at the matrix (their offsets run over K rows: pp_eligible keeps those below 2 GiB).
     const uint16_t* baseA = TA ? a.A : a.A + (int64_t)m0 * a.lda;
-    const uint16_t* baseB = TB ? a.B : a.B + (int64_t)n0 * a.ldb;
+    const uint16_t* baseB = (TB || SWI) ? a.B : a.B + (int64_t)n0 * a.ldb;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, 0x7fffffff, 0x00020000);
     const int kstepA = TA ? (int)(a.lda * 128) : 128, kstepB = TB ? (int)(a.ldb * 128) : 128;   // bytes per K tile
@@ -792,7 +846,13 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     phase(I3{}, I0{}, F{}, F{}, t + 1, 0);
     if (wm == 0) __builtin_amdgcn_s_barrier();               // the first group catches the barrier count up
     __syncthreads();
-    gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+    if constexpr (SWI) gemm_epilogue_swiglu(acc, a, smem, m0, tn, wm, wn, wave, lane);
+    else gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
+}
+
+__global__ __launch_bounds__(512) void gemm_pp_swiglu_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_pp_tile<false, false, 0, true>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,6 +1329,27 @@ extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t
     if (!in || !out || rows <= 0 || cols <= 0 || (ld_in & 7) || !mm_aligned16(in) || !mm_aligned16(out)) return MM355_EINVAL;
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (int)rows, (int)cols, out, ld_out);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* gu, int64_t ld_gu,
+                                      mm355_bf16* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wgu || !gu || !act || M <= 0 || I <= 0 || K <= 0) return MM355_EINVAL;
+    if ((ldx & 7) || (ldw & 7) || (ld_gu & 7) || (ld_act & 7) || !mm_aligned16(X) || !mm_aligned16(Wgu) || !mm_aligned16(gu) || !mm_aligned16(act))
+        return MM355_EINVAL;
+    if (M > 0x7fffffff || I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    // whole 128-channel tiles, whole pairs of K tiles, 31-bit weight offsets (2 I rows from the weight's first row)
+    if ((I & 127) || K < 128 || (K & 127) || (2 * I * ldw + K) * 2 >= 0x7fffffffLL || (256 * ldx + K) * 2 >= 0x7fffffffLL) return MM355_EUNSUPPORTED;
+    GemmArgs a;
+    a.A = X; a.B = Wgu; a.C = gu; a.bias = nullptr; a.res = act;
+    a.lda = ldx; a.ldb = ldw; a.ldc = ld_gu; a.ldr = ld_act; a.res_mod = I;
+    a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.flags = 0; a.ntm = a.ntn = 0;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_swiglu_kernel, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    const int64_t total = pp_prepare(a);
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_pp_swiglu_kernel, dim3((unsigned)total), dim3(512), PP_LDS, (hipStream_t)stream, a);
     return mm_launch_status();
 }
 

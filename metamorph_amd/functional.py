@@ -27,6 +27,8 @@ _DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
 # MM355_NORM_T=0: recompute the RMSNorm outputs in the backward pass and transpose them (two passes each) instead of rebuilding them
 # contraction-major from the saved rstd in one (rmsnorm_apply_t); A/B switch.
 _NORM_T = os.environ.get("MM355_NORM_T", "1") != "0"
+# MM355_FUSE_SWIGLU=0: gate|up GEMM and SwiGLU as two launches (A/B switch; the fused launch writes the same bits)
+_FUSE_SWIGLU = os.environ.get("MM355_FUSE_SWIGLU", "1") != "0"
 _CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
 
 
@@ -263,9 +265,13 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
     n2, rstd2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps, want_rstd=True)
-    gu = ops.gemm(n2, wgu)
-    del n2
-    act = ops.swiglu_fwd(gu, m.I)
+    if _FUSE_SWIGLU and ops.gemm_swiglu_supported(n2, wgu, m.I):
+        gu, act = ops.gemm_swiglu(n2, wgu, m.I)                # SiLU(gate) * up formed in the GEMM epilogue: same bits, one pass less
+        del n2
+    else:
+        gu = ops.gemm(n2, wgu)
+        del n2
+        act = ops.swiglu_fwd(gu, m.I)
     y = ops.gemm(act, mlp.down_proj.weight, residual=x2)
     # rstd1 / rstd2 (fp32 [M] each): the backward pass rebuilds the TRANSPOSED norm outputs from them in one pass (rmsnorm_apply_t)
     return y, (qkv, o, lse, x2, gu, rstd1, rstd2)

@@ -391,6 +391,27 @@ def cast_f32_to_bf16_2d(src_f32, dst2d):
 
 # ------------------------------------------------------------------------------------------------ elementwise
 
+def gemm_swiglu_supported(x, wgu, I):
+    """mm355_gemm_swiglu_bf16 takes this problem (whole 128-channel tiles and K-tile pairs, a launch of at least one wave of
+    256 x 256 tiles -- smaller problems go through mm355_gemm_bf16's small-tile kernels + mm355_swiglu_fwd)."""
+    M, K = x.shape
+    tiles = ((M + 255) // 256) * ((2 * I + 255) // 256)
+    return (I % 128 == 0 and K >= 128 and K % 128 == 0 and wgu.shape[0] == 2 * I and wgu.is_contiguous() and x.is_contiguous()
+            and tiles >= 200 and (2 * I * K + K) * 2 < 0x7fffffff)
+
+
+def gemm_swiglu(x, wgu, I):
+    """(gu [M, 2I], act [M, I]) = fused gate|up GEMM + SwiGLU: the bits of gemm(x, wgu) and swiglu_fwd(gu, I) in one launch."""
+    _chk_dev(x, wgu)
+    M, K = x.shape
+    assert x.dtype == BF16 and wgu.dtype == BF16 and wgu.shape == (2 * I, K)
+    gu = torch.empty((M, 2 * I), device=x.device, dtype=BF16)
+    act = torch.empty((M, I), device=x.device, dtype=BF16)
+    _lib.check(_L().mm355_gemm_swiglu_bf16(x.data_ptr(), K, wgu.data_ptr(), K, gu.data_ptr(), 2 * I, act.data_ptr(), I, M, I, K, _stream()),
+               f"mm355_gemm_swiglu_bf16 M={M} I={I} K={K}")
+    return gu, act
+
+
 def swiglu_fwd(gu, I):
     _chk_dev(gu)
     assert gu.is_contiguous() and gu.shape[-1] == 2 * I

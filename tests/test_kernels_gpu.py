@@ -528,6 +528,29 @@ def test_attn3_full_length_against_oracle_slice(ops, L, Hq):
         close(gv, v.grad[0, 0], what=f"attn3 dv L={L} sample {b} group {g}", **tol)
 
 
+def test_gemm_swiglu_fused_equals_two_launches(ops):
+    """mm355_gemm_swiglu_bf16 (gate|up GEMM with SiLU(gate) * up formed in the epilogue; the B tile staged from two row ranges of the fused
+    weight) writes bit for bit what mm355_gemm_bf16 + mm355_swiglu_fwd write: LLaMA-3-8B widths at 4096 rows, a ragged row count, and
+    TinyLlama's I = 5632 (44 tiles of 128 channels); unsupported shapes are refused, not approximated."""
+    for (M, K, I) in [(4096, 4096, 14336), (2304 + 77, 2048, 5632), (6000, 1024, 4608)]:
+        x = rnd(M, K, seed=M, scale=0.5).to(DEV)
+        w = rnd(2 * I, K, seed=I, scale=0.05).to(DEV)
+        assert ops.gemm_swiglu_supported(x, w, I), (M, K, I)
+        gu_ref = ops.gemm(x, w)
+        act_ref = ops.swiglu_fwd(gu_ref, I)
+        gu, act = ops.gemm_swiglu(x, w, I)
+        assert torch.equal(gu, gu_ref), (M, K, I, float((gu.float() - gu_ref.float()).abs().max()))
+        assert torch.equal(act, act_ref), (M, K, I)
+        # and against the oracle arithmetic (bf16 tolerances of the GEMM test)
+        ref = x.float().cpu() @ w.float().cpu().t()
+        close(gu[:, :64], ref[:, :64], 2e-2, 2e-2, "fused gu gate block")
+        close(gu[:, I:I + 64], ref[:, I:I + 64], 2e-2, 2e-2, "fused gu up block")
+    x = rnd(512, 256, seed=1).to(DEV)
+    assert not ops.gemm_swiglu_supported(x, rnd(2 * 192, 256, seed=2).to(DEV), 192)          # I % 128 != 0
+    with pytest.raises(Exception):
+        ops.gemm_swiglu(x, rnd(2 * 192, 256, seed=2).to(DEV), 192)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 
 def test_swiglu_gelu(ops):
