@@ -135,6 +135,32 @@ class GemmTimer:
                                  2.0 * (m0 * k0 + n0 * k0 + m0 * n0 + m1 * k1 + n1 * k1 + m1 * n1)))
             return r
         self.ops.gemm_pair = timed_pair
+        # the fused MLP launches are GEMMs too (gate|up + SwiGLU; down_proj input gradient + SwiGLU backward): their flops over their WHOLE
+        # duration, fused epilogue included
+        orig_sw, orig_swb = self.ops.gemm_swiglu, self.ops.gemm_swiglu_bwd
+
+        def timed_sw(x, wgu, I):
+            if not self.enabled:
+                return orig_sw(x, wgu, I)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_sw(x, wgu, I)
+            e.record()
+            M, K = x.shape
+            self.records.append((s, e, 2.0 * M * 2 * I * K, ("swiglu", M, 2 * I, K), 2.0 * (M * K + 2 * I * K + M * 2 * I)))
+            return r
+
+        def timed_swb(dy, wdT, gu, I):
+            if not self.enabled:
+                return orig_swb(dy, wdT, gu, I)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_swb(dy, wdT, gu, I)
+            e.record()
+            M, K = dy.shape
+            self.records.append((s, e, 2.0 * M * I * K, ("swiglu_bwd", M, I, K), 2.0 * (M * K + I * K + M * I)))
+            return r
+        self.ops.gemm_swiglu, self.ops.gemm_swiglu_bwd = timed_sw, timed_swb
 
     def summary(self):
         torch.cuda.synchronize()
@@ -453,7 +479,7 @@ def main():
                 if k["kernel"].startswith("gemm_pp_kernel<false, false>"):
                     traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + tname
         alg_bytes = sum(r[4] for r in timer.records) / n_gemm
-        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps)",
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_pp_swiglu*_kernel / gemm_nt_kernel (bf16 MFMA GEMM family, all launches of the timed steps; fused epilogues included in the durations)",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over launches",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),

@@ -74,6 +74,16 @@ int mm355_gemm_num_variants(void);
 int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* gu, int64_t ld_gu,
                            mm355_bf16* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, void* stream);
 
+/* Fused backward of the same MLP stage: d act[M][I] = dY[M][K] . WdT[I][K]^T (the down_proj input gradient; WdT = down_proj.weight
+ * transposed, [I][K]) is formed in the accumulators, rounded to bf16, and fed straight into the SwiGLU backward with gate / up from
+ * gu[M][2 I]:  dgu[M][2 I] (row-major: the operand of the gate|up input-gradient GEMM) AND the contraction-major copies actT[I][ldT],
+ * dguT[2 I][ldT] (the operands of the down_proj / gate|up weight-gradient GEMMs) -- the outputs of mm355_gemm_bf16 + mm355_swiglu_bwd_t,
+ * without d act ever reaching memory.  Requirements: I % 64 == 0, M % 8 == 0, K % 128 == 0, ldT >= M, leading dimensions % 8 == 0;
+ * MM355_EUNSUPPORTED otherwise.  Columns [M, ldT) of actT / dguT are not written (callers zero their padding). */
+int mm355_gemm_swiglu_bwd_bf16(const mm355_bf16* dY, int64_t ldy, const mm355_bf16* WdT, int64_t ldw, const mm355_bf16* gu, int64_t ld_gu,
+                               mm355_bf16* dgu, int64_t ld_dgu, mm355_bf16* actT, mm355_bf16* dguT, int64_t ldT,
+                               int64_t M, int64_t I, int64_t K, void* stream);
+
 /* Two independent problems of the form above, C0 (+)= A0 . B0^T and C1 (+)= A1 . B1^T, in ONE launch of the 256x256 ping-pong
  * kernel.  A launch runs in waves of 256 workgroups (one tile per CU): the LLaMA-3-8B weight gradients of qkv (384 tiles) and
  * down_proj (896 tiles) cost 2 + 4 wave times launched separately and 5 as a pair.  The host side pairs them at the end of

@@ -30,6 +30,9 @@ struct GemmArgs {
     uint32_t flags;
     int ntm, ntn;
     int gm;                                                  // raster group height in tiles (ping-pong kernel)
+    uint16_t* aux0;                                          // fused SwiGLU-backward epilogue: actT [I][ld_aux]
+    uint16_t* aux1;                                          //                                 dguT [2 I][ld_aux]
+    int64_t ld_aux;
 };
 
 // ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
@@ -191,6 +194,115 @@ MM_DEV void gemm_epilogue_swiglu(f32x4 (&acc)[8][4], const GemmArgs& a, unsigned
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = round_bf(gb[e] / (1.0f + __expf(-gb[e]))) * ub[e];
             *(u32x4*)(act + (int64_t)grow * a.ldr + ch) = pack8(o);
+        }
+    }
+}
+
+// Epilogue of the fused down_proj input-gradient GEMM + SwiGLU backward (mm355_gemm_swiglu_bwd_bf16).  The accumulators are
+// d act = dY . Wd of a 256 x 256 (rows x channels) tile; rounded to bf16 they are exactly what mm355_gemm_bf16 would have stored and
+// mm355_swiglu_bwd_t re-read, and the same arithmetic follows: with g / u from gu [M][2 I] (a.res)
+//     a = bf(silu(g)) u,   du = da bf(silu(g)),   dg = da u sigma(g) (1 + g (1 - sigma(g)))
+// go out row-major as dgu [M][2 I] (a.C) AND contraction-major as actT [I][ld_aux] (aux0), dguT [2 I][ld_aux] (aux1) -- what the two
+// weight-gradient GEMMs read -- through a wave-private LDS tile: 32 rows x 64 channels x 3 quantities per flush, 16-B transposed
+// stores (64-B runs per channel and flush, two flushes fill a line).  d act itself never reaches memory.
+// LDS: [0, 32 KiB) the waves' fp32 staging slabs, then 8 x SWB_T bytes of transposition tiles (launch with SWB_LDS).
+constexpr int SWB_TROW = 144;                                // bytes per tile row: 64 channels bf16 + 16 (16-B aligned rows, banks spread)
+constexpr int SWB_T = 3 * 32 * SWB_TROW;                     // 13 824 B per wave
+constexpr int SWB_LDS = 32768 + 8 * SWB_T;                   // 143 360 B (of 160 KiB)
+MM_DEV void gemm_epilogue_swiglu_bwd(f32x4 (&acc)[8][4], const GemmArgs& a, unsigned char* smem, int m0, int n0, int wm, int wn, int wave, int lane) {
+    constexpr int TN = 64, PF = 4;                           // PF: i-blocks of gate / up rows kept in flight ahead of their use
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds4_t;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, I = a.N;
+    float* stg = (float*)smem + wave * (16 * TN);
+    unsigned char* tile = smem + 32768 + wave * SWB_T;       // [3 quantities][32 rows][SWB_TROW]
+    const int row_l = lane >> 2, k4 = lane & 3;
+    const uint16_t* gu = a.res;
+    uint16_t* dgu = (uint16_t*)a.C;
+    const int c_wave = n0 + wn * 64;                         // first channel of this wave
+    if (c_wave >= I) return;                                 // (I % 64 == 0: a wave is in or out as a whole)
+    const int row0 = m0 + wm * 128 + row_l;                  // this lane's row in i-block 0
+    u32x4 gq[PF][2], uq[PF][2];
+    auto fetch = [&](int i, int slot) {
+        const int grow = row0 + i * 16;
+#pragma unroll
+        for (int j8 = 0; j8 < 2; ++j8) {
+            const int64_t ro = (int64_t)min(grow, M - 1) * a.ldr + c_wave + k4 * 16 + j8 * 8;
+            gq[slot][j8] = *(const u32x4*)(gu + ro);
+            uq[slot][j8] = *(const u32x4*)(gu + ro + I);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(i, i);
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int i = ib * 2 + half;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int grow = row0 + i * 16;
+            const bool live = grow < M;
+#pragma unroll
+            for (int j8 = 0; j8 < 2; ++j8) {
+                const int c = k4 * 16 + j8 * 8;
+                float daf[8], g[8], u[8], dg[8], du[8], av[8], da[8];
+                const f32x4 s0 = *(const f32x4*)(stg + row_l * TN + c), s1 = *(const f32x4*)(stg + row_l * TN + c + 4);
+                daf[0] = s0.x; daf[1] = s0.y; daf[2] = s0.z; daf[3] = s0.w; daf[4] = s1.x; daf[5] = s1.y; daf[6] = s1.z; daf[7] = s1.w;
+                unpack8(pack8(daf), da);                     // the bf16 d act the unfused path stores and re-reads
+                unpack8(gq[i % PF][j8], g);
+                unpack8(uq[i % PF][j8], u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sg = 1.0f / (1.0f + __expf(-g[e]));
+                    const float silu = g[e] * sg;
+                    av[e] = round_bf(silu) * u[e];
+                    du[e] = da[e] * round_bf(silu);
+                    dg[e] = da[e] * u[e] * (sg * (1.0f + g[e] * (1.0f - sg)));
+                }
+                const u32x4 pg = pack8(dg), pu = pack8(du), pa = pack8(av);
+                if (live) {
+                    const int64_t wo = (int64_t)grow * a.ldc + c_wave + c;
+                    *(u32x4*)(dgu + wo) = pg;
+                    *(u32x4*)(dgu + wo + I) = pu;
+                }
+                unsigned char* tp = tile + (half * 16 + row_l) * SWB_TROW + c * 2;
+                *(u32x4*)(tp) = pa;
+                *(u32x4*)(tp + 32 * SWB_TROW) = pg;
+                *(u32x4*)(tp + 64 * SWB_TROW) = pu;
+            }
+            if (i + PF < 8) fetch(i + PF, i % PF);           // this slot's values are consumed: refill it PF blocks ahead
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // flush 32 rows x 64 channels x 3 quantities with ds_read_b64_tr_b16: the 16 lanes of a group supply sixteen 8-byte pieces
+        // P_0 .. P_15 (each four consecutive channels of one tile row) and lane L receives element L % 4 of P_{4k + L / 4}, k = 0 .. 3.
+        // With P_{4k + s} = row 8 s + k of a 4-channel block, lane L = 4 s + j ends up with rows 8 s .. 8 s + 3 (second read: + 4 .. 7) of
+        // channel j: the four lanes j, 4 + j, 8 + j, 12 + j hold the 32 rows of one channel, i.e. one 64-B run of the transposed output.
+        const int r_base = m0 + wm * 128 + ib * 32;
+        const int s_l = fr >> 2, j_l = fr & 3;
+        const unsigned char* tb = tile + (8 * (fr & 3) + (fr >> 2)) * SWB_TROW + fq * 8;   // this lane's PIECE: row 8 (l % 4) + l / 4
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {                 // channel block it*16 + fq*4
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(tb + q * 32 * SWB_TROW + it * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(tb + (q * 32 + 4) * SWB_TROW + it * 32));
+                const int ch = c_wave + it * 16 + fq * 4 + j_l;
+                const int r8 = r_base + 8 * s_l;
+                if (r8 < M) {                                // (M % 8 == 0: a vector is in or out as a whole)
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    uint16_t* outp = (q == 0 ? a.aux0 : a.aux1) + (int64_t)(q == 2 ? I + ch : ch) * a.ld_aux;
+                    *(s16x8*)(outp + r8) = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
         }
     }
 }
@@ -627,9 +739,9 @@ template <int N> MM_DEV void wait_vmcnt() {
 
 // body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
 // in one grid)
-template <bool TA, bool TB, int ABL = 0, bool SWI = false>
+template <bool TA, bool TB, int ABL = 0, bool SWI = false, bool SWB = false>
 MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
-    static_assert(!SWI || (!TA && !TB), "fused SwiGLU epilogue: row-major operands");
+    static_assert(!(SWI || SWB) || (!TA && !TB), "fused SwiGLU epilogues: row-major operands");
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
     constexpr int A_BYTES = BM * 128;
@@ -847,12 +959,18 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     if (wm == 0) __builtin_amdgcn_s_barrier();               // the first group catches the barrier count up
     __syncthreads();
     if constexpr (SWI) gemm_epilogue_swiglu(acc, a, smem, m0, tn, wm, wn, wave, lane);
+    else if constexpr (SWB) gemm_epilogue_swiglu_bwd(acc, a, smem, m0, n0, wm, wn, wave, lane);
     else gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
 __global__ __launch_bounds__(512) void gemm_pp_swiglu_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gemm_pp_tile<false, false, 0, true>(a, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(512) void gemm_pp_swiglu_bwd_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_pp_tile<false, false, 0, false, true>(a, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1230,7 +1348,7 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
     if ((flags & MM355_GEMM_BIAS) && (!bias || !mm_aligned16(bias))) return MM355_EINVAL;
     if ((flags & MM355_GEMM_RESIDUAL) && (!residual || !mm_aligned16(residual))) return MM355_EINVAL;
     if ((flags & MM355_GEMM_GELU_ERF) && (flags & MM355_GEMM_GELU_TANH)) return MM355_EINVAL;
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.res = residual;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_row_mod;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
@@ -1299,7 +1417,7 @@ extern "C" int mm355_gemm_tn_bf16(const mm355_bf16* At, int64_t lda, const mm355
     if (K % 64) return MM355_EUNSUPPORTED;                  // contraction rows are DMA'd unmasked: whole 64-row tiles only
     if (flags & ~(MM355_GEMM_ACCUMULATE | MM355_GEMM_OUT_F32)) return MM355_EINVAL;
     if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = At; a.B = Bt; a.C = C; a.bias = nullptr; a.res = nullptr;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = 0; a.res_mod = 0;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
@@ -1315,7 +1433,7 @@ extern "C" int mm355_gemm_nn_bf16(const mm355_bf16* A, int64_t lda, const mm355_
     if (flags & ~(MM355_GEMM_ACCUMULATE | MM355_GEMM_OUT_F32 | MM355_GEMM_RESIDUAL)) return MM355_EINVAL;
     if ((flags & MM355_GEMM_RESIDUAL) && (!residual || !mm_aligned16(residual) || (ldr & 7))) return MM355_EINVAL;
     if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = A; a.B = Bt; a.C = C; a.bias = nullptr; a.res = residual;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = 0;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags; a.ntm = a.ntn = 0;
@@ -1341,7 +1459,7 @@ extern "C" int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm
     if (M > 0x7fffffff || I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;
     // whole 128-channel tiles, whole pairs of K tiles, 31-bit weight offsets (2 I rows from the weight's first row)
     if ((I & 127) || K < 128 || (K & 127) || (2 * I * ldw + K) * 2 >= 0x7fffffffLL || (256 * ldx + K) * 2 >= 0x7fffffffLL) return MM355_EUNSUPPORTED;
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = X; a.B = Wgu; a.C = gu; a.bias = nullptr; a.res = act;
     a.lda = ldx; a.ldb = ldw; a.ldc = ld_gu; a.ldr = ld_act; a.res_mod = I;
     a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.flags = 0; a.ntm = a.ntn = 0;
@@ -1350,6 +1468,30 @@ extern "C" int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm
     const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL(gemm_pp_swiglu_kernel, dim3((unsigned)total), dim3(512), PP_LDS, (hipStream_t)stream, a);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_gemm_swiglu_bwd_bf16(const mm355_bf16* dY, int64_t ldy, const mm355_bf16* WdT, int64_t ldw, const mm355_bf16* gu, int64_t ld_gu,
+                                          mm355_bf16* dgu, int64_t ld_dgu, mm355_bf16* actT, mm355_bf16* dguT, int64_t ldT,
+                                          int64_t M, int64_t I, int64_t K, void* stream) {
+    (void)hipGetLastError();
+    if (!dY || !WdT || !gu || !dgu || !actT || !dguT || M <= 0 || I <= 0 || K <= 0) return MM355_EINVAL;
+    if ((ldy & 7) || (ldw & 7) || (ld_gu & 7) || (ld_dgu & 7) || (ldT & 7) || ldT < M || !mm_aligned16(dY) || !mm_aligned16(WdT) || !mm_aligned16(gu)
+        || !mm_aligned16(dgu) || !mm_aligned16(actT) || !mm_aligned16(dguT))
+        return MM355_EINVAL;
+    if (M > 0x7fffffff || I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    // whole 64-channel wave columns, 8-row vectors, whole pairs of K tiles, 31-bit tile-relative operand offsets
+    if ((I & 63) || (M & 7) || K < 128 || (K & 127) || (256 * ldy + K) * 2 >= 0x7fffffffLL || (256 * ldw + K) * 2 >= 0x7fffffffLL) return MM355_EUNSUPPORTED;
+    GemmArgs a = {};
+    a.A = dY; a.B = WdT; a.C = dgu; a.bias = nullptr; a.res = gu;
+    a.lda = ldy; a.ldb = ldw; a.ldc = ld_dgu; a.ldr = ld_gu; a.res_mod = 0;
+    a.M = (int)M; a.N = (int)I; a.K = (int)K; a.flags = 0; a.ntm = a.ntn = 0;
+    a.aux0 = actT; a.aux1 = dguT; a.ld_aux = ldT;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_swiglu_bwd_kernel, SWB_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    const int64_t total = pp_prepare(a);
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_pp_swiglu_bwd_kernel, dim3((unsigned)total), dim3(512), SWB_LDS, (hipStream_t)stream, a);
     return mm_launch_status();
 }
 

@@ -29,6 +29,8 @@ _DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
 _NORM_T = os.environ.get("MM355_NORM_T", "1") != "0"
 # MM355_FUSE_SWIGLU=0: gate|up GEMM and SwiGLU as two launches (A/B switch; the fused launch writes the same bits)
 _FUSE_SWIGLU = os.environ.get("MM355_FUSE_SWIGLU", "1") != "0"
+# MM355_FUSE_SWIGLU_BWD=0: down_proj input-gradient GEMM and SwiGLU backward as two launches (A/B switch; same bits)
+_FUSE_SWIGLU_BWD = os.environ.get("MM355_FUSE_SWIGLU_BWD", "1") != "0"
 _CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
 
 
@@ -315,18 +317,29 @@ class DecoderLayerFn(Function):
         dev = x.device
 
         # ---- MLP ----
-        dact = input_grad_gemm(dy, mlp.down_proj.weight)                       # [M, I]
         gu_params = [mlp.gate_proj.weight, mlp.up_proj.weight]
         # full fine-tune on whole 64-row tiles: SwiGLU backward writes act^T and dgu^T itself (no transpose passes over them)
-        fused_t = (not _DW_TN and dact.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
+        fused_t = (not _DW_TN and dy.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
                    and all(p.requires_grad for p in gu_params))
-        if fused_t:
-            dgu, actT, dguT = ops.swiglu_bwd_t(gu, dact, m.I)
+        wdT = None
+        if fused_t and _FUSE_SWIGLU_BWD:
+            wdT = transpose_padded(mlp.down_proj.weight)
+            if not ops.gemm_swiglu_bwd_supported(dy, wdT, gu, m.I):
+                wdT = None
+        if wdT is not None:
+            # d act = dy Wd formed, rounded and consumed in the GEMM's epilogue: same bits as the two launches, no d act round trip
+            dgu, actT, dguT = ops.gemm_swiglu_bwd(dy, wdT, gu, m.I)
             act = None
+            del wdT
         else:
-            dgu, act = ops.swiglu_bwd(gu, dact, m.I, want_act=mlp.down_proj.weight.requires_grad)
-            actT = dguT = None
-        del dact
+            dact = input_grad_gemm(dy, mlp.down_proj.weight)                   # [M, I]
+            if fused_t:
+                dgu, actT, dguT = ops.swiglu_bwd_t(gu, dact, m.I)
+                act = None
+            else:
+                dgu, act = ops.swiglu_bwd(gu, dact, m.I, want_act=mlp.down_proj.weight.requires_grad)
+                actT = dguT = None
+            del dact
         qkv_params = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
         held = None                      # down_proj's weight-gradient problem, kept back to share a launch with qkv's
         if mlp.down_proj.weight.requires_grad:

@@ -412,6 +412,29 @@ def gemm_swiglu(x, wgu, I):
     return gu, act
 
 
+def gemm_swiglu_bwd_supported(dy, wdT, gu, I):
+    """mm355_gemm_swiglu_bwd_bf16 takes this problem (and it is big enough for the 256 x 256 ping-pong tiles)."""
+    M, K = dy.shape
+    tiles = ((M + 255) // 256) * ((I + 255) // 256)
+    return (I % 64 == 0 and M % 64 == 0 and K >= 128 and K % 128 == 0 and wdT.shape[0] == I and wdT.shape[1] == K and wdT.is_contiguous()
+            and dy.is_contiguous() and gu.is_contiguous() and gu.shape == (M, 2 * I) and tiles >= 200)
+
+
+def gemm_swiglu_bwd(dy, wdT, gu, I):
+    """(dgu [M, 2I], actT [I, M], dguT [2I, M]) = SwiGLU backward of d act = dy @ wdT^T, fused into that GEMM's epilogue: the bits of
+    gemm(dy, wdT) followed by swiglu_bwd_t(gu, d act, I), without the d act round trip through HBM."""
+    _chk_dev(dy, wdT, gu)
+    M, K = dy.shape
+    assert dy.dtype == BF16 and wdT.dtype == BF16 and gu.dtype == BF16
+    dgu = torch.empty_like(gu)
+    actT = torch.empty((I, M), device=gu.device, dtype=BF16)
+    dguT = torch.empty((2 * I, M), device=gu.device, dtype=BF16)
+    _lib.check(_L().mm355_gemm_swiglu_bwd_bf16(dy.data_ptr(), K, wdT.data_ptr(), K, gu.data_ptr(), 2 * I, dgu.data_ptr(), 2 * I,
+                                               actT.data_ptr(), dguT.data_ptr(), M, M, I, K, _stream()),
+               f"mm355_gemm_swiglu_bwd_bf16 M={M} I={I} K={K}")
+    return dgu, actT, dguT
+
+
 def swiglu_fwd(gu, I):
     _chk_dev(gu)
     assert gu.is_contiguous() and gu.shape[-1] == 2 * I

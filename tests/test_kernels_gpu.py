@@ -551,6 +551,30 @@ def test_gemm_swiglu_fused_equals_two_launches(ops):
         ops.gemm_swiglu(x, rnd(2 * 192, 256, seed=2).to(DEV), 192)
 
 
+def test_gemm_swiglu_bwd_fused_equals_two_launches(ops):
+    """mm355_gemm_swiglu_bwd_bf16 (down_proj input-gradient GEMM with the SwiGLU backward in its epilogue: d act never reaches memory) against
+    mm355_gemm_bf16 + mm355_swiglu_bwd_t on the same operands: dgu, actT and dguT bit for bit (the epilogue rounds d act to bf16 and uses
+    the same expressions), LLaMA-3-8B widths at 4096 rows and TinyLlama's I = 5632 with a row count that is not a multiple of 256."""
+    for (M, K, I) in [(4096, 4096, 14336), (2304 + 64, 2048, 5632)]:
+        dy = rnd(M, K, seed=M + 1, scale=0.5).to(DEV)
+        wdT = rnd(I, K, seed=I + 1, scale=0.05).to(DEV)
+        gu = rnd(M, 2 * I, seed=7, scale=1.5).to(DEV)
+        assert ops.gemm_swiglu_bwd_supported(dy, wdT, gu, I), (M, K, I)
+        dact = ops.gemm(dy, wdT)
+        dgu_ref, actT_ref, dguT_ref = ops.swiglu_bwd_t(gu, dact, I)
+        dgu, actT, dguT = ops.gemm_swiglu_bwd(dy, wdT, gu, I)
+        for name, got, ref in (("dgu", dgu, dgu_ref), ("actT", actT, actT_ref), ("dguT", dguT, dguT_ref)):
+            same = torch.equal(got, ref)
+            if not same:                                         # fp contraction may differ between the two kernels: <= 1 bf16 ulp, rare
+                d = (got.float() - ref.float()).abs()
+                frac = float((d > 0).float().mean())
+                assert frac < 1e-3 and float((d / ref.float().abs().clamp_min(1e-6)).max()) <= 2.0 ** -7, (name, M, K, I, frac)
+        assert torch.equal(dguT[:I], dgu[:, :I].t()) and torch.equal(dguT[I:], dgu[:, I:].t())     # the transposed copies ARE transposes
+        act = ops.swiglu_fwd(gu, I)
+        assert torch.equal(actT, act.t())
+    assert not ops.gemm_swiglu_bwd_supported(rnd(512, 256, seed=1).to(DEV), rnd(192, 256, seed=2).to(DEV), rnd(512, 384, seed=3).to(DEV), 192)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 
 def test_swiglu_gelu(ops):
