@@ -421,7 +421,7 @@ def gemm_swiglu_bwd_supported(dy, wdT, gu, I):
 
 
 def gemm_swiglu_bwd(dy, wdT, gu, I):
-    """(dgu [M, 2I], actT [I, M], dguT [2I, M]) = SwiGLU backward of d act = dy @ wdT^T, fused into that GEMM's epilogue: the bits of
+    """(dgu [M, 2I], actT [I, M], dguT [2I, M]) = SwiGLU backward of d act = dy . wdT^T, fused into that GEMM's epilogue: the bits of
     gemm(dy, wdT) followed by swiglu_bwd_t(gu, d act, I), without the d act round trip through HBM."""
     _chk_dev(dy, wdT, gu)
     M, K = dy.shape

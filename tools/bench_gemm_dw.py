@@ -13,7 +13,7 @@ def t(fn, it=6):
         s.record(); fn(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     return statistics.median(ts)
 
-T = 16384
+T = int(os.environ.get("TOKENS", 16384))
 for name, n_out, k_in in [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)]:
     dy = (torch.randn(T, n_out, device="cuda") * 0.5).bfloat16()
     x = (torch.randn(T, k_in, device="cuda") * 0.5).bfloat16()
