@@ -161,6 +161,20 @@ class GemmTimer:
             self.records.append((s, e, 2.0 * M * I * K, ("swiglu_bwd", M, I, K), 2.0 * (M * K + I * K + M * I)))
             return r
         self.ops.gemm_swiglu, self.ops.gemm_swiglu_bwd = timed_sw, timed_swb
+        orig_rope = self.ops.gemm_rope                       # q|k|v GEMM with the RoPE rotation in its epilogue: a plain GEMM launch (+ 1 %)
+
+        def timed_rope(x, wqkv, *a, **kw):
+            if not self.enabled:
+                return orig_rope(x, wqkv, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_rope(x, wqkv, *a, **kw)
+            e.record()
+            M, K = x.shape
+            N = wqkv.shape[0]
+            self.records.append((s, e, 2.0 * M * N * K, (M, N, K), 2.0 * (M * K + N * K + M * N)))
+            return r
+        self.ops.gemm_rope = timed_rope
 
     def fused_summary(self):
         """(launches, seconds, GEMM flops) of the fused MLP launches (gate|up + SwiGLU; down_proj input gradient + SwiGLU backward)."""
@@ -489,7 +503,7 @@ def main():
                 if k["kernel"].startswith("gemm_pp_kernel<false, false"):
                     traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + tname
         alg_bytes = bytes_gemm / n_gemm
-        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (+ its two-problem form gemm_pp_pair_kernel and the small-tile gemm_nt_kernel): the plain bf16 MFMA GEMM launches "
+        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (+ its two-problem form gemm_pp_pair_kernel, gemm_pp_rope_kernel = the same body with the RoPE rotation in the q|k|v epilogue, and the small-tile gemm_nt_kernel): the plain bf16 MFMA GEMM launches "
                                                "of the timed steps -- the dominant kernel; the two fused MLP launches are listed under roofline_fused_mlp",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over launches",

@@ -74,6 +74,16 @@ int mm355_gemm_num_variants(void);
 int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* gu, int64_t ld_gu,
                            mm355_bf16* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, void* stream);
 
+/* Fused q|k|v projection + RoPE (reference: HF LlamaAttention q_proj / k_proj / v_proj + apply_rotary_pos_emb, reached at
+ * metamorph_llama.py:349-359), head size 128:  qkv[M][N] = X[M][K] . Wqkv[N][K]^T with the rotate-half rotation of mm355_rope_qk applied
+ * in the epilogue to the columns below n_rot (= (Hq + Hkv) * 128: the q and k blocks; the v block is stored unrotated) -- the bits of
+ * mm355_gemm_bf16 followed by mm355_rope_qk[_pos], without the in-place pass over q and k.  Row r is position r % L (+ pos_offset[r / L]
+ * when pos_offset != NULL) of the cos / sin tables ([positions][128] bf16 from mm355_rope_table).  Requirements: N % 256 == 0,
+ * n_rot % 128 == 0, K % 128 == 0, leading dimensions % 8 == 0; MM355_EUNSUPPORTED otherwise. */
+int mm355_gemm_rope_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                         const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset,
+                         int64_t M, int64_t N, int64_t K, int64_t L, int64_t n_rot, void* stream);
+
 /* Fused backward of the same MLP stage: d act[M][I] = dY[M][K] . WdT[I][K]^T (the down_proj input gradient; WdT = down_proj.weight
  * transposed, [I][K]) is formed in the accumulators, rounded to bf16, and fed straight into the SwiGLU backward with gate / up from
  * gu[M][2 I]:  dgu[M][2 I] (row-major: the operand of the gate|up input-gradient GEMM) AND the contraction-major copies actT[I][ldT],

@@ -307,6 +307,63 @@ MM_DEV void gemm_epilogue_swiglu_bwd(f32x4 (&acc)[8][4], const GemmArgs& a, unsi
     }
 }
 
+// Epilogue of the fused QKV projection + RoPE (mm355_gemm_rope_bf16, head size 128).  The B tile is staged from permuted weight rows
+// (gemm_pp_tile<.., ROPE>): a wave's 64 tile columns are d = sub*32 .. +31 (first half of a head) followed by d = 64 + sub*32 .. +31 (second
+// half), so the rotation partners x1 = x[d], x2 = x[d + 64] of a row sit 32 floats apart in the wave's staging slab.  Both are rounded to
+// bf16 first (what mm355_gemm_bf16 would have stored) and rotated with the arithmetic of rope_qk_kernel, bit for bit:
+//     y1 = bf(bf(x1 c) + bf(-x2 s)),  y2 = bf(bf(x2 c) + bf(x1 s)),  c / s = cos / sin[position][d]
+// for the columns below a.res_mod (the q and k blocks); the v block is stored as it is.  a.aux0 / a.aux1 = cos / sin tables [*][128] bf16,
+// a.ld_aux = L (rows per sample), a.bias = optional int32 position offsets per sample.
+MM_DEV void gemm_epilogue_rope(f32x4 (&acc)[8][4], const GemmArgs& a, unsigned char* smem, int m0, int n0, int wm, int wn, int wave, int lane) {
+    constexpr int TN = 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int M = a.M, L = (int)a.ld_aux, n_rot = (int)a.res_mod;
+    float* stg = (float*)smem + wave * (16 * TN);
+    const int row_l = lane >> 2, k4 = lane & 3;
+    uint16_t* out = (uint16_t*)a.C;
+    const int32_t* pos_off = (const int32_t*)a.bias;
+    const int d1 = (wn & 1) * 32 + k4 * 8;                    // this lane's eight d of the first half
+    const int col1 = n0 + (wn >> 1) * 128 + d1;               // and their output columns (second half: + 64)
+    const bool rot = col1 < n_rot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int grow = m0 + wm * 128 + i * 16 + row_l;
+        if (grow < M) {
+            float a1[8], a2[8], x1[8], x2[8];
+            const f32x4 p0 = *(const f32x4*)(stg + row_l * TN + k4 * 8), p1 = *(const f32x4*)(stg + row_l * TN + k4 * 8 + 4);
+            const f32x4 q0 = *(const f32x4*)(stg + row_l * TN + 32 + k4 * 8), q1 = *(const f32x4*)(stg + row_l * TN + 32 + k4 * 8 + 4);
+            a1[0] = p0.x; a1[1] = p0.y; a1[2] = p0.z; a1[3] = p0.w; a1[4] = p1.x; a1[5] = p1.y; a1[6] = p1.z; a1[7] = p1.w;
+            a2[0] = q0.x; a2[1] = q0.y; a2[2] = q0.z; a2[3] = q0.w; a2[4] = q1.x; a2[5] = q1.y; a2[6] = q1.z; a2[7] = q1.w;
+            u32x4 w1 = pack8(a1), w2 = pack8(a2);
+            if (rot) {
+                unpack8(w1, x1);
+                unpack8(w2, x2);
+                const int b = grow / L;
+                const int l = grow - b * L + (pos_off ? pos_off[b] : 0);
+                float c[8], sn[8], y1[8], y2[8];
+                unpack8(*(const u32x4*)(a.aux0 + (int64_t)l * 128 + d1), c);
+                unpack8(*(const u32x4*)(a.aux1 + (int64_t)l * 128 + d1), sn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    y1[e] = round_bf(x1[e] * c[e]) + round_bf(-x2[e] * sn[e]);
+                    y2[e] = round_bf(x2[e] * c[e]) + round_bf(x1[e] * sn[e]);
+                }
+                w1 = pack8(y1); w2 = pack8(y2);
+            }
+            *(u32x4*)(out + (int64_t)grow * a.ldc + col1) = w1;
+            *(u32x4*)(out + (int64_t)grow * a.ldc + col1 + 64) = w2;
+        }
+    }
+}
+
 // TNL = true: both operands are stored contraction-major ("TN": A = At[K][M], B = Bt[K][N], C = At^T Bt), which is the
 // weight-gradient form dW = dY^T X on the activations as they lie in memory -- no transposed copies.  LDS tiles are then
 // [64 k][256] with the MFMA fragments gathered by ds_read_b64_tr_b16 (hardware 4x16 transpose read).
@@ -739,9 +796,9 @@ template <int N> MM_DEV void wait_vmcnt() {
 
 // body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
 // in one grid)
-template <bool TA, bool TB, int ABL = 0, bool SWI = false, bool SWB = false>
+template <bool TA, bool TB, int ABL = 0, bool SWI = false, bool SWB = false, bool ROPE = false>
 MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) {
-    static_assert(!(SWI || SWB) || (!TA && !TB), "fused SwiGLU epilogues: row-major operands");
+    static_assert(!(SWI || SWB || ROPE) || (!TA && !TB), "fused epilogues: row-major operands");
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int BUF = (BM + BN) * 128;                    // 64 KiB per K tile
     constexpr int A_BYTES = BM * 128;
@@ -801,6 +858,11 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
                     // tile column block (wave column q >> 2, half blk) = channels tn*128 + (q >> 2)*32 + .. of the gate (blk 0) or
                     // the up (blk 1) rows of the fused [2 I][K] weight; offsets from row 0 of the weight (host: 2 I ldb 2 < 2 GiB)
                     const int wrow = blk * (int)a.res_mod + tn * 128 + (q >> 2) * 32 + (q & 3) * 8 + rin;
+                    src[kd][h] = (uint32_t)((int64_t)wrow * a.ldb * 2 + c * 16);
+                } else if constexpr (ROPE) {
+                    // wave column q >> 2 = (head of the tile, half-of-half sub): its block 0 = weight rows d = sub*32 .. of that head,
+                    // block 1 = rows d + 64 (the rotation partners); N % 256 == 0, offsets from the tile's first row n0
+                    const int wrow = ((q >> 2) >> 1) * 128 + blk * 64 + ((q >> 2) & 1) * 32 + (q & 3) * 8 + rin;
                     src[kd][h] = (uint32_t)((int64_t)wrow * a.ldb * 2 + c * 16);
                 } else {
                     src[kd][h] = (uint32_t)((int64_t)(min(n0 + row + rin, N - 1) - n0) * a.ldb * 2 + c * 16);   // from row n0
@@ -960,12 +1022,18 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     __syncthreads();
     if constexpr (SWI) gemm_epilogue_swiglu(acc, a, smem, m0, tn, wm, wn, wave, lane);
     else if constexpr (SWB) gemm_epilogue_swiglu_bwd(acc, a, smem, m0, n0, wm, wn, wave, lane);
+    else if constexpr (ROPE) gemm_epilogue_rope(acc, a, smem, m0, n0, wm, wn, wave, lane);
     else gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
 __global__ __launch_bounds__(512) void gemm_pp_swiglu_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gemm_pp_tile<false, false, 0, true>(a, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(512) void gemm_pp_rope_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_pp_tile<false, false, 0, false, false, true>(a, blockIdx.x, smem);
 }
 
 __global__ __launch_bounds__(512) void gemm_pp_swiglu_bwd_kernel(GemmArgs a) {
@@ -1468,6 +1536,29 @@ extern "C" int mm355_gemm_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm
     const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
     hipLaunchKernelGGL(gemm_pp_swiglu_kernel, dim3((unsigned)total), dim3(512), PP_LDS, (hipStream_t)stream, a);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_gemm_rope_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                                    const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset,
+                                    int64_t M, int64_t N, int64_t K, int64_t L, int64_t n_rot, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wqkv || !qkv || !cos_t || !sin_t || M <= 0 || N <= 0 || K <= 0 || L <= 0 || n_rot < 0 || n_rot > N) return MM355_EINVAL;
+    if ((ldx & 7) || (ldw & 7) || (ld_qkv & 7) || !mm_aligned16(X) || !mm_aligned16(Wqkv) || !mm_aligned16(qkv) || !mm_aligned16(cos_t) || !mm_aligned16(sin_t))
+        return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff || L > 0x7fffffff) return MM355_EINVAL;
+    // heads of 128 in whole 256-column tiles, whole pairs of K tiles, 31-bit tile-relative offsets
+    if ((N & 255) || (n_rot & 127) || K < 128 || (K & 127) || (256 * ldx + K) * 2 >= 0x7fffffffLL || (256 * ldw + K) * 2 >= 0x7fffffffLL) return MM355_EUNSUPPORTED;
+    GemmArgs a = {};
+    a.A = X; a.B = Wqkv; a.C = qkv; a.bias = (const uint16_t*)pos_offset; a.res = nullptr;
+    a.lda = ldx; a.ldb = ldw; a.ldc = ld_qkv; a.ldr = 0; a.res_mod = n_rot;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = 0; a.ntm = a.ntn = 0;
+    a.aux0 = (uint16_t*)cos_t; a.aux1 = (uint16_t*)sin_t; a.ld_aux = L;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (mm_ensure_dynamic_lds((const void*)gemm_pp_rope_kernel, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    const int64_t total = pp_prepare(a);
+    if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+    hipLaunchKernelGGL(gemm_pp_rope_kernel, dim3((unsigned)total), dim3(512), PP_LDS, (hipStream_t)stream, a);
     return mm_launch_status();
 }
 

@@ -29,6 +29,8 @@ _DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
 _NORM_T = os.environ.get("MM355_NORM_T", "1") != "0"
 # MM355_FUSE_SWIGLU=0: gate|up GEMM and SwiGLU as two launches (A/B switch; the fused launch writes the same bits)
 _FUSE_SWIGLU = os.environ.get("MM355_FUSE_SWIGLU", "1") != "0"
+# MM355_FUSE_ROPE=0: q|k|v GEMM and RoPE as two launches (A/B switch; same bits)
+_FUSE_ROPE = os.environ.get("MM355_FUSE_ROPE", "1") != "0"
 # MM355_FUSE_SWIGLU_BWD=0: down_proj input-gradient GEMM and SwiGLU backward as two launches (A/B switch; same bits)
 _FUSE_SWIGLU_BWD = os.environ.get("MM355_FUSE_SWIGLU_BWD", "1") != "0"
 _CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
@@ -260,9 +262,13 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
     wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
     n1, rstd1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps, want_rstd=True)
-    qkv = ops.gemm(n1, wqkv)
-    del n1
-    ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)
+    if _FUSE_ROPE and ops.gemm_rope_supported(n1, wqkv, m.Hq, m.Hkv, m.d, m.cos):
+        qkv = ops.gemm_rope(n1, wqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)     # rotation in the GEMM epilogue: same bits
+        del n1
+    else:
+        qkv = ops.gemm(n1, wqkv)
+        del n1
+        ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)
     nq, nk = m.Hq * m.d, m.Hkv * m.d
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)

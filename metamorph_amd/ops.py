@@ -345,6 +345,28 @@ def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False, pos_offset=None):
     return qkv
 
 
+def gemm_rope_supported(x, wqkv, Hq, Hkv, d, cos):
+    """mm355_gemm_rope_bf16 takes this problem (head size 128, whole 256-column tiles, at least one wave of 256 x 256 tiles)."""
+    M, K = x.shape
+    N = wqkv.shape[0]
+    return (d == 128 and N == (Hq + 2 * Hkv) * d and N % 256 == 0 and K >= 128 and K % 128 == 0 and wqkv.shape[1] == K
+            and wqkv.is_contiguous() and x.is_contiguous() and cos.shape[1] == 128 and ((M + 255) // 256) * (N // 256) >= 200)
+
+
+def gemm_rope(x, wqkv, B, L, Hq, Hkv, d, cos, sin, pos_offset=None):
+    """qkv [B*L, (Hq + 2 Hkv) d] = fused q|k|v projection + RoPE on the q / k blocks: the bits of gemm(x, wqkv) followed by rope_qk_."""
+    _chk_dev(x, wqkv, cos, sin, pos_offset)
+    M, K = x.shape
+    N = wqkv.shape[0]
+    assert M == B * L and x.dtype == BF16 and wqkv.dtype == BF16 and cos.shape[0] >= L
+    if pos_offset is not None:
+        assert pos_offset.dtype == torch.int32 and pos_offset.numel() == B
+    qkv = torch.empty((M, N), device=x.device, dtype=BF16)
+    _lib.check(_L().mm355_gemm_rope_bf16(x.data_ptr(), K, wqkv.data_ptr(), K, qkv.data_ptr(), N, cos.data_ptr(), sin.data_ptr(), _p(pos_offset),
+                                         M, N, K, L, (Hq + Hkv) * d, _stream()), f"mm355_gemm_rope_bf16 M={M} N={N} K={K}")
+    return qkv
+
+
 def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None):
     """q2d/k2d/v2d: [B*L, ld] views starting at the q / k / v column blocks (k and v share the leading dimension)."""
     _chk_dev(q2d, k2d, v2d)

@@ -551,6 +551,25 @@ def test_gemm_swiglu_fused_equals_two_launches(ops):
         ops.gemm_swiglu(x, rnd(2 * 192, 256, seed=2).to(DEV), 192)
 
 
+def test_gemm_rope_fused_equals_two_launches(ops):
+    """mm355_gemm_rope_bf16 (q|k|v projection with the rotate-half RoPE of the q and k blocks in the epilogue; B tile staged from permuted
+    weight rows so that d and d + 64 meet in one lane) writes bit for bit what mm355_gemm_bf16 + mm355_rope_qk[_pos] write: LLaMA-3-8B head
+    geometry (32 / 8 heads of 128), ragged row count, with and without per-sample position offsets; and 70B's 64 / 8."""
+    d = 128
+    for (B, L, Hq, Hkv, K, off) in [(2, 2048, 32, 8, 4096, False), (3, 811, 32, 8, 2048, True), (2, 1024, 64, 8, 1024, False)]:
+        N = (Hq + 2 * Hkv) * d
+        x = rnd(B * L, K, seed=L, scale=0.5).to(DEV)
+        w = rnd(N, K, seed=N, scale=0.05).to(DEV)
+        cos, sin = ops.rope_table(2 * L, d, 500000.0, DEV)
+        po = torch.tensor([5, 0, 17][:B], dtype=torch.int32, device=DEV) if off else None
+        assert ops.gemm_rope_supported(x, w, Hq, Hkv, d, cos), (B, L, Hq, Hkv, K)
+        ref = ops.gemm(x, w)
+        ops.rope_qk_(ref, B, L, Hq, Hkv, d, cos, sin, pos_offset=po)
+        got = ops.gemm_rope(x, w, B, L, Hq, Hkv, d, cos, sin, pos_offset=po)
+        assert torch.equal(got, ref), (B, L, Hq, Hkv, K, float((got.float() - ref.float()).abs().max()))
+    assert not ops.gemm_rope_supported(rnd(512, 256, seed=1).to(DEV), rnd(4 * 64, 256, seed=2).to(DEV), 2, 1, 64, cos)      # d = 64
+
+
 def test_gemm_swiglu_bwd_fused_equals_two_launches(ops):
     """mm355_gemm_swiglu_bwd_bf16 (down_proj input-gradient GEMM with the SwiGLU backward in its epilogue: d act never reaches memory) against
     mm355_gemm_bf16 + mm355_swiglu_bwd_t on the same operands: dgu, actT and dguT bit for bit (the epilogue rounds d act to bf16 and uses
