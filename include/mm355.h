@@ -215,6 +215,16 @@ int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v
                    int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
                    float* workspace, void* stream);
 
+/* mm355_attn_bwd with the inverse RoPE rotation of dq / dk (what mm355_rope_qk(inverse = 1) does to the stored gradients: reference HF
+ * apply_rotary_pos_emb backward, reached at metamorph_llama.py:349-359) applied in the kernels' epilogues: q and k are the POST-RoPE tensors the
+ * forward attention saw, dq / dk come out as gradients of the PRE-RoPE projections.  Row l of sample b is position l (+ pos_offset[b]) of the
+ * cos / sin tables ([positions][128] bf16).  d == 128 only (MM355_EUNSUPPORTED otherwise: call mm355_attn_bwd + mm355_rope_qk). */
+int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
+                        const mm355_bf16* d_o, int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens,
+                        mm355_bf16* dq, int64_t ld_dq, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
+                        int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
+                        const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset, void* stream);
+
 /* floats of `workspace` mm355_attn_bwd needs for this geometry (ld_max = largest of ld_q / ld_k / ld_o); 0 when none is needed */
 int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, int64_t ld_max);
 

@@ -92,14 +92,17 @@ extern "C" int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, in
     return 2 * B * L * Hq * d;
 }
 
-extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
-                              int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
-                              mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
-                              float scale, int causal, float* workspace, void* stream) {
+namespace {
+int attn_bwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
+                  int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
+                  mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                  float scale, int causal, float* workspace, const uint16_t* rope_cos, const uint16_t* rope_sin, const int32_t* rope_pos,
+                  void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (ld_dq & 7)) return MM355_EINVAL;
     const bool fast = fast128(d, std::max(std::max(ld_q, ld_k), ld_o));
+    if (rope_cos && !fast) return MM355_EUNSUPPORTED;        // the fused inverse rotation lives in the d == 128 kernels' epilogues
     // GQA on the generic kernels: the group is summed from fp32 partials in the workspace (the d == 128 kernel sums in registers)
     if (Hq != Hkv && !fast && !workspace) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -110,7 +113,7 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
         dvp = workspace + (int64_t)B * L * Hq * d;
     }
     attn2::Args a{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
-                  dk, dv, dkp, dvp, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
+                  dk, dv, dkp, dvp, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal, rope_cos, rope_sin, rope_pos};
     int rc = fast ? mm355_attn3_dkdv_launch(a, s) : mm355_attn2_dkdv_launch(a, pick_dp(d), s);
     if (rc != MM355_OK) return rc;
     if (dkp) {
@@ -122,4 +125,23 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
         if (rc != MM355_OK) return rc;
     }
     return fast ? mm355_attn3_dq_launch(a, s) : mm355_attn2_dq_launch(a, pick_dp(d), s);
+}
+}  // namespace
+
+extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
+                              int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
+                              mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                              float scale, int causal, float* workspace, void* stream) {
+    return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, workspace,
+                         nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
+                                   int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
+                                   mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                                   float scale, int causal, const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset,
+                                   void* stream) {
+    if (!cos_t || !sin_t) return MM355_EINVAL;
+    return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, nullptr,
+                         cos_t, sin_t, pos_offset, stream);
 }

@@ -10,6 +10,9 @@ struct Args {
     uint16_t* dk; uint16_t* dv; float* dkp; float* dvp; int64_t ld_dkv;   // dK/dV kernel outputs (bf16 direct, or fp32 per-query-head partials)
     int B, L, Hq, Hkv, d;
     float scale; int causal;
+    // backward only, d == 128 kernels: when set, dq / dk leave the kernels already rotated back through RoPE (the inverse rotation of
+    // mm355_rope_qk on the bf16-rounded gradients): cos / sin tables [positions][128] bf16, optional per-sample position offsets
+    const uint16_t* rope_cos; const uint16_t* rope_sin; const int32_t* rope_pos;
 };
 
 #ifdef __HIPCC__

@@ -42,7 +42,22 @@ __global__ __launch_bounds__(256) void dkdv_kernel(Args a) {
             if (key >= L) continue;
             f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
             if (!zero) { x0 = *(const f32x4*)(so + r * DP + c); x1 = *(const f32x4*)(so + r * DP + c + 4); }
-            const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            if (a.rope_cos && !is_dv && !zero) {
+                // inverse RoPE on the bf16-rounded dk (mm355_rope_qk(inverse)): the partner columns c ^ 64 of this key row are in the slab too
+                const int cp = c ^ 64;
+                const f32x4 p0 = *(const f32x4*)(so + r * DP + cp), p1 = *(const f32x4*)(so + r * DP + cp + 4);
+                const float pf[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                const int pos = key + (a.rope_pos ? a.rope_pos[b] : 0);
+                float cs[8], sn[8];
+                unpack8(*(const u32x4*)(a.rope_cos + (int64_t)pos * DP + (c & 63)), cs);
+                unpack8(*(const u32x4*)(a.rope_sin + (int64_t)pos * DP + (c & 63)), sn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float own = round_bf(f[e]), par = round_bf(pf[e]);
+                    f[e] = c < 64 ? own * cs[e] + par * sn[e] : own * cs[e] - par * sn[e];
+                }
+            }
             *(u32x4*)((is_dv ? a.dv : a.dk) + (row_base + key) * a.ld_dkv + (int64_t)hk * DP + c) = pack8(f);
         }
         __syncthreads();

@@ -530,6 +530,29 @@ __global__ __launch_bounds__(256, RQ == 2 ? 2 : 1) void dq_kernel(Args a) {
         }
     }
     __syncthreads();
+    if (a.rope_cos) {
+        // inverse RoPE on the bf16-rounded dq (what mm355_rope_qk(inverse) does to the stored gradient): d and d + 64 of a query row are
+        // fragments j and j + 4 of the same lane;  dx1 = dy1 c + dy2 s,  dx2 = dy2 c - dy1 s
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+            const int qg = qw0 + rq * 16 + fr;
+            const float keep = qg < seqlen ? 1.0f : 0.0f;
+            const int pos = min(qg, L - 1) + (a.rope_pos ? a.rope_pos[b] : 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x2 cw = *(const u32x2*)(a.rope_cos + (int64_t)pos * DP + j * 16 + fq * 4);
+                const u32x2 sw = *(const u32x2*)(a.rope_sin + (int64_t)pos * DP + j * 16 + fq * 4);
+                const float c[4] = {bf2f((uint16_t)(cw.x & 0xffffu)), bf2f((uint16_t)(cw.x >> 16)), bf2f((uint16_t)(cw.y & 0xffffu)), bf2f((uint16_t)(cw.y >> 16))};
+                const float sn[4] = {bf2f((uint16_t)(sw.x & 0xffffu)), bf2f((uint16_t)(sw.x >> 16)), bf2f((uint16_t)(sw.y & 0xffffu)), bf2f((uint16_t)(sw.y >> 16))};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x1 = round_bf(dqt[rq][j][r] * keep), x2 = round_bf(dqt[rq][j + 4][r] * keep);
+                    dqt[rq][j][r] = x1 * c[r] + x2 * sn[r];
+                    dqt[rq][j + 4][r] = x2 * c[r] - x1 * sn[r];
+                }
+            }
+        }
+    }
     // dq[q][d] bf16 -> LDS [32 q][128] per wave -> row-contiguous 16-B stores (rows >= seqlen are zero)
     unsigned char* so = smem + wave * (ROWS * DP * 2);
 #pragma unroll

@@ -381,10 +381,13 @@ class DecoderLayerFn(Function):
             weight_grad_gemm(dx2, o, buf, acc)
             commit_grad(att.o_proj.weight, buf)
         dqkv = torch.empty_like(qkv)
+        fuse_rope = _FUSE_ROPE and ops.attn_bwd_rope_supported(m.d)      # inverse RoPE of dq / dk in the attention kernels' epilogues
         ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
-                     m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:])
+                     m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:],
+                     rope=(m.cos, m.sin, m.pos_offset) if fuse_rope else None)
         del do
-        ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True, pos_offset=m.pos_offset)
+        if not fuse_rope:
+            ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True, pos_offset=m.pos_offset)
         wqkv = fused_weight(qkv_params)
         dn1 = input_grad_gemm(dqkv, wqkv)
         if any(p.requires_grad for p in qkv_params):

@@ -551,6 +551,42 @@ def test_gemm_swiglu_fused_equals_two_launches(ops):
         ops.gemm_swiglu(x, rnd(2 * 192, 256, seed=2).to(DEV), 192)
 
 
+@pytest.mark.parametrize("case", [(2, 333, 8, 2, [333, 256], False), (3, 513, 4, 2, None, True), (1, 2048, 32, 8, None, False)])
+def test_attn_bwd_with_fused_inverse_rope_equals_two_launches(ops, case):
+    """mm355_attn_bwd_rope (d == 128 kernels; inverse RoPE of dq / dk in the epilogues: dq from the accumulator fragments j / j + 4 of a lane,
+    dk from the fp32 staging rows) against mm355_attn_bwd + mm355_rope_qk(inverse): dv bit for bit (untouched); dq / dk equal up to the
+    rounding of one fused multiply-add (both forms rotate the bf16-rounded gradient; the compiler may contract a different product), i.e.
+    <= 1 bf16 ulp on a small fraction of the elements."""
+    B, L, Hq, Hkv, seqlens, off = case
+    d = 128
+    qkv, q, k, v, valid = _attn_setup((B, L, Hq, Hkv, d, True, seqlens), seed=5)
+    do = rnd(B * L, Hq * d, seed=6, scale=0.5)
+    if valid is not None:
+        do = (do.view(B, L, -1) * valid[:, :, None]).reshape(B * L, -1).contiguous()
+    dev = qkv.to(DEV)
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
+    nq, nk = Hq * d, Hkv * d
+    qd, kd, vd = dev[:, :nq], dev[:, nq:nq + nk], dev[:, nq + nk:]
+    o, lse = ops.attn_fwd(qd, kd, vd, B, L, Hq, Hkv, d, d ** -0.5, True, sl)
+    cos, sin = ops.rope_table(L + 32, d, 500000.0, DEV)
+    po = torch.tensor([3, 0, 29][:B], dtype=torch.int32, device=DEV) if off else None
+    ref = torch.full_like(dev, float("nan"))
+    ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, B, L, Hq, Hkv, d, d ** -0.5, True, sl, ref[:, :nq], ref[:, nq:nq + nk], ref[:, nq + nk:])
+    ops.rope_qk_(ref, B, L, Hq, Hkv, d, cos, sin, inverse=True, pos_offset=po)
+    got = torch.full_like(dev, float("nan"))
+    ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, B, L, Hq, Hkv, d, d ** -0.5, True, sl, got[:, :nq], got[:, nq:nq + nk], got[:, nq + nk:],
+                 rope=(cos, sin, po))
+    assert bool(torch.isfinite(got.float()).all())
+    assert torch.equal(got[:, nq + nk:], ref[:, nq + nk:])
+    for name, a, b in (("dq", got[:, :nq], ref[:, :nq]), ("dk", got[:, nq:nq + nk], ref[:, nq:nq + nk])):
+        if not torch.equal(a, b):
+            diff = (a.float() - b.float()).abs()
+            frac = float((diff > 0).float().mean())
+            rel_ulp = float((diff / b.float().abs().clamp_min(1e-4)).max())
+            print(f"   {name}: {frac:.2e} of the elements differ, max relative difference {rel_ulp:.2e}")
+            assert frac < 2e-2 and rel_ulp <= 2.0 ** -6, (name, case, frac, rel_ulp)
+
+
 def test_gemm_rope_fused_equals_two_launches(ops):
     """mm355_gemm_rope_bf16 (q|k|v projection with the rotate-half RoPE of the q and k blocks in the epilogue; B tile staged from permuted
     weight rows so that d and d + 64 meet in one lane) writes bit for bit what mm355_gemm_bf16 + mm355_rope_qk[_pos] write: LLaMA-3-8B head
