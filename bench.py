@@ -496,7 +496,7 @@ def main():
         # the gfx950 x2 read correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed
         # under profiles/; they only apply to the configuration they were taken on.
         traffic, traffic_src = None, None
-        tname = {12: "r1_step_b12_hbm_traffic_e.json", 16: "r3_step_b16_hbm_traffic_b.json"}.get(args.batch, "none")
+        tname = {12: "r1_step_b12_hbm_traffic_e.json", 16: "r3_step_b16_hbm_traffic_c.json"}.get(args.batch, "none")
         tpath = os.path.join(REPO, "profiles", tname)
         if args.layers == 32 and args.seq == 2048 and args.frames == 1 and os.path.exists(tpath):
             for k in json.load(open(tpath))["kernels"]:
