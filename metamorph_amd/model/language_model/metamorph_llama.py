@@ -91,32 +91,57 @@ class _DecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
 
-class HipKVCache(DynamicCache):
-    """What `past_key_values` is under HF `generate()` (reference metamorph_llama.py:711-717, `use_customize_greedy=False`): a
-    `transformers` Cache whose payload is `functional.KVCache` -- post-RoPE keys / values of every decoder layer in the layout the
-    decode kernels read ([layers, 1, max_len, Hkv*d] bf16, write position on the device) -- plus the captured hipGraph of the
-    per-token step.  HF only asks a cache for its length; the tensors never leave the device or change layout."""
+class _SeqState:
+    """Decode state of ONE sequence (a batch row / a beam): the KV cache of every layer + the captured per-token step."""
 
-    def __init__(self, capacity=None, **kw):
-        super().__init__(**kw)
-        self.capacity = capacity          # rows to allocate at the first (prompt) pass; None: prompt + 1024 + 2
+    def __init__(self):
         self.kv = None                    # functional.KVCache
         self.stepper = None               # functional.DecodeStepGraph
         self.meta = None
 
+
+class HipKVCache(DynamicCache):
+    """What `past_key_values` is under HF `generate()` (reference metamorph_llama.py:711-717, `use_customize_greedy=False`): a
+    `transformers` Cache whose payload is one `functional.KVCache` per sequence -- post-RoPE keys / values of every decoder layer in the
+    layout the decode kernels read ([layers, 1, max_len, Hkv*d] bf16, write position on the device) -- plus the captured hipGraph of the
+    per-token step.  HF only asks a cache for its length and, under beam search, to re-order its batch rows (`reorder_cache`); the tensors
+    never leave the device or change layout."""
+
+    def __init__(self, capacity=None, **kw):
+        super().__init__(**kw)
+        self.capacity = capacity          # rows to allocate at the first (prompt) pass; None: prompt + 1024 + 2
+        self.states = []                  # one _SeqState per sequence (batch row or beam), all of the same length
+
+    @property
+    def kv(self):
+        return self.states[0].kv if self.states else None
+
     def get_seq_length(self, layer_idx=0):
-        return 0 if self.kv is None else int(self.kv.length)
+        return 0 if not self.states else int(self.states[0].kv.length)
 
     def get_max_cache_shape(self, layer_idx=0):
-        return -1 if self.kv is None else int(self.kv.max_len)
+        return -1 if not self.states else int(self.states[0].kv.max_len)
 
     def reorder_cache(self, beam_idx):
-        if int(beam_idx.numel()) != 1 or int(beam_idx.reshape(-1)[0]) != 0:
-            raise NotImplementedError("beam search (num_beams > 1) needs one KV cache per beam; the decode kernels hold one sequence")
+        """Beam search: row i continues the hypothesis that lived in row beam_idx[i].  Rows that change owner get a copy of the owner's
+        keys / values (snapshot first: a row may be both a source and a target); buffers and captured graphs stay with their row."""
+        idx = [int(i) for i in beam_idx.reshape(-1).tolist()]
+        if len(idx) != len(self.states):
+            raise ValueError(f"reorder_cache: {len(idx)} indices for {len(self.states)} sequences")
+        moved = [(i, j) for i, j in enumerate(idx) if i != j]
+        if not moved:
+            return
+        n = self.get_seq_length()
+        snap = {j: (self.states[j].kv.k[:, :, :n].clone(), self.states[j].kv.v[:, :, :n].clone()) for j in {j for _, j in moved}}
+        for i, j in moved:
+            self.states[i].kv.k[:, :, :n].copy_(snap[j][0])
+            self.states[i].kv.v[:, :, :n].copy_(snap[j][1])
+            self.states[i].kv.set_length(n)
 
     def crop(self, max_length):
-        if self.kv is not None and 0 <= max_length < self.kv.length:
-            self.kv.set_length(int(max_length))
+        for st in self.states:
+            if 0 <= max_length < st.kv.length:
+                st.kv.set_length(int(max_length))
 
 
 class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
@@ -572,25 +597,25 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         return (output, emb) if output_image else output
 
     # ------------------------------------------------------------------ HF generate() on the decode kernels (reference :711-738)
-    def _prefill_rows(self, x2d, cache):
-        """[L0, h] prompt rows -> hidden rows [L0, h] (pre final norm); fills `cache` (allocating it on first use)."""
+    def _prefill_rows(self, x2d, state, capacity):
+        """[L0, h] prompt rows of ONE sequence -> hidden rows [L0, h] (pre final norm); allocates and fills `state`."""
         dev = x2d.device
         L0, h = x2d.shape
         _, meta = self._decode_meta(L0)
-        cap = cache.capacity if cache.capacity is not None else L0 + 1024 + 2
+        cap = capacity if capacity is not None else L0 + 1024 + 2
         if cap < L0 + 1:
             raise ValueError(f"HipKVCache capacity {cap} is smaller than the prompt ({L0} rows)")
         cos, sin = self.model.rope_tables(cap, dev)
         meta.cos, meta.sin = cos, sin
-        cache.kv = F.KVCache(len(self.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
-        cache.meta = meta
-        rows = F.decoder_prefill(x2d, self.model.layers, meta, cache.kv)
-        cache.stepper = F.DecodeStepGraph(self.model.layers, meta, cache.kv, cos, sin, h, dev)
+        state.kv = F.KVCache(len(self.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
+        state.meta = meta
+        rows = F.decoder_prefill(x2d, self.model.layers, meta, state.kv)
+        state.stepper = F.DecodeStepGraph(self.model.layers, meta, state.kv, cos, sin, h, dev)
         return rows
 
-    def _decode_rows(self, x2d, cache):
-        """New rows (usually one) appended one at a time against the cache -> their hidden rows [n, h] (pre final norm)."""
-        outs = [cache.stepper.step(x2d[i:i + 1]).clone() for i in range(x2d.shape[0])]
+    def _decode_rows(self, x2d, state):
+        """New rows (usually one) of ONE sequence appended one at a time against its cache -> their hidden rows [n, h] (pre final norm)."""
+        outs = [state.stepper.step(x2d[i:i + 1]).clone() for i in range(x2d.shape[0])]
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     def _rows_logits(self, rows):
@@ -609,10 +634,8 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         if inputs_embeds.dtype != BF16:
             raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
         B, n, h = inputs_embeds.shape
-        if B != 1:
-            raise NotImplementedError("cached decoding handles one sequence (batch 1, num_beams 1), like the reference's own loop")
         if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
-            raise NotImplementedError("cached decoding takes an un-padded prompt (attention_mask all ones)")
+            raise NotImplementedError("cached decoding takes un-padded prompts (attention_mask all ones)")
         cache = past_key_values
         if cache is None:
             cache = HipKVCache()
@@ -620,12 +643,19 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
             if cache.get_seq_length() != 0:
                 raise NotImplementedError("past_key_values must be a metamorph_amd HipKVCache (generate() creates one); a foreign, "
                                           "already filled transformers Cache holds tensors in another layout")
-            fresh = HipKVCache()                              # an empty HF cache object: swap in ours
-            cache = fresh
-        x2d = inputs_embeds.reshape(n, h).contiguous()
-        rows = self._prefill_rows(x2d, cache) if cache.kv is None else self._decode_rows(x2d, cache)
-        logits = self._rows_logits(rows.contiguous()).view(1, n, -1)
-        hidden = self.model.norm(rows).view(1, n, h)
+            cache = HipKVCache()                              # an empty HF cache object: swap in ours
+        first = not cache.states
+        if first:
+            cache.states = [_SeqState() for _ in range(B)]    # batch rows / beams are independent sequences, each with its own cache
+        elif len(cache.states) != B:
+            raise ValueError(f"cache holds {len(cache.states)} sequences, the step brings {B}")
+        rows = []
+        for b, st in enumerate(cache.states):
+            x2d = inputs_embeds[b].reshape(n, h).contiguous()
+            rows.append(self._prefill_rows(x2d, st, cache.capacity) if first else self._decode_rows(x2d, st))
+        rows = rows[0] if B == 1 else torch.cat(rows, 0)
+        logits = self._rows_logits(rows.contiguous()).view(B, n, -1)
+        hidden = self.model.norm(rows).view(B, n, h)
         if return_dict is False:
             return (logits, cache)
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=hidden, attentions=None)
@@ -654,8 +684,6 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         if not use_customize_greedy:
             # reference :711-717: `super().generate(position_ids=..., attention_mask=..., inputs_embeds=..., **kwargs)` -- HF's sampling
             # / greedy search driving forward() with a cache.  Here the cache is a HipKVCache (decode kernels + hipGraph replay).
-            if int(kwargs.get("num_beams", 1) or 1) != 1:
-                raise NotImplementedError("num_beams > 1: the decode kernels hold one sequence's KV cache")
             if kwargs.get("past_key_values") is None and kwargs.get("use_cache", True):
                 L0 = int(inputs_embeds.shape[1])
                 new = kwargs.get("max_new_tokens")

@@ -845,7 +845,7 @@ def gen_hfgen():
     GenerationMixin driving the reference's forward with a KV cache.  Weights as in gen_decode (sparse lm_head whose planned rows are
     solved on the hidden rows the reference itself produces, so every decision has a margin far above bf16 noise); recorded: the
     greedy ids, and a SAMPLING run (do_sample, temperature 0.7, top_p 0.9) -- the planned token holds > 0.9 of the probability mass at
-    every step, so the nucleus is that one token and the sampled ids are seed-independent (checked with three seeds)."""
+    every step, so the nucleus is that one token and the sampled ids are seed-independent (checked with three seeds); and a beam search (num_beams = 2, both hypotheses returned with their scores)."""
     A = 128000
     cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1)}
     plan = [(0, 41), (1, 42), (2, ST), (3, 43), (4, 44), (5, 128009)]      # HF path: <image_start> is an ordinary token, no image mode
@@ -911,7 +911,23 @@ def gen_hfgen():
             torch.manual_seed(sseed)
             sampled.append(run(rows, torch.float32, do_sample=True, temperature=0.7, top_p=0.9)[0])
         assert all(sm == toks for sm in sampled), sampled
-        save_npz(f"hfgen_{name}.npz", seed=np.int64(seed), input_ids=ids_t, images=images if images is not None else torch.zeros(0),
+        # beam search (num_beams = 2, both hypotheses returned): the second beam leaves the planned path, so the cache rows are re-ordered
+        sd2 = dict(sd)
+        sd2["lm_head.weight"] = decode_lm_head(sd, rows)
+        beams = {}
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            model = build_reference(cfg, sd2, dt)
+            model.eval()
+            with torch.no_grad():
+                bo = model.generate(inputs=ids_t, images=None if images is None else images.to(dt), use_customize_greedy=False, num_beams=2,
+                                    num_return_sequences=2, do_sample=False, max_new_tokens=10, eos_token_id=128009, pad_token_id=128001,
+                                    return_dict_in_generate=True, output_scores=True)
+            beams[tag] = (bo.sequences.clone(), bo.sequences_scores.float().clone())
+        assert beams["f32"][0].tolist() == beams["bf16"][0].tolist(), (beams["f32"][0].tolist(), beams["bf16"][0].tolist())
+        assert beams["f32"][0][0].tolist()[:len(toks)] == toks
+        print(f"    {name}: beams {beams['f32'][0].tolist()} scores {beams['f32'][1].tolist()} (bf16 {beams['bf16'][1].tolist()})")
+        save_npz(f"hfgen_{name}.npz", beam_sequences=beams["f32"][0], beam_scores=beams["f32"][1], beam_scores_bf16=beams["bf16"][1],
+                 seed=np.int64(seed), input_ids=ids_t, images=images if images is not None else torch.zeros(0),
                  active=np.array(DECODE_ACTIVE, dtype=np.int64), row_tokens=np.array(list(rows.keys()), dtype=np.int64),
                  row_values=torch.stack(list(rows.values())), tokens=np.array(toks, dtype=np.int64), margins=margins,
                  top_prob_at_T07=probs, sampled_tokens=np.array(sampled[0], dtype=np.int64),

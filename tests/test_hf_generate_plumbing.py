@@ -34,19 +34,23 @@ def _cpu_model(g):
             h = RM.llama_layer(sd, cfg, i, h, None, cos, sin)
         return h[0]
 
-    def prefill(x2d, cache):
+    def prefill(x2d, state, capacity):
         calls["prefill"] += 1
-        cache.rows = x2d.float()
-        cache.kv = SimpleNamespace(length=x2d.shape[0], max_len=cache.capacity)
-        return decoder_rows(cache.rows).bfloat16()
+        L0, h = x2d.shape
+        # the stand-in cache keeps the INPUT rows in `kv.k` (same fields HipKVCache.reorder_cache copies between beams)
+        state.kv = SimpleNamespace(k=torch.zeros(1, 1, capacity, h), v=torch.zeros(1, 1, capacity, 1), length=L0, max_len=capacity)
+        state.kv.set_length = lambda n, kv=state.kv: setattr(kv, "length", n)
+        state.kv.k[0, 0, :L0] = x2d.float()
+        return decoder_rows(state.kv.k[0, 0, :L0]).bfloat16()
 
-    def decode(x2d, cache):
+    def decode(x2d, state):
         calls["decode"] += 1
         assert x2d.shape[0] == 1                                  # one new row per step
-        cache.rows = torch.cat([cache.rows, x2d.float()], 0)
-        cache.kv.length += 1
-        assert cache.kv.length <= cache.kv.max_len
-        return decoder_rows(cache.rows)[-1:].bfloat16()
+        n = state.kv.length
+        assert n + 1 <= state.kv.max_len
+        state.kv.k[0, 0, n] = x2d[0].float()
+        state.kv.length = n + 1
+        return decoder_rows(state.kv.k[0, 0, :n + 1])[-1:].bfloat16()
 
     model._prefill_rows = prefill
     model._decode_rows = decode
@@ -71,10 +75,20 @@ def test_hf_generate_greedy_and_sampling_reproduce_reference_ids():
         out = model.generate(inputs=ids, use_customize_greedy=False, do_sample=True, temperature=0.7, top_p=0.9,
                              max_new_tokens=int(g["max_new_tokens"]), eos_token_id=128009, pad_token_id=128001)
         assert out[0].tolist() == g["sampled_tokens"].tolist() == want
-    # beam search is refused, not silently run as greedy
-    import pytest
-    with pytest.raises(NotImplementedError):
-        model.generate(inputs=ids, use_customize_greedy=False, num_beams=2, max_new_tokens=4)
+
+
+def test_hf_generate_beam_search_reproduces_reference_beams():
+    """num_beams = 2 with both hypotheses returned: the second beam leaves the planned path (so HF re-orders the cache rows through
+    `HipKVCache.reorder_cache`); sequences and sequence scores as the reference's own beam search gave them."""
+    g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
+    model, calls = _cpu_model(g)
+    out = model.generate(inputs=torch.from_numpy(g["input_ids"]), use_customize_greedy=False, num_beams=2, num_return_sequences=2,
+                         do_sample=False, max_new_tokens=int(g["max_new_tokens"]), eos_token_id=128009, pad_token_id=128001,
+                         return_dict_in_generate=True, output_scores=True)
+    assert out.sequences.tolist() == g["beam_sequences"].tolist(), (out.sequences.tolist(), g["beam_sequences"].tolist())
+    assert torch.allclose(out.sequences_scores.float(), torch.from_numpy(g["beam_scores"]), atol=2e-3), out.sequences_scores
+    assert calls["prefill"] == 2                                  # one prompt pass per beam, then one cached row per beam and step
+    assert len(out.past_key_values.states) == 2
 
 
 def test_hip_kv_cache_is_a_transformers_cache():
@@ -82,7 +96,14 @@ def test_hip_kv_cache_is_a_transformers_cache():
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
     c = HipKVCache(capacity=32)
     assert isinstance(c, Cache) and c.get_seq_length() == 0
-    c.kv = SimpleNamespace(length=7, max_len=32, set_length=lambda n: setattr(c.kv, "length", n))
+    def seq(n, fill):
+        kv = SimpleNamespace(k=torch.full((2, 1, 32, 4), fill), v=torch.full((2, 1, 32, 4), -fill), length=n, max_len=32)
+        kv.set_length = lambda m, kv=kv: setattr(kv, "length", m)
+        return SimpleNamespace(kv=kv, stepper=None, meta=None)
+    c.states = [seq(7, 1.0), seq(7, 2.0), seq(7, 3.0)]
     assert c.get_seq_length() == 7 and c.get_max_cache_shape() == 32
+    c.reorder_cache(torch.tensor([1, 1, 0]))                      # row 1 is source AND target, row 0 both as well: snapshot semantics
+    assert [float(st.kv.k[0, 0, 0, 0]) for st in c.states] == [2.0, 2.0, 1.0] and float(c.states[2].kv.v[0, 0, 6, 0]) == -1.0
+    assert float(c.states[0].kv.k[0, 0, 7, 0]) == 1.0            # rows beyond the length are left alone
     c.crop(5)
     assert c.get_seq_length() == 5
