@@ -90,16 +90,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_two_ranks_equal_one_rank(tmp_path, dtype, overlap):
+@pytest.mark.parametrize("world,dtype,overlap", [(2, torch.float32, False), (2, torch.float32, True), (2, torch.bfloat16, False),
+                                                 (2, torch.bfloat16, True), (3, torch.float32, True), (4, torch.float32, True),
+                                                 (4, torch.bfloat16, True), (8, torch.float32, True), (8, torch.bfloat16, False)])
+def test_n_ranks_equal_one_rank(tmp_path, world, dtype, overlap):
     """overlap=True: each "layer" segment is reduced asynchronously as soon as it is announced (the RCCL reduce-scatter /
-    backward overlap of the product, here gloo all-reduce), the rest at step(); the result must not depend on it."""
-    world, steps = 2, 3
+    backward overlap of the product, here gloo all-reduce), the rest at step(); the result must not depend on it.
+    world 2 / 4 / 8 are the sizes of the one-node scaling run (`bench.py --gpus N`), 3 a size that divides nothing."""
+    steps = 3
     mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path), overlap), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
-    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
-    assert torch.equal(r0, r1), "ranks must hold identical parameters after the all-gather"
+    for r in range(1, world):
+        assert torch.equal(r0, torch.load(os.path.join(tmp_path, f"rank{r}.pt"))), "ranks must hold identical parameters after the all-gather"
 
     # single-rank reference with the same per-step gradients (step 2: last parameter has no gradient)
     params = _make_params(dtype)
@@ -113,9 +115,11 @@ def test_two_ranks_equal_one_rank(tmp_path, dtype, overlap):
             if s == 2:
                 g[-n_last:] = 0
             per_rank.append(g)
-        summed = per_rank[0] + per_rank[1]
-        if dtype == torch.bfloat16:
-            summed = summed.to(dtype).float()
+        summed = per_rank[0]
+        for g in per_rank[1:]:                                       # gloo sums in rank order; bf16 rounds after every addition
+            summed = summed + g
+            if dtype == torch.bfloat16:
+                summed = summed.to(dtype).float()
         coef = min(1.0, 1.0 / (float(summed.norm()) / world + 1e-6)) / world
         R.adamw_step(flat, summed, m, v, s, 1e-2, 0.9, 0.95, 1e-8, 0.1, grad_scale=coef)
     want = flat.to(dtype)
@@ -251,14 +255,15 @@ def _model_worker(rank, world, port, tmp, overlap):
         dist.destroy_process_group()
 
 
-def test_overlap_on_the_real_module_tree(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_overlap_on_the_real_module_tree(tmp_path, world):
     """tag_segments + enable_overlap on the actual MetaMorph module tree (CPU parameters, gloo): one segment per decoder
     layer, announcements start that layer's reduction, and the result is bit-identical to the non-overlapped schedule."""
     for ov in (False, True):
-        mp.spawn(_model_worker, args=(2, _free_port(), str(tmp_path), ov), nprocs=2, join=True)
-    a0, a1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov0.pt")) for r in (0, 1))
-    b0, b1 = (torch.load(os.path.join(tmp_path, f"model_rank{r}_ov1.pt")) for r in (0, 1))
-    assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(a0, b0)
+        mp.spawn(_model_worker, args=(world, _free_port(), str(tmp_path), ov), nprocs=world, join=True)
+    a = [torch.load(os.path.join(tmp_path, f"model_rank{r}_ov0.pt")) for r in range(world)]
+    b = [torch.load(os.path.join(tmp_path, f"model_rank{r}_ov1.pt")) for r in range(world)]
+    assert all(torch.equal(a[0], x) for x in a[1:] + b)
 
 
 def test_param_groups_with_their_own_learning_rate():

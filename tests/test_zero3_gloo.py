@@ -120,11 +120,13 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_zero3_two_ranks_equal_zero2_one_rank(tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    a, b = torch.load(tmp_path / "z3_rank0.pt"), torch.load(tmp_path / "z3_rank1.pt")
-    assert torch.equal(a, b)
-    # one rank, ZeRO-2, gradient = mean over the two ranks of the sum over micro-steps
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_zero3_n_ranks_equal_zero2_one_rank(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / "z3_rank0.pt")
+    for r in range(1, world):
+        assert torch.equal(a, torch.load(tmp_path / f"z3_rank{r}.pt"))
+    # one rank, ZeRO-2, gradient = mean over the ranks of the sum over micro-steps
     from metamorph_amd import functional as F
     from metamorph_amd.zero2 import Zero2AdamW
     model = _build()
@@ -135,12 +137,15 @@ def test_zero3_two_ranks_equal_zero2_one_rank(tmp_path):
     for step in (1, 2):
         opt.zero_grad()
         for p in params:
-            g = sum(_grad_for(names[id(p)], p.shape, step, micro, r) for micro in range(2) for r in range(2)) / 2
+            g = sum(_grad_for(names[id(p)], p.shape, step, micro, r) for micro in range(2) for r in range(world)) / world
             p._mm_grad_buf.copy_(g)
             p.grad = p._mm_grad_buf
         opt.step()
     one = torch.cat([p.data.reshape(-1) for p in params])
-    torch.testing.assert_close(a, one, rtol=2e-5, atol=2e-5)   # clip epsilon (1e-6) acts on the summed vs the mean norm; fp32 order
+    # clip epsilon (1e-6) acts on the summed vs the mean norm; fp32 summation order over `world` ranks (2 of 343 424 elements reach 2.4e-5
+    # at world 8: AdamW's g / sqrt(v) at step 1-2 amplifies the last bit of a small gradient)
+    tol = 2e-5 * max(1, world // 2)
+    torch.testing.assert_close(a, one, rtol=tol, atol=tol)
 
 
 def test_zero3_single_process_matches_zero2():
