@@ -58,3 +58,54 @@ class FakeTokenizer:
         if self.add_bos:
             ids = [self.bos_token_id] + ids
         return SimpleNamespace(input_ids=ids)
+
+
+class VocabTokenizer(FakeTokenizer):
+    """FakeTokenizer + the three extra things the rest of the reference's Python surface asks a tokenizer for: `batch_decode`
+    (KeywordsStoppingCriteria, mm_utils.py:226-258), `add_tokens` / `__len__` (initialize_vision_tokenizer, metamorph_arch.py:427-469).
+    Words come from a fixed list so ids decode back; unknown words share one id."""
+
+    WORDS = ("the cat sat on a mat ### stop </s> Human : Assistant answer is yes no maybe done . , ! image of red blue green "
+             "one two three four five").split()
+
+    def __init__(self, base_vocab=512, **kw):
+        super().__init__(**kw)
+        self.base_vocab = base_vocab
+        self.word_id = {w: 10 + i for i, w in enumerate(self.WORDS)}
+        self.id_word = {i: w for w, i in self.word_id.items()}
+        self.added = []
+
+    def _word(self, w):
+        if w in self.added:
+            return self.base_vocab + self.added.index(w)
+        return self.word_id.get(w, 9)
+
+    def encode_plain(self, text):
+        for w in self.added:
+            text = text.replace(w, f" {w} ")
+        return super().encode_plain(text)
+
+    def add_tokens(self, tokens, special_tokens=False):
+        new = [t for t in tokens if t not in self.added]
+        self.added.extend(new)
+        return len(new)
+
+    def __len__(self):
+        return self.base_vocab + len(self.added)
+
+    def batch_decode(self, ids, skip_special_tokens=False):
+        special = set(SPECIALS.values()) | {self.bos_token_id, self.pad_token_id}
+        inv = {v: k for k, v in SPECIALS.items()}
+        out = []
+        for row in ids:
+            words = []
+            for t in (row.tolist() if hasattr(row, "tolist") else list(row)):
+                if t in special:
+                    if not skip_special_tokens:
+                        words.append(inv.get(t, f"<{t}>"))
+                elif t >= self.base_vocab and t - self.base_vocab < len(self.added):
+                    words.append(self.added[t - self.base_vocab])
+                else:
+                    words.append(self.id_word.get(t, "<unk>"))
+            out.append(" ".join(words))
+        return out

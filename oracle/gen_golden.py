@@ -936,6 +936,96 @@ def gen_hfgen():
         print(f"    {name}: seed {seed} tokens {toks} min margin {float(margins.min()):.2f} min top prob at T=0.7 {float(probs.min()):.4f}")
 
 
+def gen_surface():
+    """The rest of the Python surface SURVEY.md 8(b) lists, recorded from the reference: `get_model_name_from_path` (mm_utils.py:218-224),
+    `KeywordsStoppingCriteria` (mm_utils.py:226-258: id-suffix match, decoded-text match over the last `max_keyword_len` NEW tokens, all rows
+    of a batch must stop), `initialize_vision_tokenizer` (metamorph_arch.py:427-469: added tokens, embedding resize, new rows = mean of the
+    old ones in the weights' own dtype, requires_grad policy, rows taken from a stage-1 adapter file of either shape)."""
+    import tempfile
+    from types import SimpleNamespace
+    from metamorph.mm_utils import KeywordsStoppingCriteria, get_model_name_from_path
+    from oracle.fake_tokenizer import VocabTokenizer
+    out = {}
+    paths = ["org/model-7b", "/abs/run/checkpoint-500", "runs/x/checkpoint-12/", "single", "/a/b/c/", "a/checkpoint-", "checkpoint-3",
+             "x/y/checkpoints-3"]
+    names = []
+    for q in paths:
+        try:
+            names.append(get_model_name_from_path(q))
+        except Exception as e:
+            names.append(f"{type(e).__name__}")
+    out["model_names"] = dict(zip(paths, names))
+
+    tok = VocabTokenizer(add_bos=True)
+    enc = lambda text: tok(text).input_ids[1:]
+    prompt = torch.tensor([[128000] + enc("Human : the cat sat")])
+    stop_cases = []
+    for kws in (["###"], ["stop", "###"], ["answer is yes"], ["done ."]):
+        for add_bos in (True, False):
+            tk = VocabTokenizer(add_bos=add_bos)
+            crit = KeywordsStoppingCriteria(kws, tk, prompt)
+            for gen in ("", "a mat", "a mat ###", "### a", "answer is yes", "answer is yes .", "is yes", "the answer is yes no", "done", "done .",
+                        "stop", "one two three four answer is yes", "answer is yes one two three four"):
+                ids = torch.cat([prompt, torch.tensor([enc(gen)], dtype=torch.long)], 1)
+                stop_cases.append(dict(keywords=kws, add_bos=add_bos, generated=gen, stop=bool(crit(ids, None)),
+                                       max_keyword_len=int(crit.max_keyword_len), start_len=int(crit.start_len)))
+    # batches: every row must stop
+    crit = KeywordsStoppingCriteria(["###"], tok, prompt)
+    for gens in (("a ###", "mat ###"), ("a ###", "mat a"), ("a a", "mat a")):
+        ids = torch.cat([prompt.repeat(2, 1), torch.tensor([enc(g) for g in gens])], 1)
+        stop_cases.append(dict(keywords=["###"], add_bos=True, generated=list(gens), stop=bool(crit(ids, None)), max_keyword_len=int(crit.max_keyword_len),
+                               start_len=int(crit.start_len)))
+    out["stopping"] = stop_cases
+    out["prompt_ids"] = prompt[0].tolist()
+
+    cfg = tiny_cfg(vocab_size=512, hidden_size=64, intermediate_size=128, num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=51)
+    rng = np.random.default_rng(52)
+    vt = []
+    with tempfile.TemporaryDirectory() as tmp:
+        adapters = {}
+        for kind, rows in (("full", 514), ("rows", 2), ("bad", 7)):
+            path = os.path.join(tmp, f"adapter_{kind}.bin")
+            w = torch.from_numpy(rng.standard_normal((rows, cfg.hidden_size), dtype=np.float32))
+            torch.save({"model.embed_tokens.weight": w}, path)
+            adapters[kind] = (path, w)
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            for patch, se, tune, adapter in ((False, False, False, None), (True, False, True, None), (False, True, False, None), (False, True, True, None),
+                                             (True, True, True, None), (False, True, False, "full"), (False, True, True, "rows"), (False, True, False, "bad")):
+                model = build_reference(cfg, sd, dt)
+                tk = VocabTokenizer()
+                margs = SimpleNamespace(mm_use_im_patch_token=patch, mm_use_im_start_end=se, tune_mm_mlp_adapter=tune,
+                                        pretrain_mm_mlp_adapter=adapters[adapter][0] if adapter else None)
+                rec = dict(dtype=tag, mm_use_im_patch_token=patch, mm_use_im_start_end=se, tune_mm_mlp_adapter=tune, adapter=adapter)
+                rg0 = (model.get_input_embeddings().weight.requires_grad, model.get_output_embeddings().weight.requires_grad)
+                try:
+                    model.initialize_vision_tokenizer(margs, tk)
+                    rec["error"] = None
+                except Exception as e:
+                    rec["error"] = type(e).__name__
+                ie, oe = model.get_input_embeddings().weight, model.get_output_embeddings().weight
+                n_new = len(tk) - 512
+                rec.update(len_tokenizer=len(tk), added=list(tk.added), embed_shape=list(ie.shape), lm_head_shape=list(oe.shape),
+                           requires_grad_before=list(rg0), requires_grad=[ie.requires_grad, oe.requires_grad],
+                           old_rows_unchanged=bool(torch.equal(ie.data[:512].float(), sd["model.embed_tokens.weight"].to(dt).float())
+                                                   and torch.equal(oe.data[:512].float(), sd["lm_head.weight"].to(dt).float())),
+                           config_vocab_size=int(model.config.vocab_size))
+                # the start / end rows are deterministic (mean of the old rows, or adapter rows) unless a patch-token row -- random in the
+                # reference too (HF's resize draws it) -- was appended first and entered that mean
+                n_det = 2 if (se and n_new >= 2 and not patch) else 0
+                rec["new_embed_rows"] = ie.data[ie.shape[0] - n_det:].float().tolist() if n_det else []
+                rec["new_lm_head_rows"] = oe.data[oe.shape[0] - n_det:].float().tolist() if n_det else []
+                vt.append(rec)
+        # the test regenerates the adapter rows: default_rng(52).standard_normal((rows, hidden), float32) for rows = 514, 2, 7 in this order
+        out["adapter_rows_sum"] = {k: float(v[1].double().sum()) for k, v in adapters.items()}
+    out["vision_tokenizer"] = vt
+    out["seed"] = 51
+    with open(os.path.join(OUT, "surface.json"), "w") as f:
+        json.dump(out, f)
+    print(f"  wrote surface.json: {len(names)} names, {len(stop_cases)} stopping cases ({sum(c['stop'] for c in stop_cases)} stop), "
+          f"{len(vt)} tokenizer cases; errors {[c['error'] for c in vt if c['error']]}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:
