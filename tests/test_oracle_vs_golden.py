@@ -128,7 +128,8 @@ def head_variant(g):
     """normalize_vision / apply_softmax of an e2e fixture (A8: cosine, mean-abs and soft-CE heads)."""
     return dict(normalize_vision=bool(int(g["normalize_vision"])), apply_softmax=bool(int(g["apply_softmax"])),
                 tokenizer_padding_side="left" if int(g["left"]) else "right", mm_projector_type=str(g["mm_projector_type"]),
-                image_token_reduction=str(g["image_token_reduction"]))
+                image_token_reduction=str(g["image_token_reduction"]),
+                **({"vision_head_type": str(g["vision_head_type"])} if "vision_head_type" in g else {}))
 
 
 def _grad_summary(t):
