@@ -270,6 +270,28 @@ def gen_a3():
                      features=feat, projected=proj[:, :, ::4], target=tgt[:, :, ::16])
 
 
+def gen_a3sel():
+    """Two more branches of `SiglipVisionTower.forward` (siglip_encoder.py:129-150): `mm_vision_select_layer = -2` (hidden_states[-2] = the
+    output of the encoder layer before the last) and `num_image_tokens = -1` (the tower returns ZEROS of the un-reduced shape)."""
+    cfg = tiny_cfg(num_image_tokens=4, v_layers=3)
+    sd = init_state_dict(cfg, seed=23)
+    rng = np.random.default_rng(24)
+    images = torch.from_numpy(rng.standard_normal((2, 3, 56, 56), dtype=np.float32))
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        model = build_reference(cfg, sd, dt)
+        tower = model.get_model().vision_tower
+        with torch.no_grad():
+            tower.select_layer = -2
+            hs = tower.vision_tower(images.to(dt), output_hidden_states=True).hidden_states
+            feat = tower(images.to(dt))
+            tower.select_layer = -1
+            tower.image_token_len = -1
+            zeros = tower(images.to(dt))
+        assert not torch.equal(hs[-2], hs[-1])
+        save_npz(f"a3sel_tower_{tag}.npz", images=images, seed=np.int64(23), raw_hidden_m2=hs[-2][:, :, ::8], features_m2=feat,
+                 tokens_minus1=zeros[:, :, ::64], tokens_minus1_shape=np.array(zeros.shape), tokens_minus1_absmax=zeros.abs().max())
+
+
 # ----------------------------------------------------------------------------- per-op (v)
 
 def gen_ops():

@@ -645,6 +645,32 @@ def test_tower_output_matches_reference_recorded(Timg):
     assert float((n - 1).abs().max()) < 1e-2                       # normalize_vision
 
 
+def test_tower_select_layer_and_zero_token_branches_match_reference_recorded():
+    """tests/golden/a3sel_tower_*.npz: `mm_vision_select_layer = -2` on a 3-layer tower (hidden_states[-2], siglip_encoder.py:129-131) and
+    `num_image_tokens = -1` (zeros of the un-reduced shape, :146-148), as the reference's tower returned them."""
+    g16, g32 = (np.load(os.path.join(GOLDEN, f"a3sel_tower_{t}.npz")) for t in ("bf16", "f32"))
+    cfg = tiny_cfg(num_image_tokens=4, v_layers=3)
+    model = hip_model(cfg, init_state_dict(cfg, seed=int(g16["seed"]), dtype=torch.bfloat16)).eval()
+    images = T(g16["images"]).to(DEV).bfloat16()
+    tower = model.get_model().vision_tower
+    with torch.no_grad():
+        tower.select_layer = -2
+        raw = tower.vision_tower.forward_features(images, tower.select_layer)
+        feat = tower(images)
+        last = tower.vision_tower.forward_features(images, -1)
+        tower.select_layer, tower.image_token_len = -1, -1
+        zeros = tower(images)
+    assert not torch.equal(raw, last)
+    for name, got, key in (("hidden_states[-2]", raw[:, :, ::8], "raw_hidden_m2"), ("features", feat, "features_m2")):
+        e_hip, e_ref = rel(got, T(g32[key])), rel(T(g16[key]), T(g32[key]))
+        print(f"\n   tower select_layer=-2 {name}: rel err vs reference fp32 hip={e_hip:.3e} reference-bf16={e_ref:.3e}")
+        assert got.shape == tuple(g32[key].shape)
+        assert e_hip <= max(1.5 * e_ref, 4e-3), (name, e_hip, e_ref)
+    assert list(zeros.shape) == g32["tokens_minus1_shape"].tolist() and zeros.dtype == torch.bfloat16 and float(zeros.abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        tower.vision_tower.forward_features(images, -5)          # 3 layers: hidden_states has 4 entries
+
+
 # ------------------------------------------------------------------ BASELINE configs[0] at its real widths
 def _fullwidth_check(cfg, ids, labels, mask, images, seed, *, grad_tol, hidden_tol, what, check_embed_grad=True):
     """HIP model (bf16) vs the CPU oracle in fp32 on the SAME bf16-rounded weights: integer outputs bit-exact, loss, valid hidden

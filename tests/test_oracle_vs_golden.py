@@ -122,6 +122,23 @@ def test_a3_tower(Timg, tag):
         torch.testing.assert_close(proj[:, :, ::4].float(), T(g["projected"]), **tolf)
 
 
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_a3_tower_select_layer_minus_2(tag):
+    """`mm_vision_select_layer = -2` (siglip_encoder.py:129-131): hidden_states[-2] of a 3-layer tower = the oracle's tower cut after layer 2;
+    `num_image_tokens = -1` returns zeros of the un-reduced shape (:146-148)."""
+    g = np.load(os.path.join(GOLDEN, f"a3sel_tower_{tag}.npz"))
+    dt = DT[tag]
+    sd = init_state_dict(tiny_cfg(num_image_tokens=4, v_layers=3), seed=int(g["seed"]), dtype=dt)
+    cfg = tiny_cfg(num_image_tokens=4, v_layers=2)               # layers 0 and 1 of the same state dict
+    images = T(g["images"]).to(dt)
+    tol = dict(rtol=1e-4, atol=2e-5) if tag == "f32" else dict(rtol=5e-2, atol=3e-2)
+    with torch.no_grad():
+        torch.testing.assert_close(siglip_hidden(sd, cfg, images)[:, :, ::8].float(), T(g["raw_hidden_m2"]), **tol)
+        tolf = dict(rtol=1e-4, atol=1e-5) if tag == "f32" else dict(rtol=5e-2, atol=4e-3)
+        torch.testing.assert_close(vision_features(sd, cfg, images).float(), T(g["features_m2"]), **tolf)
+    assert float(g["tokens_minus1_absmax"]) == 0.0 and g["tokens_minus1_shape"].tolist() == [2, 16, 1152]
+
+
 # ------------------------------------------------------------------ end to end
 
 def head_variant(g):
