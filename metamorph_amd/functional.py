@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -984,6 +985,39 @@ class SpliceFn(Function):
             ops.embed_grad_(buf, dout, plan["emb_tok"], plan["emb_seg"], plan["emb_pos"], True)
             commit_grad(w, buf)
         return None, dproj, None, None
+
+
+class EmbeddingFn(Function):
+    """Plain `embed_tokens(ids)` WITH a gradient: the text-only training path (forward(images=None): the reference's splice returns early,
+    metamorph_arch.py:184-191, and HF's LlamaModel embeds the ids itself).  Backward = the splice's deterministic segmented row sum
+    (`mm355_embed_grad`: rows sorted by token id on the host, one D2H copy of the ids -- this is not the hot path)."""
+
+    @staticmethod
+    def forward(ctx, embed_weight, embed_module, ids):
+        ctx.embed_module = embed_module
+        ctx.ids = ids
+        flat = ids.reshape(-1).to(torch.int32)
+        out = ops.splice_gather(embed_weight, None, flat, embed_weight.shape[1])
+        return out.view(*ids.shape, embed_weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        w = ctx.embed_module.weight
+        if w.requires_grad:
+            flat = ctx.ids.reshape(-1).detach().cpu().numpy().astype(np.int64)
+            order = np.argsort(flat, kind="stable")
+            sorted_tok = flat[order]
+            starts = np.flatnonzero(np.concatenate(([True], sorted_tok[1:] != sorted_tok[:-1])))
+            dev = dout.device
+            tok = torch.from_numpy(sorted_tok[starts].astype(np.int32)).to(dev)
+            seg = torch.from_numpy(np.concatenate((starts, [sorted_tok.size])).astype(np.int32)).to(dev)
+            pos = torch.from_numpy(order.astype(np.int32)).to(dev)
+            buf, acc = grad_target(w)
+            if not acc:
+                buf.zero_()
+            ops.embed_grad_(buf, dout.reshape(-1, dout.shape[-1]).contiguous(), tok, seg, pos, True)
+            commit_grad(w, buf)
+        return None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

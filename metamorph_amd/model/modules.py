@@ -84,8 +84,11 @@ class HipEmbedding(nn.Module):
         nn.init.normal_(self.weight, std=0.02)
 
     def forward(self, ids):
-        """Plain lookup (inference paths); training goes through the splice plan."""
+        """Plain lookup.  Multimodal training goes through the splice plan; a direct call under autograd (text-only batches,
+        forward(images=None)) gets its gradient from `EmbeddingFn`."""
         _require_bf16(self.weight, "HipEmbedding")
+        if torch.is_grad_enabled() and self.weight.requires_grad and ids.numel() > 0:
+            return F.EmbeddingFn.apply(self.weight, self, ids)
         flat = ids.reshape(-1).to(torch.int32)
         out = ops.splice_gather(self.weight.data, None, flat, self.embedding_dim)
         return out.view(*ids.shape, self.embedding_dim)

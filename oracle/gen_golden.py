@@ -1056,6 +1056,35 @@ def gen_surface():
           f"{len(vt)} tokenizer cases; errors {[c['error'] for c in vt if c['error']]}")
 
 
+def gen_textonly():
+    """forward(images=None): `prepare_inputs_labels_for_multimodal` returns early (metamorph_arch.py:184-191), the decoder embeds the ids itself,
+    `image_positions` is None so the image-AR block is skipped (metamorph_llama.py:333, 420): loss = CE alone, `loss_language` / `loss_image_ar`
+    are not touched.  Right-padded batch of two rows, labels on the tail of each."""
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=61)
+    rng = np.random.default_rng(62)
+    rows = [[128000] + rng.integers(3, 127000, 11).tolist(), [128000] + rng.integers(3, 127000, 6).tolist()]
+    labs = [[-100] * 5 + rows[0][5:], [-100] * 3 + rows[1][3:]]
+    ids_t, lab_t = torch.tensor(pad_rows(rows, 128001)), torch.tensor(pad_rows(labs, -100))
+    msk_t = ids_t.ne(128001)
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        model = build_reference(cfg, sd, dt)
+        for n, p in model.named_parameters():
+            p.requires_grad_("vision_tower" not in n)
+        out = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=None)
+        rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, seed=np.int64(61), loss=out.loss.detach().float(),
+                   logits_sub=out.logits[:, :, ::997], hidden=out.hidden_states, logits_shape=np.array(out.logits.shape),
+                   has_loss_language=np.int64(hasattr(model, "loss_language")))
+        out.loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                rec["grad::" + n] = grad_summary(p.grad)
+        rec["params_without_grad"] = np.array(sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None))
+        save_npz(f"r3_textonly_{tag}.npz", **rec)
+        print(f"    {tag}: loss {float(out.loss):.6f}, {sum(k.startswith('grad::') for k in rec)} gradients, no gradient for {rec['params_without_grad'].tolist()}, "
+              f"has loss_language attr: {hasattr(model, 'loss_language')}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

@@ -259,6 +259,9 @@ def heads(sd, cfg: OracleConfig, hid, lab, img_pos, target, return_logits=True, 
             out["loss"] = None
             return out
         ce = ops.shifted_cross_entropy(logits, lab, IGNORE_INDEX)
+    if img_pos is None:                                         # no images given: the image-AR block is skipped altogether (:333, :420)
+        out["loss"] = ce
+        return out
     # rows of hidden[:, :-1] whose NEXT position is an answer-image row (metamorph_llama.py:386-390,425-432)
     sel = img_pos[:, 1:].bool()
     pred_in = hid[:, :-1][sel]                                  # [R,h], row-major (b,t) order
@@ -289,6 +292,16 @@ def heads(sd, cfg: OracleConfig, hid, lab, img_pos, target, return_logits=True, 
 
 def forward(sd, cfg: OracleConfig, input_ids, attention_mask, labels, images, return_logits=True, train_vision=False,
             ce_rows_only=False, image_embeds=None):
+    if images is None and image_embeds is None:
+        # prepare_inputs_labels_for_multimodal returns its inputs untouched (metamorph_arch.py:184-191): plain LLaMA forward over the padded
+        # ids with the caller's mask, no image bookkeeping
+        x = sd["model.embed_tokens.weight"][input_ids]
+        key_valid = attention_mask.bool() if attention_mask is not None else torch.ones_like(input_ids, dtype=torch.bool)
+        hid = llama_decoder(sd, cfg, x, key_valid, None)
+        out = {"hidden_states": hid, "labels": labels, "attention_mask": key_valid, "image_positions": None, "target_features": None,
+               "inputs_embeds": x}
+        out.update(heads(sd, cfg, hid, labels, None, None, return_logits, ce_rows_only))
+        return out
     if image_embeds is not None:                               # `encode_imagesembed` (metamorph_arch.py:166-173): features given, no tower
         feat = image_embeds
     else:

@@ -671,6 +671,38 @@ def test_tower_select_layer_and_zero_token_branches_match_reference_recorded():
         tower.vision_tower.forward_features(images, -5)          # 3 layers: hidden_states has 4 entries
 
 
+def test_text_only_forward_without_images_matches_reference_recorded():
+    """forward(images=None) (r3_textonly_*.npz, recorded from the reference): the splice returns early (metamorph_arch.py:184-191), loss = CE
+    alone, no gradient reaches the projector / vision head."""
+    g, g32 = (np.load(os.path.join(GOLDEN, f"r3_textonly_{t}.npz")) for t in ("bf16", "f32"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
+    model.train()
+    ids, lab, msk = T(g["input_ids"]).to(DEV), T(g["labels"]).to(DEV), T(g["attention_mask"]).to(DEV)
+    out = model(input_ids=ids, attention_mask=msk, labels=lab, images=None)
+    got, ref16, truth = float(out.loss.detach()), float(g["loss"]), float(g32["loss"])
+    valid = T(g["attention_mask"]).bool()
+    e_h, e_r = rel(out.hidden_states.float().cpu()[valid], T(g32["hidden"])[valid]), rel(T(g["hidden"])[valid], T(g32["hidden"])[valid])
+    print(f"\n   text only, images=None: loss hip={got:.6f} reference bf16={ref16:.6f} fp32={truth:.6f}; hidden rel err hip={e_h:.3e} reference-bf16={e_r:.3e}")
+    assert abs(got - truth) <= 1e-3 * abs(truth) and abs(got - ref16) <= 1e-3 * abs(ref16)
+    assert e_h <= max(1.5 * e_r, 1.2e-2)
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    for n in g["params_without_grad"].tolist():
+        assert params[n].grad is None or float(params[n].grad.float().abs().max()) == 0.0, n
+    worst = 0.0
+    for k in g32.files:
+        if k.startswith("grad::"):
+            got_g = grad_summary(params[k[6:]].grad)
+            nz = int((T(g32[k])[1:] != 0).sum())
+            if nz > 4:
+                e = rel(got_g[1:], T(g32[k])[1:])
+                worst = max(worst, e)
+                assert e <= max(3.0 * rel(T(g[k])[1:], T(g32[k])[1:]), 3.3e-2), (k, e)
+            assert abs(float(got_g[0]) - float(g32[k][0])) <= 3e-2 * float(g32[k][0]), k
+    print(f"   gradients: worst rel err vs reference fp32 {worst:.3e}")
+
+
 # ------------------------------------------------------------------ BASELINE configs[0] at its real widths
 def _fullwidth_check(cfg, ids, labels, mask, images, seed, *, grad_tol, hidden_tol, what, check_embed_grad=True):
     """HIP model (bf16) vs the CPU oracle in fp32 on the SAME bf16-rounded weights: integer outputs bit-exact, loss, valid hidden

@@ -270,3 +270,30 @@ def test_oracle_image_embeds_and_pretraining_tp_match_reference(kind):
             assert torch.allclose(got, T(k), atol=1e-6, rtol=2e-3), k
             n += 1
     assert n >= 25
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_text_only_forward_without_images(tag):
+    """forward(images=None) as the reference ran it (r3_textonly_*.npz): early return of the splice, CE alone, no gradient for the projector /
+    vision head, `loss_language` never set."""
+    g = np.load(os.path.join(GOLDEN, f"r3_textonly_{tag}.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    dt = DT[tag]
+    sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=dt)
+    for k, v in sd.items():
+        v.requires_grad_("vision_tower" not in k)
+    out = forward(sd, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), None)
+    tol = 2e-5 if tag == "f32" else 5e-3
+    assert abs(float(out["loss"]) - float(g["loss"])) < tol * float(g["loss"])
+    assert list(out["logits"].shape) == g["logits_shape"].tolist() and "loss_language" not in out and int(g["has_loss_language"]) == 0
+    valid = T(g["attention_mask"]).bool()
+    # padded rows: the reference's SDPA output there depends on its mask fill value; the loss never reads them
+    torch.testing.assert_close(out["hidden_states"].float()[valid], T(g["hidden"])[valid], rtol=1e-4 if tag == "f32" else 5e-2, atol=2e-5 if tag == "f32" else 5e-2)
+    torch.testing.assert_close(out["logits"][:, :, ::997].float()[valid], T(g["logits_sub"])[valid], rtol=1e-4 if tag == "f32" else 5e-2, atol=5e-5 if tag == "f32" else 5e-2)
+    out["loss"].backward()
+    no_grad = sorted(k for k, v in sd.items() if v.requires_grad and v.grad is None)
+    assert no_grad == g["params_without_grad"].tolist()
+    if tag == "f32":
+        for k in g.files:
+            if k.startswith("grad::"):
+                torch.testing.assert_close(_grad_summary(sd[k[6:]].grad), T(g[k]), rtol=2e-4, atol=2e-6)
