@@ -99,7 +99,12 @@ def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_p
                     raise IndexError("index -1 is out of bounds for dimension 0 with size 0 "
                                      "(an <image> sentinel with no token before it; reference metamorph_arch.py:317)")
                 answer = int(seg_lab[-1]) == image_start_id
-                if max_length is not None and cur_len + T > max_length:
+                if max_length is None:
+                    # a config without `tokenizer_model_max_length` only survives text-only batches in the reference: the overflow test
+                    # compares against None (metamorph_arch.py:271, 324)
+                    raise TypeError("'>' not supported between instances of 'int' and 'NoneType' (config.tokenizer_model_max_length is not "
+                                    "set and a sample holds an <image>; reference metamorph_arch.py:324)")
+                if cur_len + T > max_length:
                     stopped = True
                     placeholder.append(img)
                 else:

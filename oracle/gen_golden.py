@@ -206,19 +206,28 @@ def gen_a5():
     sd = init_state_dict(cfg, seed=11)
     rng = np.random.default_rng(5)
     pad_id = 128001
-    for name, ids, labs, T, max_len, side in a5_cases():
+
+    def record(name, ids, labs, T, max_len, side, use_labels=True, use_mask=True, pos=None, pad_rows_with=pad_id):
         cfg.num_image_tokens = T
         cfg.tokenizer_model_max_length = max_len
         cfg.tokenizer_padding_side = side
         model = build_reference(cfg, sd, torch.float32)
+        if max_len is None:                                   # a config without the attribute: no truncation, no overflow rule (:271)
+            del model.config.tokenizer_model_max_length
         n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
-        ids_t = torch.tensor(pad_rows(ids, pad_id))
+        ids_t = torch.tensor(pad_rows(ids, pad_rows_with))
         lab_t = torch.tensor(pad_rows(labs, -100))
         msk_t = ids_t.ne(pad_id)
+        pos_t = None if pos is None else torch.tensor(pos)
         with torch.no_grad():
             proj, feat = model.encode_images(images)
-            out = model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images)
+            try:
+                out = model.prepare_inputs_labels_for_multimodal(ids_t, pos_t, msk_t if use_mask else None, None, lab_t if use_labels else None, images)
+            except TypeError as e:                            # known answer: no tokenizer_model_max_length + an image -> `int > None` (:324)
+                save_npz(f"a5_{name}.npz", input_ids=ids_t, labels=lab_t, attention_mask=msk_t, rows_per_image=np.int64(T), max_length=np.int64(-1),
+                         left=np.int64(side == "left"), num_images=np.int64(n_img), error=np.array(type(e).__name__))
+                return
         _, pos_ids, att, _, emb, new_lab, img_pos, tgt = out
         # derive, from the reference's own output, where every spliced row came from
         W = model.get_model().embed_tokens.weight.detach()
@@ -226,11 +235,11 @@ def gen_a5():
         B, L, _ = emb.shape
         src = np.full((B, L), -1, dtype=np.int64)
         for b in range(B):
-            toks = [t for t in ids[b] if t >= 0]
+            toks = [t for t in ids_t[b].tolist() if t >= 0]
             for l in range(L):
                 row = emb[b, l]
-                if not att[b, l]:
-                    assert torch.count_nonzero(row) == 0
+                if torch.count_nonzero(row) == 0:             # padding rows (zero embeddings)
+                    assert att is None or not att[b, l]
                     continue
                 hit = (flat_proj == row).all(dim=1).nonzero()
                 if len(hit):
@@ -244,11 +253,43 @@ def gen_a5():
             hit = [i for i in range(feat.shape[0]) if torch.equal(feat[i], tgt[r])]
             assert len(hit) == 1
             keep.append(hit[0])
-        save_npz(f"a5_{name}.npz", input_ids=ids_t, labels=lab_t, attention_mask=msk_t,
-                 rows_per_image=np.int64(T), max_length=np.int64(max_len), left=np.int64(side == "left"),
-                 num_images=np.int64(n_img), out_src=src, out_labels=new_lab, out_attention_mask=att,
-                 out_image_positions=img_pos, out_position_ids_is_none=np.int64(pos_ids is None),
-                 out_target_keep=np.array(keep, dtype=np.int64))
+        if use_labels and use_mask and pos is None and max_len is not None:     # the original seven cases: same keys, same order as before
+            rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t,
+                       rows_per_image=np.int64(T), max_length=np.int64(max_len), left=np.int64(side == "left"),
+                       num_images=np.int64(n_img), out_src=src, out_labels=new_lab, out_attention_mask=att,
+                       out_image_positions=img_pos, out_position_ids_is_none=np.int64(pos_ids is None),
+                       out_target_keep=np.array(keep, dtype=np.int64))
+        else:
+            rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t,
+                       rows_per_image=np.int64(T), max_length=np.int64(max_len if max_len is not None else -1), left=np.int64(side == "left"),
+                       num_images=np.int64(n_img), out_src=src, out_image_positions=img_pos, out_position_ids_is_none=np.int64(pos_ids is None),
+                       out_target_keep=np.array(keep, dtype=np.int64))
+            rec.update(labels_given=np.int64(use_labels), mask_given=np.int64(use_mask), out_labels_is_none=np.int64(new_lab is None),
+                       out_mask_is_none=np.int64(att is None), out_shape=np.array(emb.shape[:2]))
+            if new_lab is not None:
+                rec["out_labels"] = new_lab
+            if att is not None:
+                rec["out_attention_mask"] = att
+                rec["out_attention_mask_dtype"] = np.array(str(att.dtype))
+            if pos is not None:
+                rec["position_ids"] = pos_t
+                rec["out_position_ids"] = pos_ids
+        save_npz(f"a5_{name}.npz", **rec)
+
+    for name, ids, labs, T, max_len, side in a5_cases():
+        record(name, ids, labs, T, max_len, side)
+    # the wrapper's None handling (metamorph_arch.py:245-256, 400-412), recorded after the original cases (same image stream, their files unchanged)
+    base = a5_cases()[0]
+    nopad = ([[128000, 128000, 11, ST, IM, EN, 13, 14], [128000, 21, 22, 23, ST, IM, EN, 128009]],
+             [[-100] * 6 + [13, 14], [-100] * 4 + [ST, IM, EN, 128009]])
+    record("wrap_nolabels", base[1], base[2], 4, 64, "right", use_labels=False)                   # inference: labels None -> None back
+    record("wrap_nomask", nopad[0], nopad[1], 4, 64, "right", use_mask=False)                     # attention_mask None -> None back
+    record("wrap_nomask_padded", base[1], base[2], 4, 64, "right", use_mask=False)                # ... and pad ids are then EMBEDDED like any token
+    pos = [list(range(7, 7 + len(pad_rows(base[1], pad_id)[0])))] * 3
+    record("wrap_position_ids", base[1], base[2], 4, 64, "right", pos=pos)                        # given position_ids are REPLACED by arange per sample
+    record("wrap_position_ids_left", base[1], base[2], 4, 64, "left", pos=pos)
+    record("wrap_no_max_length", a5_cases()[3][1], a5_cases()[3][2], 16, None, "right")           # no tokenizer_model_max_length + images: the reference raises
+    record("wrap_no_max_length_text", [[128000, 5, 6, 7], [128000, 8]], [[-100, 5, 6, 7], [-100, 8]], 4, None, "right")   # ... text-only rows never reach that line
 
 
 # ----------------------------------------------------------------------------- A3 tower

@@ -83,7 +83,9 @@ def splice_bookkeeping(input_ids, labels, attention_mask, num_images_total, rows
                 cur_pos.extend([0] * len(seg_ids[i]))
             if i < n_img:
                 answer = seg_lab[i][-1] == image_start_id      # IndexError on empty segment
-                if max_length is not None and len(cur_src) + rows_per_image > max_length:
+                if max_length is None:                         # :324 compares against None: `int > NoneType`
+                    raise TypeError("'>' not supported between instances of 'int' and 'NoneType'")
+                if len(cur_src) + rows_per_image > max_length:
                     stop = True
                     placeholder.append(img)
                 else:

@@ -67,20 +67,43 @@ def test_prepare_inputs_matches_reference(path):
     g = np.load(path)
     Timg = int(g["rows_per_image"])
     left = bool(int(g["left"]))
-    cfg = tiny_cfg(hidden_size=32, intermediate_size=64, num_image_tokens=Timg, tokenizer_model_max_length=int(g["max_length"]),
+    max_len = int(g["max_length"]) if int(g["max_length"]) >= 0 else None
+    cfg = tiny_cfg(hidden_size=32, intermediate_size=64, num_image_tokens=Timg, tokenizer_model_max_length=max_len,
                    tokenizer_padding_side="left" if left else "right")
     sd = init_state_dict(cfg, seed=11, dtype=torch.bfloat16)
     model = hip_model(cfg, sd)
+    if max_len is None:
+        model.config.tokenizer_model_max_length = None
     N = int(g["num_images"])
     images = torch.randn(N, 3, 56, 56, generator=torch.Generator().manual_seed(5))
     ids, lab, msk = T(g["input_ids"]).to(DEV), T(g["labels"]).to(DEV), T(g["attention_mask"]).to(DEV)
+    # a5_wrap_*: the wrapper's None handling (reference metamorph_arch.py:245-256, 400-412)
+    if "labels_given" in g.files and not int(g["labels_given"]):
+        lab = None
+    if "mask_given" in g.files and not int(g["mask_given"]):
+        msk = None
+    pos_in = T(g["position_ids"]).to(DEV) if "position_ids" in g.files else None
     with torch.no_grad():
         proj, feat = model.encode_images(images.to(DEV))
-        out = model.prepare_inputs_labels_for_multimodal(ids, None, msk, None, lab, images.to(DEV))
+        if "error" in g.files:                                # no tokenizer_model_max_length + an image: TypeError in the reference (:324)
+            with pytest.raises(TypeError):
+                model.prepare_inputs_labels_for_multimodal(ids, pos_in, msk, None, lab, images.to(DEV))
+            return
+        out = model.prepare_inputs_labels_for_multimodal(ids, pos_in, msk, None, lab, images.to(DEV))
     none_ids, pos_ids, att, _, emb, new_lab, img_pos, tgt = out
-    assert none_ids is None and pos_ids is None
-    assert torch.equal(new_lab.cpu(), T(g["out_labels"]))
-    assert torch.equal(att.cpu(), T(g["out_attention_mask"]))
+    assert none_ids is None
+    if "out_position_ids" in g.files:                         # given position_ids come back REPLACED by arange over each sample's rows
+        assert torch.equal(pos_ids.cpu(), T(g["out_position_ids"])) and pos_ids.dtype == torch.int64
+    else:
+        assert pos_ids is None
+    if "out_labels" in g.files:
+        assert torch.equal(new_lab.cpu(), T(g["out_labels"]))
+    else:
+        assert new_lab is None
+    if "out_attention_mask" in g.files:
+        assert torch.equal(att.cpu(), T(g["out_attention_mask"])) and att.dtype == torch.bool
+    else:
+        assert att is None
     assert torch.equal(img_pos.cpu(), T(g["out_image_positions"]))
     keep = g["out_target_keep"].tolist()
     assert tgt.shape[0] == len(keep)

@@ -45,17 +45,30 @@ def test_a1_tokenizer_image_token():
 def test_a5_splice_bookkeeping(path):
     g = np.load(path)
     Timg = int(g["rows_per_image"])
-    plan = splice_bookkeeping(g["input_ids"].tolist(), g["labels"].tolist(), g["attention_mask"].tolist(),
-                              int(g["num_images"]), Timg, int(g["max_length"]),
-                              "left" if int(g["left"]) else "right")
+    labels = g["labels"].tolist() if ("labels_given" not in g.files or int(g["labels_given"])) else None       # a5_wrap_*: None handling
+    mask = g["attention_mask"].tolist() if ("mask_given" not in g.files or int(g["mask_given"])) else None
+    args = (g["input_ids"].tolist(), labels, mask, int(g["num_images"]), Timg, int(g["max_length"]) if int(g["max_length"]) >= 0 else None,
+            "left" if int(g["left"]) else "right")
+    if "error" in g.files:
+        with pytest.raises(TypeError):
+            splice_bookkeeping(*args)
+        return
+    plan = splice_bookkeeping(*args)
     src = [[-1 if s is None else (-2 - (s[1] * Timg + s[2]) if isinstance(s, tuple) else s) for s in row]
            for row in plan["src"]]
     assert np.array_equal(np.array(src), g["out_src"])
-    assert np.array_equal(np.array(plan["labels"]), g["out_labels"])
-    assert np.array_equal(np.array(plan["attention_mask"]), g["out_attention_mask"])
+    if "out_labels" in g.files:
+        assert np.array_equal(np.array(plan["labels"]), g["out_labels"])
+    else:
+        assert plan["labels"] is None
+    if "out_attention_mask" in g.files:
+        assert np.array_equal(np.array(plan["attention_mask"]), g["out_attention_mask"])
     assert np.array_equal(np.array(plan["image_positions"]), g["out_image_positions"])
     assert plan["target_keep"] == g["out_target_keep"].tolist()
-    assert int(g["out_position_ids_is_none"]) == 1
+    if "out_position_ids" in g.files:
+        assert int(g["out_position_ids_is_none"]) == 0 and np.array_equal(np.array(plan["position_ids"]), g["out_position_ids"])
+    else:
+        assert int(g["out_position_ids_is_none"]) == 1
 
 
 # ------------------------------------------------------------------ per-op
