@@ -726,6 +726,16 @@ def gen_decode():
             assert float(logits[t][128009]) < float(logits[t].max()) - 0.3        # argmax returns first, so it can never be emitted)
         toks16, emb16, _, logits16 = run(rows, torch.bfloat16)
         assert toks16 == toks
+        # `max_new_tokens` cuts the loop after max_new + 1 iterations, image-mode iterations included (:587-590): 2 -> <image_start> + two
+        # continuous tokens, 6 -> through <image_end> and the first text token
+        cut = {}
+        for mn in (2, 6):
+            t_m, e_m, _, l_m = run(rows, torch.float32, max_new=mn)
+            cut[f"tokens_max{mn}"] = np.array(t_m, dtype=np.int64)
+            cut[f"n_pred_z_max{mn}"] = np.int64(e_m.shape[0])
+            cut[f"iterations_max{mn}"] = np.int64(len(l_m))
+            assert e_m.shape[0] == 0 or torch.equal(e_m, emb[:e_m.shape[0]])
+        print(f"    {name}: cut runs { {k: v.tolist() for k, v in cut.items()} }")
         save_npz(f"n1_decode_{name}.npz", seed=np.int64(seed), input_ids=ids_t,
                  images=images if images is not None else torch.zeros(0), active=np.array(DECODE_ACTIVE, dtype=np.int64),
                  row_tokens=np.array(list(rows.keys()), dtype=np.int64), row_values=torch.stack(list(rows.values())),
@@ -734,7 +744,7 @@ def gen_decode():
                  step_argmax=np.array([int(t.indices[0]) for t in top2], dtype=np.int64),
                  active_logits=torch.stack([l[DECODE_ACTIVE] for l in logits]),
                  active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]),
-                 pred_z=emb, pred_z_bf16=emb16, max_new_tokens=np.int64(12))
+                 pred_z=emb, pred_z_bf16=emb16, max_new_tokens=np.int64(12), **cut)
         print(f"    {name}: seed {seed} tokens {toks} min decision margin {float(margins[decision].min()):.3f} "
               f"pred_z bf16-vs-f32 rel {float((emb16 - emb).norm() / emb.norm()):.3e}")
 

@@ -508,6 +508,14 @@ def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
     assert e_hip <= max(1.5 * e_ref, 1.2e-2)                       # measured 7.6e-3 .. 8.3e-3 (reference-bf16 7.9e-3 .. 8.2e-3)
     for r in range(emb.shape[0]):                                   # every image-mode step, not only the average
         assert rel(emb[r], T(g["pred_z"])[r]) <= max(3.0 * e_ref, 2e-2), r
+    # `max_new_tokens` ends the loop after max_new + 1 iterations, image-mode iterations included (reference :587-590): 2 stops inside the
+    # image (one id, two pred_z rows), 6 after <image_end> and one text token; `output_image=False` returns the id list alone
+    for mn in (2, 6):
+        o_m, e_m = model.generate(inputs=T(g["input_ids"]).to(DEV), images=images, output_image=True, max_new_tokens=mn, use_cache=use_cache)
+        assert o_m[0].tolist() == g[f"tokens_max{mn}"].tolist() and e_m.shape[0] == int(g[f"n_pred_z_max{mn}"]), (mn, o_m[0].tolist(), e_m.shape)
+        assert e_m.shape[0] == 0 or torch.equal(e_m, emb[:e_m.shape[0]])
+    only = model.generate(inputs=T(g["input_ids"]).to(DEV), images=images, max_new_tokens=2, use_cache=use_cache)
+    assert isinstance(only, list) and len(only) == 1 and only[0].tolist() == g["tokens_max2"].tolist()
 
 
 @pytest.mark.parametrize("name", ["text", "image_prompt"])
