@@ -237,6 +237,9 @@ def test_n1_greedy_decode_matches_reference_loop(name):
     torch.testing.assert_close(pz, T(g["pred_z"]), rtol=1e-4, atol=1e-6)
     act = g["active"].tolist()
     torch.testing.assert_close(torch.stack([l[act] for l in logits]), T(g["active_logits"]), rtol=1e-4, atol=2e-5)
+    for mn in (2, 6):                                          # max_new_tokens counts image-mode iterations too (:587-590)
+        t_m, pz_m, l_m = greedy_decode(sd, cfg, T(g["input_ids"]), images, max_new_tokens=mn)
+        assert (t_m, pz_m.shape[0], len(l_m)) == (g[f"tokens_max{mn}"].tolist(), int(g[f"n_pred_z_max{mn}"]), int(g[f"iterations_max{mn}"]))
 
 
 def test_mean_abs_loss_row_mismatch_matches_reference():
