@@ -1136,6 +1136,44 @@ def gen_textonly():
               f"has loss_language attr: {hasattr(model, 'loss_language')}")
 
 
+def gen_optgroups():
+    """`MetaMorphTrainer.create_optimizer` (metamorph_trainer.py:154-245) run through a stub trainer: which parameter NAMES land in which
+    group (decay x {base lr, mm_projector_lr | vision_lr}), with the tower frozen and trainable.  `get_optimizer_cls_and_kwargs` is replaced by
+    plain torch AdamW (it needs real TrainingArguments); the grouping under test happens before that call."""
+    from types import SimpleNamespace
+    T, MT = _import_train()
+    import transformers
+    # transformers==4.45.0 (the reference's pin, pyproject.toml:16) registers LlamaRMSNorm as a layer-norm type when modeling_llama is imported
+    # (`ALL_LAYERNORM_LAYERS.append(LlamaRMSNorm)`), so RMSNorm weights get NO weight decay under the reference's own stack; the 5.x installed
+    # here dropped that line.  Re-create the pinned behaviour for this recording (and say so in the fixture).
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+    if LlamaRMSNorm not in MT.ALL_LAYERNORM_LAYERS:
+        MT.ALL_LAYERNORM_LAYERS.append(LlamaRMSNorm)
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=47)
+    out = []
+    orig = transformers.Trainer.get_optimizer_cls_and_kwargs
+    transformers.Trainer.get_optimizer_cls_and_kwargs = staticmethod(lambda args, model=None: (torch.optim.AdamW, dict(lr=1e-3)))
+    try:
+        for train_tower in (False, True):
+            for mm_lr, v_lr in ((None, None), (2e-5, None), (None, 2e-6), (2e-5, 2e-6)):
+                model = build_reference(cfg, sd, torch.float32)
+                for n, p in model.named_parameters():
+                    p.requires_grad_(train_tower or "vision_tower" not in n)
+                name_of = {id(p): n for n, p in model.named_parameters()}
+                stub = SimpleNamespace(model=model, optimizer=None, args=SimpleNamespace(weight_decay=0.05, mm_projector_lr=mm_lr, vision_lr=v_lr))
+                opt = MT.MetaMorphTrainer.create_optimizer(stub)
+                groups = [dict(weight_decay=g["weight_decay"], lr=g["lr"], names=[name_of[id(p)] for p in g["params"]]) for g in opt.param_groups]
+                out.append(dict(train_tower=train_tower, mm_projector_lr=mm_lr, vision_lr=v_lr, base_lr=1e-3, groups=groups))
+    finally:
+        transformers.Trainer.get_optimizer_cls_and_kwargs = orig
+    with open(os.path.join(OUT, "n4_optimizer_groups.json"), "w") as f:
+        json.dump({"note": "grouping by the reference's create_optimizer with LlamaRMSNorm registered in ALL_LAYERNORM_LAYERS as transformers==4.45.0 "
+                           "(the reference's pin) does at import", "cases": out}, f)
+    for c in out:
+        print("   ", c["train_tower"], c["mm_projector_lr"], c["vision_lr"], [(g["weight_decay"], g["lr"], len(g["names"])) for g in c["groups"]])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
     for w in which:

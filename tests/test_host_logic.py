@@ -600,3 +600,36 @@ def test_initialize_vision_tokenizer_matches_reference_recorded(tmp_path):
         elif c["mm_use_im_start_end"] and not c["error"]:         # after a (randomly initialised) patch-token row: the mean includes that row
             assert torch.equal(ie.data[-2:], ie.data[:-2].mean(dim=0, keepdim=True).expand(2, -1))
             assert torch.equal(oe.data[-2:], oe.data[:-2].mean(dim=0, keepdim=True).expand(2, -1))
+
+
+def test_optimizer_parameter_groups_match_reference_recorded():
+    """`MetaMorphTrainer.create_optimizer`'s grouping (reference metamorph_trainer.py:154-245) recorded from the reference on the same tiny
+    model, tower frozen and trainable, with `mm_projector_lr` / `vision_lr` (the former wins when both are set): same parameter names in the
+    same groups, same per-group lr / weight decay.  Norm weights (RMSNorm included, as under the reference's pinned transformers) and biases
+    are not decayed.  Empty groups are dropped here; the attention-pool `head.*` of the HF tower does not exist in this build."""
+    from metamorph_amd.factory import build_model
+    from metamorph_amd.trainer import optimizer_grouped_parameters
+    with open(os.path.join(GOLDEN, "n4_optimizer_groups.json")) as f:
+        cases = json.load(f)["cases"]
+    llm = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=128258,
+               rms_norm_eps=1e-5, rope_theta=500000.0)
+    geo = dict(hidden_size=1152, intermediate_size=144, num_hidden_layers=2, num_attention_heads=16, image_size=56, patch_size=14)
+    model = build_model(llm, geo, num_image_tokens=4, max_length=64)
+    mine = {n for n, _ in model.named_parameters()}
+    assert len(cases) == 8
+    for c in cases:
+        for n, p in model.named_parameters():
+            p.requires_grad_(c["train_tower"] or "vision_tower" not in n)
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        groups = optimizer_grouped_parameters(model, 0.05, c["mm_projector_lr"], c["vision_lr"])
+        got = [(g["weight_decay"], g.get("lr", c["base_lr"]), [name_of[id(p)] for p in g["params"]]) for g in groups]
+        want = []
+        for g in c["groups"]:
+            absent = [n for n in g["names"] if n not in mine]
+            assert all(".vision_tower.head." in n for n in absent), absent
+            names = [n for n in g["names"] if n in mine]
+            if names:
+                want.append((g["weight_decay"], g["lr"], names))
+        assert len(got) == len(want), (c, [len(x[2]) for x in got], [len(x[2]) for x in want])
+        for (wd_g, lr_g, n_g), (wd_w, lr_w, n_w) in zip(got, want):
+            assert (wd_g, lr_g) == (wd_w, lr_w) and n_g == n_w, (c["train_tower"], c["mm_projector_lr"], c["vision_lr"], set(n_g) ^ set(n_w))
