@@ -1101,6 +1101,27 @@ def gen_surface():
         out["adapter_rows_sum"] = {k: float(v[1].double().sum()) for k, v in adapters.items()}
     out["vision_tokenizer"] = vt
     out["seed"] = 51
+    # initialize_vision_modules (metamorph_arch.py:46-96): config side effects, projector un-frozen, vision_proj re-created, temperature_in
+    vm = []
+    for frozen, mtype in ((True, "mlp2x_gelu"), (False, "mlp2x_gelu")):
+        model = build_reference(cfg, sd, torch.float32)
+        inner = model.get_model()
+        for p in inner.mm_projector.parameters():
+            p.requires_grad_(not frozen)
+        old_proj = inner.vision_proj
+        t_before = inner.temperature_in
+        margs = SimpleNamespace(vision_tower="siglip/CLIP-ViT-SO400M-14-384", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                                pretrain_mm_mlp_adapter=None, mm_projector_type=mtype, mm_patch_merge_type="flat")
+        inner.vision_tower.load_model = lambda *a, **k: None      # the hub download cannot run offline; the tower is already built
+        inner.initialize_vision_modules(margs, fsdp=None)
+        c = model.config
+        vm.append(dict(projector_frozen_before=frozen, temperature_in_before=t_before, temperature_in=inner.temperature_in,
+                       vision_proj_is_new_object=inner.vision_proj is not old_proj, vision_proj_shape=list(inner.vision_proj.weight.shape),
+                       projector_requires_grad=[p.requires_grad for p in inner.mm_projector.parameters()],
+                       config={k: getattr(c, k) for k in ("mm_vision_tower", "use_mm_proj", "mm_projector_type", "mm_hidden_size", "mm_vision_select_layer",
+                                                          "mm_vision_select_feature", "mm_patch_merge_type")},
+                       tower_select_layer_attr=inner.vision_tower.select_layer))
+    out["vision_modules"] = vm
     with open(os.path.join(OUT, "surface.json"), "w") as f:
         json.dump(out, f)
     print(f"  wrote surface.json: {len(names)} names, {len(stop_cases)} stopping cases ({sum(c['stop'] for c in stop_cases)} stop), "

@@ -633,3 +633,29 @@ def test_optimizer_parameter_groups_match_reference_recorded():
         assert len(got) == len(want), (c, [len(x[2]) for x in got], [len(x[2]) for x in want])
         for (wd_g, lr_g, n_g), (wd_w, lr_w, n_w) in zip(got, want):
             assert (wd_g, lr_g) == (wd_w, lr_w) and n_g == n_w, (c["train_tower"], c["mm_projector_lr"], c["vision_lr"], set(n_g) ^ set(n_w))
+
+
+def test_initialize_vision_modules_side_effects_match_reference_recorded():
+    """metamorph_arch.py:46-96 as the reference ran it: config fields written, a frozen projector un-frozen, `vision_proj` re-created,
+    `temperature_in` 0.1 -> 1, and the ALREADY BUILT tower keeps its own `select_layer` (only the config takes the new value)."""
+    from types import SimpleNamespace
+    from metamorph_amd.factory import build_model
+    llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=512,
+               rms_norm_eps=1e-5, rope_theta=500000.0)
+    geo = dict(hidden_size=1152, intermediate_size=144, num_hidden_layers=2, num_attention_heads=16, image_size=56, patch_size=14)
+    for c in _surface()["vision_modules"]:
+        model = build_model(llm, geo, num_image_tokens=4, max_length=64)
+        inner = model.get_model()
+        for p in inner.mm_projector.parameters():
+            p.requires_grad_(not c["projector_frozen_before"])
+        old_proj = inner.vision_proj
+        assert inner.temperature_in == c["temperature_in_before"]
+        margs = SimpleNamespace(vision_tower=c["config"]["mm_vision_tower"], mm_vision_select_layer=c["config"]["mm_vision_select_layer"],
+                                mm_vision_select_feature=c["config"]["mm_vision_select_feature"], pretrain_mm_mlp_adapter=None,
+                                mm_projector_type=c["config"]["mm_projector_type"], mm_patch_merge_type=c["config"]["mm_patch_merge_type"])
+        inner.initialize_vision_modules(margs, fsdp=None)
+        assert {k: getattr(model.config, k) for k in c["config"]} == c["config"]
+        assert inner.temperature_in == c["temperature_in"] and (inner.vision_proj is not old_proj) == c["vision_proj_is_new_object"]
+        assert list(inner.vision_proj.weight.shape) == c["vision_proj_shape"]
+        assert [p.requires_grad for p in inner.mm_projector.parameters()] == c["projector_requires_grad"]
+        assert inner.vision_tower.select_layer == c["tower_select_layer_attr"]
