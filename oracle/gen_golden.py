@@ -464,6 +464,7 @@ E2E_CASES = [
     ("mixed", 4, True, "cos", "right", {"vision_head_type": "mlp2x_gelu"}),
     ("mixed", 4, True, "cos", "right", {"vision_head_type": "linear"}),     # Linear(h, h): width != 1152 -> the try/except fallback L_img = CE (:451-455)
     ("generation_only", 4, True, "cos", "right", {"vision_head_type": "None"}),   # the constructor default: one Linear(h, 1152)
+    ("mixed", 4, True, "cos", "right", {"vision_coef": 0.25}),                   # loss = CE + 0.25 * L_img (:470-474)
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
@@ -486,7 +487,7 @@ def gen_e2e():
         n_img = sum(max(1, sum(1 for t in r if t == IM)) for r in ids)
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
         suffix = ("" if variant == "cos" else "_" + variant) + ("" if side == "right" else "_" + side) + "".join(
-            "_" + ("head-" if k == "vision_head_type" else "") + str(v) for k, v in extra.items())
+            "_" + ("head-" if k == "vision_head_type" else "coef" if k == "vision_coef" else "") + str(v) for k, v in extra.items())
         for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             model = build_reference(cfg, sd, dt)
             for n, p in model.named_parameters():
@@ -497,6 +498,7 @@ def gen_e2e():
                        normalize_vision=np.int64(nv), apply_softmax=np.int64(sm), left=np.int64(side == "left"),
                        mm_projector_type=np.array(cfg.mm_projector_type), image_token_reduction=np.array(cfg.image_token_reduction),
                        **({"vision_head_type": np.array(cfg.vision_head_type)} if "vision_head_type" in extra else {}),
+                       **({"vision_coef": np.float64(cfg.vision_coef)} if "vision_coef" in extra else {}),
                        target_features_shape=np.array(model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images.to(dt))[7].shape),
                        loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language),
                        loss_image_ar=np.float64(model.loss_image_ar),

@@ -133,7 +133,8 @@ def test_e2e_forward_backward(path):
                    normalize_vision=bool(int(g["normalize_vision"])), apply_softmax=bool(int(g["apply_softmax"])),
                    tokenizer_padding_side="left" if int(g["left"]) else "right", mm_projector_type=str(g["mm_projector_type"]),
                    image_token_reduction=str(g["image_token_reduction"]),
-                   **({"vision_head_type": str(g["vision_head_type"])} if "vision_head_type" in g else {}))
+                   **({"vision_head_type": str(g["vision_head_type"])} if "vision_head_type" in g else {}),
+                **({"vision_coef": float(g["vision_coef"])} if "vision_coef" in g else {}))
     sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16)
     model = hip_model(cfg, sd, vision_head=cfg.vision_head_type)
     model.train()
