@@ -465,6 +465,7 @@ E2E_CASES = [
     ("mixed", 4, True, "cos", "right", {"vision_head_type": "linear"}),     # Linear(h, h): width != 1152 -> the try/except fallback L_img = CE (:451-455)
     ("generation_only", 4, True, "cos", "right", {"vision_head_type": "None"}),   # the constructor default: one Linear(h, 1152)
     ("mixed", 4, True, "cos", "right", {"vision_coef": 0.25}),                   # loss = CE + 0.25 * L_img (:470-474)
+    ("mixed", 4, False, "cos"),                      # use_vision_ar = False WITH answer images: L_img is computed and logged, not added (:470)
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
