@@ -197,4 +197,6 @@ class MetaMorphTrainer(Trainer):
             if z.world > 1:
                 raise RuntimeError("_save under ZeRO-3 needs the gathered state dict: call save_model() (a collective every rank enters)")
             state_dict = z.full_state_dict(self.model, device="cpu")
+        elif z is not None:
+            z.synchronize()                                          # an asynchronous update / all-gather may still be writing the parameters
         super()._save(output_dir, state_dict)

@@ -466,6 +466,9 @@ E2E_CASES = [
     ("generation_only", 4, True, "cos", "right", {"vision_head_type": "None"}),   # the constructor default: one Linear(h, 1152)
     ("mixed", 4, True, "cos", "right", {"vision_coef": 0.25}),                   # loss = CE + 0.25 * L_img (:470-474)
     ("mixed", 4, False, "cos"),                      # use_vision_ar = False WITH answer images: L_img is computed and logged, not added (:470)
+    # depth: 8 decoder layers (4 heads over 1 KV head, d = 64) and 4 tower layers on the multi-frame batch -- the oracle's layer stacking
+    # (and its layer-streamed form, oracle/ref_stream.py) pinned to the reference beyond the 2-layer fixtures
+    ("multi_frame", 4, True, "cos", "right", {"num_hidden_layers": 8, "v_layers": 4, "num_attention_heads": 4}),
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
@@ -489,6 +492,9 @@ def gen_e2e():
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
         suffix = ("" if variant == "cos" else "_" + variant) + ("" if side == "right" else "_" + side) + "".join(
             "_" + ("head-" if k == "vision_head_type" else "coef" if k == "vision_coef" else "") + str(v) for k, v in extra.items())
+        structural = {k: v for k, v in extra.items() if k in ("num_hidden_layers", "v_layers", "num_attention_heads", "num_key_value_heads")}
+        if structural:
+            suffix = f"_deep{extra['num_hidden_layers']}"
         for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             model = build_reference(cfg, sd, dt)
             for n, p in model.named_parameters():
@@ -500,6 +506,7 @@ def gen_e2e():
                        mm_projector_type=np.array(cfg.mm_projector_type), image_token_reduction=np.array(cfg.image_token_reduction),
                        **({"vision_head_type": np.array(cfg.vision_head_type)} if "vision_head_type" in extra else {}),
                        **({"vision_coef": np.float64(cfg.vision_coef)} if "vision_coef" in extra else {}),
+                       **({"cfg_json": np.array(json.dumps(structural))} if structural else {}),
                        target_features_shape=np.array(model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images.to(dt))[7].shape),
                        loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language),
                        loss_image_ar=np.float64(model.loss_image_ar),

@@ -8,6 +8,7 @@ Floors next to the factors are 1.5 x the value measured on MI355X in round 3 (pr
 regression of any of them fails.  Integer outputs are compared bit-exactly.
 """
 import glob
+import json
 import os
 
 import numpy as np
@@ -134,7 +135,8 @@ def test_e2e_forward_backward(path):
                    tokenizer_padding_side="left" if int(g["left"]) else "right", mm_projector_type=str(g["mm_projector_type"]),
                    image_token_reduction=str(g["image_token_reduction"]),
                    **({"vision_head_type": str(g["vision_head_type"])} if "vision_head_type" in g else {}),
-                **({"vision_coef": float(g["vision_coef"])} if "vision_coef" in g else {}))
+                **({"vision_coef": float(g["vision_coef"])} if "vision_coef" in g else {}),
+                **(json.loads(str(g["cfg_json"])) if "cfg_json" in g else {}))
     sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16)
     model = hip_model(cfg, sd, vision_head=cfg.vision_head_type)
     model.train()

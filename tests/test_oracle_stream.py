@@ -56,3 +56,38 @@ def test_streamed_oracle_equals_plain_oracle():
     assert not any(k.startswith("model.layers.1.") for k in got["grads"])
     fwd = full_depth(lambda k: sd[k].detach().clone(), cfg, ids, msk, lab, images, backward=False)
     assert fwd["grads"] == {} and abs(fwd["loss"] - got["loss"]) < 1e-7
+
+
+def test_streamed_oracle_against_reference_recorded_8_layer_run():
+    """oracle/ref_stream.full_depth DIRECTLY against the reference: tests/golden/e2e_multi_frame_T4_ar1_deep8_f32.npz is the reference's own
+    forward + backward of an 8-layer decoder (4 heads over one KV head) + 4-layer tower on the multi-frame batch (oracle/gen_golden.py e2e).
+    Loss, final hidden rows and the gradient summaries of decoder layers 0 and 7, the heads and the projector."""
+    import json
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "e2e_multi_frame_T4_ar1_deep8_f32.npz"))
+    cfg = OracleConfig(hidden_size=256, intermediate_size=512, num_key_value_heads=1, vocab_size=128258, v_intermediate=144, v_image=56,
+                       num_image_tokens=4, tokenizer_model_max_length=64, **json.loads(str(g["cfg_json"])))
+    assert cfg.num_hidden_layers == 8 and cfg.v_layers == 4
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    T = torch.from_numpy
+    got = full_depth(lambda k: sd[k].detach().clone(), cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]),
+                     grad_layers=(0, 7))
+    assert abs(got["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(got["loss_language"] - float(g["loss_language"])) <= 2e-5 * abs(float(g["loss_language"]))
+    assert abs(got["loss_image_ar"] - float(g["loss_image_ar"])) <= 2e-5
+    valid = got["attention_mask"]
+    torch.testing.assert_close(got["hidden_states"][valid], T(g["hidden"])[valid], rtol=2e-4, atol=2e-5)
+
+    def summary(t):
+        f = t.detach().float().flatten()
+        n = min(256, f.numel())
+        idx = (torch.arange(n, dtype=torch.long) * (f.numel() - 1)) // max(n - 1, 1)
+        return torch.cat([f.norm()[None], f[idx]])
+    checked = 0
+    for name, grad in got["grads"].items():
+        key = "grad::" + name
+        assert key in g.files, name
+        torch.testing.assert_close(summary(grad), T(g[key]), rtol=5e-4, atol=2e-6)
+        checked += 1
+    assert checked == 18 + 2 + 4 + 4

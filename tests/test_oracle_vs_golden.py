@@ -160,7 +160,8 @@ def head_variant(g):
                 tokenizer_padding_side="left" if int(g["left"]) else "right", mm_projector_type=str(g["mm_projector_type"]),
                 image_token_reduction=str(g["image_token_reduction"]),
                 **({"vision_head_type": str(g["vision_head_type"])} if "vision_head_type" in g else {}),
-                **({"vision_coef": float(g["vision_coef"])} if "vision_coef" in g else {}))
+                **({"vision_coef": float(g["vision_coef"])} if "vision_coef" in g else {}),
+                **(json.loads(str(g["cfg_json"])) if "cfg_json" in g else {}))
 
 
 def _grad_summary(t):
