@@ -7,7 +7,8 @@ the reference's own Python -- metamorph.mm_utils, metamorph.model.* -- plus the 
 and random weights, and records inputs/outputs as small .npz/.json fixtures.  No reference source
 text is written anywhere; fixtures are data only.
 
-    python oracle/gen_golden.py            # rewrites tests/golden/
+    python oracle/gen_golden.py            # rewrites ALL of tests/golden/ (bit-identical to the committed files)
+    python oracle/gen_golden.py e2e a5     # only these generators
 
 Shims: import-only `wandb`/`decord` packages from oracle/_shims, and a tiny
 SiglipVisionModel assigned to the delay-loaded tower (the checkpoint cannot be downloaded).
@@ -1206,7 +1207,11 @@ def gen_optgroups():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["a1", "a5", "a3", "ops", "e2e"]
+    # every generator, in an order that reproduces the committed fixtures bit for bit in ONE process (`optgroups` last: it registers
+    # LlamaRMSNorm as a layer-norm type for the rest of the process); ~4 minutes on 8 threads
+    ALL = ["a1", "a5", "a3", "a3sel", "ops", "e2e", "n2", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
+           "optgroups"]
+    which = sys.argv[1:] or ALL
     for w in which:
         print(f"[gen_golden] {w}")
         globals()["gen_" + w]()
