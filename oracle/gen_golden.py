@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from oracle.fake_tokenizer import FakeTokenizer
+from oracle.gen_inputs import a5_random_batches
 from oracle.ref_model import OracleConfig, init_state_dict
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -291,6 +292,67 @@ def gen_a5():
     record("wrap_position_ids_left", base[1], base[2], 4, 64, "left", pos=pos)
     record("wrap_no_max_length", a5_cases()[3][1], a5_cases()[3][2], 16, None, "right")           # no tokenizer_model_max_length + images: the reference raises
     record("wrap_no_max_length_text", [[128000, 5, 6, 7], [128000, 8]], [[-100, 5, 6, 7], [-100, 8]], 4, None, "right")   # ... text-only rows never reach that line
+
+
+def gen_a5rand():
+    """120 random batches through the REFERENCE's `prepare_inputs_labels_for_multimodal` (metamorph_arch.py:177-425): labels, attention mask,
+    image positions, kept targets and the origin of every spliced row, padded to common shapes in one .npz."""
+    cfg = tiny_cfg(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_key_value_heads=1)
+    sd = init_state_dict(cfg, seed=11)
+    rng = np.random.default_rng(6)
+    pad_id = 128001
+    cases = a5_random_batches()
+    N = len(cases)
+    Lmax = max(min(max(len(r) + 16 * r.count(-200) for r in rows), mx) for rows, _, _, mx, _ in cases)
+    out_lab = np.full((N, 4, Lmax), -9, dtype=np.int64)
+    out_msk = np.full((N, 4, Lmax), -9, dtype=np.int64)
+    out_pos = np.full((N, 4, Lmax), -9, dtype=np.int64)
+    out_src = np.full((N, 4, Lmax), -9, dtype=np.int64)
+    shape = np.zeros((N, 2), dtype=np.int64)
+    keep = np.full((N, 16), -9, dtype=np.int64)
+    models = {}
+    for ci, (rows, labs, T, max_len, side) in enumerate(cases):
+        key = (T, max_len, side)
+        if key not in models:
+            cfg.num_image_tokens, cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side = T, max_len, side
+            models[key] = build_reference(cfg, sd, torch.float32)
+        model = models[key]
+        n_img = sum(max(1, r.count(-200)) for r in rows)
+        images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
+        ids_t, lab_t = torch.tensor(pad_rows(rows, pad_id)), torch.tensor(pad_rows(labs, -100))
+        msk_t = ids_t.ne(pad_id)
+        with torch.no_grad():
+            proj, feat = model.encode_images(images)
+            _, _, att, _, emb, new_lab, img_pos, tgt = model.prepare_inputs_labels_for_multimodal(ids_t, None, msk_t, None, lab_t, images)
+        B, L, _ = emb.shape
+        W = model.get_model().embed_tokens.weight.detach()
+        flat_proj = proj.reshape(-1, proj.shape[-1])
+        src = np.full((B, L), -1, dtype=np.int64)
+        for b in range(B):
+            toks = set(t for t in rows[b] if t >= 0)
+            for l in range(L):
+                if not att[b, l]:
+                    continue
+                row = emb[b, l]
+                hit = (flat_proj == row).all(dim=1).nonzero()
+                if len(hit):
+                    src[b, l] = -2 - int(hit[0, 0])
+                    continue
+                cand = [t for t in toks if torch.equal(W[t], row)]
+                assert len(cand) == 1, (ci, b, l, cand)
+                src[b, l] = cand[0]
+        kp = []
+        for r in range(tgt.shape[0]):
+            hit = [i for i in range(feat.shape[0]) if torch.equal(feat[i], tgt[r])]
+            assert len(hit) == 1
+            kp.append(hit[0])
+        shape[ci] = (B, L)
+        out_lab[ci, :B, :L], out_msk[ci, :B, :L], out_pos[ci, :B, :L], out_src[ci, :B, :L] = new_lab.numpy(), att.numpy(), img_pos.numpy(), src
+        keep[ci, :len(kp)] = kp
+    save_npz("a5rand_reference.npz", n_cases=np.int64(N), seed=np.int64(0), out_shape=shape, out_labels=out_lab, out_attention_mask=out_msk,
+             out_image_positions=out_pos, out_src=out_src, out_target_keep=keep)
+    print(f"    {N} random batches; output lengths {int(shape[:, 1].min())}..{int(shape[:, 1].max())}; "
+          f"{int((keep >= 0).sum())} kept targets; {sum(1 for c in cases if c[4] == 'left')} left-padded")
 
 
 # ----------------------------------------------------------------------------- A3 tower
@@ -1209,7 +1271,7 @@ def gen_optgroups():
 if __name__ == "__main__":
     # every generator, in an order that reproduces the committed fixtures bit for bit in ONE process (`optgroups` last: it registers
     # LlamaRMSNorm as a layer-norm type for the rest of the process); ~4 minutes on 8 threads
-    ALL = ["a1", "a5", "a3", "a3sel", "ops", "e2e", "n2", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
+    ALL = ["a1", "a5", "a5rand", "a3", "a3sel", "ops", "e2e", "n2", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
            "optgroups"]
     which = sys.argv[1:] or ALL
     for w in which:

@@ -659,3 +659,38 @@ def test_initialize_vision_modules_side_effects_match_reference_recorded():
         assert list(inner.vision_proj.weight.shape) == c["vision_proj_shape"]
         assert [p.requires_grad for p in inner.mm_projector.parameters()] == c["projector_requires_grad"]
         assert inner.vision_tower.select_layer == c["tower_select_layer_attr"]
+
+
+def test_splice_plan_matches_reference_on_120_random_batches():
+    """tests/golden/a5rand_reference.npz: what the REFERENCE's prepare_inputs_labels_for_multimodal returned for 120 seeded random ragged batches
+    (0-3 images per sample, answer / prompt images, overflow drops, truncation, text-only samples with their dummy image, every fifth case
+    left-padded; oracle/gen_golden.py a5rand).  Both the product's plan builder and the oracle's loop restatement must reproduce labels, mask,
+    image positions, kept targets and the origin of every spliced row bit for bit."""
+    from metamorph_amd.splice_plan import build_splice_plan
+    from oracle.gen_inputs import a5_random_batches
+    from oracle.ref_plan import splice_bookkeeping
+    g = np.load(os.path.join(GOLDEN, "a5rand_reference.npz"))
+    cases = a5_random_batches(int(g["n_cases"]), int(g["seed"]))
+    stats = dict(left=0, dropped=0, answer=0)
+    for ci, (rows, labs, Timg, max_len, side) in enumerate(cases):
+        T_ = max(len(r) for r in rows)
+        ids_a = np.array([r + [128001] * (T_ - len(r)) for r in rows])
+        lab_a = np.array([r + [-100] * (T_ - len(r)) for r in labs])
+        msk_a = ids_a != 128001
+        n_img = sum(max(1, r.count(-200)) for r in rows)
+        B, L = g["out_shape"][ci].tolist()
+        want = {k: g[k][ci, :B, :L] for k in ("out_labels", "out_attention_mask", "out_image_positions", "out_src")}
+        keep = [int(x) for x in g["out_target_keep"][ci] if x >= 0]
+        plan = build_splice_plan(ids_a, lab_a, msk_a, n_img, Timg, max_len, side)
+        assert (plan.B, plan.L) == (B, L), ci
+        assert np.array_equal(plan.src.reshape(B, L), want["out_src"]), ci
+        assert np.array_equal(plan.labels, want["out_labels"]) and np.array_equal(plan.image_positions, want["out_image_positions"]), ci
+        assert np.array_equal(plan.attention_mask, want["out_attention_mask"].astype(bool)) and plan.target_keep.tolist() == keep, ci
+        ref = splice_bookkeeping(ids_a.tolist(), lab_a.tolist(), msk_a.tolist(), n_img, Timg, max_len, side)
+        src = [[-1 if s is None else (-2 - (s[1] * Timg + s[2]) if isinstance(s, tuple) else s) for s in row] for row in ref["src"]]
+        assert np.array_equal(np.array(src), want["out_src"]) and np.array_equal(np.array(ref["labels"]), want["out_labels"]), ci
+        assert np.array_equal(np.array(ref["image_positions"]), want["out_image_positions"]) and ref["target_keep"] == keep, ci
+        stats["left"] += side == "left"
+        stats["dropped"] += int(sum(r.count(-200) for r in rows) * Timg > (want["out_src"] <= -2).sum())
+        stats["answer"] += len(keep)
+    assert stats["left"] == 24 and stats["dropped"] >= 10 and stats["answer"] == 180, stats
