@@ -653,6 +653,33 @@ def gen_n2():
     print(f"  wrote n2_batch_producer.json ({len(cases)} preprocess cases, {len(coll)} collate cases)")
 
 
+def gen_n2rand():
+    """40 seeded random conversations (oracle/gen_inputs.n2_random_sources) through the reference's preprocess_multimodal + preprocess_llama3
+    (train.py:309-332, 501-597) on the fake tokenizer, five tokenizer / template settings each: ids and labels (inputs are regenerated from
+    the seed by the test, only outputs are stored)."""
+    import copy
+    from types import SimpleNamespace
+    from oracle.gen_inputs import n2_random_sources
+    T, _ = _import_train()
+    cases = []
+    for si, sources in enumerate(n2_random_sources()):
+        has_image = any("<image>" in m["value"] for src in sources for m in src)
+        for add_bos, use_se, max_len in ((True, False, 4096), (False, False, 4096), (True, True, 4096), (False, True, 4096), (True, False, 24)):
+            tok = FakeTokenizer(add_bos=add_bos, model_max_length=max_len)
+            rec = dict(source=si, add_bos=add_bos, mm_use_im_start_end=use_se, model_max_length=max_len, has_image=has_image)
+            try:
+                src = T.preprocess_multimodal(copy.deepcopy(sources), SimpleNamespace(is_multimodal=True, mm_use_im_start_end=use_se))
+                out = T.preprocess_llama3(copy.deepcopy(src), tok, has_image=has_image)
+                rec.update(input_ids=out["input_ids"].tolist(), labels=out["labels"].tolist())
+            except Exception as e:
+                rec["raises"] = type(e).__name__
+            cases.append(rec)
+    with open(os.path.join(OUT, "n2_random.json"), "w") as f:
+        json.dump({"seed": 7, "n_sources": 40, "cases": cases}, f)
+    n_masked = sum(1 for c in cases if "labels" in c and all(x == -100 for x in c["labels"][0]))
+    print(f"    {len(cases)} cases, {sum('raises' in c for c in cases)} raise, {sum(c['has_image'] for c in cases)} with images, {n_masked} fully masked (mismatch rule)")
+
+
 def gen_images():
     """process_images / expand2square of the reference (mm_utils.py:151-188) driving transformers' own SigLIP image processor
     (the class the reference obtains from the hub, built here from the so400m-patch14-384 preprocessor constants at a small
@@ -1271,7 +1298,7 @@ def gen_optgroups():
 if __name__ == "__main__":
     # every generator, in an order that reproduces the committed fixtures bit for bit in ONE process (`optgroups` last: it registers
     # LlamaRMSNorm as a layer-norm type for the rest of the process); ~4 minutes on 8 threads
-    ALL = ["a1", "a5", "a5rand", "a3", "a3sel", "ops", "e2e", "n2", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
+    ALL = ["a1", "a5", "a5rand", "a3", "a3sel", "ops", "e2e", "n2", "n2rand", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
            "optgroups"]
     which = sys.argv[1:] or ALL
     for w in which:

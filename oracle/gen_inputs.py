@@ -31,3 +31,28 @@ def a5_random_batches(n_cases=120, seed=0):
             labs.append(lab)
         cases.append((rows, labs, Timg, max_len, "left" if trial % 5 == 0 else "right"))
     return cases
+
+
+_WORDS = "a red bird sat on the mat what is shown here draw me one two three blue cat please describe it now and then yes no".split()
+
+
+def n2_random_sources(n=40, seed=7):
+    """Seeded random single-sample conversations for the batch producer: 1-4 rounds, 0-6 words per turn (empty answers included), <image>
+    at the start / middle / end of a human or gpt turn (0-2 per conversation), sometimes a leading gpt turn the template must skip."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        rounds = int(rng.integers(1, 5))
+        conv = []
+        if rng.random() < 0.15:
+            conv.append({"from": "gpt", "value": "ignored greeting"})
+        budget = int(rng.integers(0, 3))
+        for r in range(rounds):
+            for who in ("human", "gpt"):
+                words = [str(rng.choice(_WORDS)) for _ in range(int(rng.integers(0 if who == "gpt" else 1, 7)))]
+                if budget and rng.random() < 0.35:
+                    words.insert(int(rng.integers(0, len(words) + 1)), "<image>")
+                    budget -= 1
+                conv.append({"from": who, "value": " ".join(words)})
+        out.append([conv])
+    return out

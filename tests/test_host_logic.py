@@ -694,3 +694,28 @@ def test_splice_plan_matches_reference_on_120_random_batches():
         stats["dropped"] += int(sum(r.count(-200) for r in rows) * Timg > (want["out_src"] <= -2).sum())
         stats["answer"] += len(keep)
     assert stats["left"] == 24 and stats["dropped"] >= 10 and stats["answer"] == 180, stats
+
+
+def test_preprocess_llama3_matches_reference_on_random_conversations():
+    """tests/golden/n2_random.json: 40 seeded random conversations x 5 tokenizer / template settings through the REFERENCE's
+    preprocess_multimodal + preprocess_llama3 (1-4 rounds, empty answers, <image> at any place of either role's turn, a leading gpt turn,
+    truncation at 24 tokens; the tokenization-mismatch rule that masks a whole sample fires in 91 of the 200 cases)."""
+    import copy
+    from types import SimpleNamespace
+    from metamorph_amd.data import preprocess, preprocess_multimodal
+    from oracle.fake_tokenizer import FakeTokenizer
+    from oracle.gen_inputs import n2_random_sources
+    with open(os.path.join(GOLDEN, "n2_random.json")) as f:
+        g = json.load(f)
+    sources = n2_random_sources(g["n_sources"], g["seed"])
+    assert len(g["cases"]) == 200
+    masked = 0
+    for c in g["cases"]:
+        tok = FakeTokenizer(add_bos=c["add_bos"], model_max_length=c["model_max_length"])
+        tag = (c["source"], c["add_bos"], c["mm_use_im_start_end"], c["model_max_length"])
+        src = preprocess_multimodal(copy.deepcopy(sources[c["source"]]), SimpleNamespace(is_multimodal=True, mm_use_im_start_end=c["mm_use_im_start_end"]))
+        out = preprocess(src, tok, has_image=c["has_image"])
+        assert out["input_ids"].tolist() == c["input_ids"], tag
+        assert out["labels"].tolist() == c["labels"], tag
+        masked += all(x == -100 for x in c["labels"][0])
+    assert masked == 91
