@@ -532,6 +532,8 @@ E2E_CASES = [
     # depth: 8 decoder layers (4 heads over 1 KV head, d = 64) and 4 tower layers on the multi-frame batch -- the oracle's layer stacking
     # (and its layer-streamed form, oracle/ref_stream.py) pinned to the reference beyond the 2-layer fixtures
     ("multi_frame", 4, True, "cos", "right", {"num_hidden_layers": 8, "v_layers": 4, "num_attention_heads": 4}),
+    # the 'identity' connector (builder.py:60-61) needs an LLM as wide as the tower: h = 1152 = 9 heads x 128 over 3 KV heads
+    ("mixed", 4, True, "cos", "right", {"mm_projector_type": "identity", "hidden_size": 1152, "num_attention_heads": 9, "num_key_value_heads": 3}),
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
@@ -555,9 +557,11 @@ def gen_e2e():
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
         suffix = ("" if variant == "cos" else "_" + variant) + ("" if side == "right" else "_" + side) + "".join(
             "_" + ("head-" if k == "vision_head_type" else "coef" if k == "vision_coef" else "") + str(v) for k, v in extra.items())
-        structural = {k: v for k, v in extra.items() if k in ("num_hidden_layers", "v_layers", "num_attention_heads", "num_key_value_heads")}
-        if structural:
+        structural = {k: v for k, v in extra.items() if k in ("num_hidden_layers", "v_layers", "num_attention_heads", "num_key_value_heads", "hidden_size")}
+        if "num_hidden_layers" in structural:
             suffix = f"_deep{extra['num_hidden_layers']}"
+        elif structural:
+            suffix = "_" + str(extra["mm_projector_type"])
         for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
             model = build_reference(cfg, sd, dt)
             for n, p in model.named_parameters():
