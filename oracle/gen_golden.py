@@ -1243,6 +1243,16 @@ def gen_textonly():
     labs = [[-100] * 5 + rows[0][5:], [-100] * 3 + rows[1][3:]]
     ids_t, lab_t = torch.tensor(pad_rows(rows, 128001)), torch.tensor(pad_rows(labs, -100))
     msk_t = ids_t.ne(128001)
+    _textonly_record(cfg, sd, ids_t, lab_t, msk_t, "r3_textonly")
+    # the same batch LEFT-padded (a tokenizer with padding_side = "left"): HF's decoder takes position_ids = arange(L), padding included
+    L = ids_t.shape[1]
+    left = lambda rws, v: torch.tensor([[v] * (L - len(r)) + r for r in rws])
+    cfg_l = tiny_cfg(num_image_tokens=4, tokenizer_padding_side="left")
+    ids_l, lab_l = left(rows, 128001), left(labs, -100)
+    _textonly_record(cfg_l, sd, ids_l, lab_l, ids_l.ne(128001), "r3_textonly_left")
+
+
+def _textonly_record(cfg, sd, ids_t, lab_t, msk_t, stem):
     for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
         model = build_reference(cfg, sd, dt)
         for n, p in model.named_parameters():
@@ -1256,7 +1266,7 @@ def gen_textonly():
             if p.grad is not None:
                 rec["grad::" + n] = grad_summary(p.grad)
         rec["params_without_grad"] = np.array(sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None))
-        save_npz(f"r3_textonly_{tag}.npz", **rec)
+        save_npz(f"{stem}_{tag}.npz", **rec)
         print(f"    {tag}: loss {float(out.loss):.6f}, {sum(k.startswith('grad::') for k in rec)} gradients, no gradient for {rec['params_without_grad'].tolist()}, "
               f"has loss_language attr: {hasattr(model, 'loss_language')}")
 

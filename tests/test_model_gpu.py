@@ -705,11 +705,13 @@ def test_tower_select_layer_and_zero_token_branches_match_reference_recorded():
         tower.vision_tower.forward_features(images, -5)          # 3 layers: hidden_states has 4 entries
 
 
-def test_text_only_forward_without_images_matches_reference_recorded():
+@pytest.mark.parametrize("stem", ["r3_textonly", "r3_textonly_left"])
+def test_text_only_forward_without_images_matches_reference_recorded(stem):
     """forward(images=None) (r3_textonly_*.npz, recorded from the reference): the splice returns early (metamorph_arch.py:184-191), loss = CE
     alone, no gradient reaches the projector / vision head."""
-    g, g32 = (np.load(os.path.join(GOLDEN, f"r3_textonly_{t}.npz")) for t in ("bf16", "f32"))
-    cfg = tiny_cfg(num_image_tokens=4)
+    g, g32 = (np.load(os.path.join(GOLDEN, f"{stem}_{t}.npz")) for t in ("bf16", "f32"))
+    # "_left": the same batch left-padded under tokenizer_padding_side = "left" (HF: position_ids = arange(L), padding included)
+    cfg = tiny_cfg(num_image_tokens=4, tokenizer_padding_side="left" if stem.endswith("left") else "right")
     model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
     model.train()
     ids, lab, msk = T(g["input_ids"]).to(DEV), T(g["labels"]).to(DEV), T(g["attention_mask"]).to(DEV)

@@ -290,12 +290,13 @@ def test_oracle_image_embeds_and_pretraining_tp_match_reference(kind):
     assert n >= 25
 
 
+@pytest.mark.parametrize("stem", ["r3_textonly", "r3_textonly_left"])
 @pytest.mark.parametrize("tag", ["f32", "bf16"])
-def test_text_only_forward_without_images(tag):
+def test_text_only_forward_without_images(tag, stem):
     """forward(images=None) as the reference ran it (r3_textonly_*.npz): early return of the splice, CE alone, no gradient for the projector /
     vision head, `loss_language` never set."""
-    g = np.load(os.path.join(GOLDEN, f"r3_textonly_{tag}.npz"))
-    cfg = tiny_cfg(num_image_tokens=4)
+    g = np.load(os.path.join(GOLDEN, f"{stem}_{tag}.npz"))
+    cfg = tiny_cfg(num_image_tokens=4, tokenizer_padding_side="left" if stem.endswith("left") else "right")
     dt = DT[tag]
     sd = init_state_dict(cfg, seed=int(g["seed"]), dtype=dt)
     for k, v in sd.items():
