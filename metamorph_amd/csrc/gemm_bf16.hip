@@ -1513,6 +1513,7 @@ extern "C" int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t
                                     int64_t ld_out, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!in || !out || rows <= 0 || cols <= 0 || (ld_in & 7) || !mm_aligned16(in) || !mm_aligned16(out)) return MM355_EINVAL;
+    if (ld_out < rows || rows > 0x7fffffff || cols > 0x7fffffff) return MM355_EINVAL;   // rows of `out` would overlap / run past it
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, (int)rows, (int)cols, out, ld_out);
     return mm_launch_status();

@@ -162,6 +162,7 @@ def test_library_exports_every_declared_symbol():
     # argument validation works without a GPU (no kernel is launched on the error path)
     assert L.mm355_gemm_bf16(0, 8, 0, 8, 0, 8, 16, 16, 16, 0, 0, 0, 0, 0, 0, 0) == -1
     assert L.mm355_rmsnorm_fwd(0, 0, 0, 4, 8, 1e-5, 0) == -1
+    assert L.mm355_transpose_bf16(16, 8, 4, 8, 32, 2, 0) == -1         # ld_out < rows: output rows would overlap
 
 
 def test_header_cites_reference_for_every_family():
