@@ -123,7 +123,8 @@ int mm355_gemm_nn_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* Bt, i
                        int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr,
                        uint32_t flags, void* stream);
 
-/* out[c][r] = in[r][c]   (rows x cols -> cols x rows), bf16.  Used for the backward GEMM operands. */
+/* out[c][r] = in[r][c]   (rows x cols -> cols x rows), bf16.  Used for the backward GEMM operands.
+ * ld_in % 8 == 0, in / out 16-byte aligned, ld_out >= rows (else MM355_EINVAL: output rows would overlap). */
 int mm355_transpose_bf16(const mm355_bf16* in, int64_t ld_in, int64_t rows, int64_t cols,
                          mm355_bf16* out, int64_t ld_out, void* stream);
 
