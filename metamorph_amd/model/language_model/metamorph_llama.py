@@ -17,7 +17,6 @@ HIP) instead of transformers' LlamaModel + torch ops:
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch

@@ -11,7 +11,6 @@ from abc import ABC, abstractmethod
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 from .. import functional as F
 from .. import ops
