@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of one ping-pong GEMM build knob (env, read once per process: MM355_GEMM_TAIL / MM355_GEMM_GM) on the GEMM shapes of a
-LLaMA-3-8B decoder layer at 32 768 tokens: TFLOP/s per shape (median of interleaved rounds) + a checksum of every output (the
-knobs must not change a single bit).  Run once per setting:  MM355_GEMM_TAIL=4 python tools/bench_gemm_tail.py"""
+"""A/B of one ping-pong GEMM process-level knob (env, read once per process: MM355_GEMM_GM, the raster group height; the early hand-over
+knob MM355_GEMM_TAIL this script was written for lost 7 % and was removed again, profiles/r3_gemm_ablation_and_pmc.md) on the GEMM shapes
+of a LLaMA-3-8B decoder layer at 32 768 tokens: TFLOP/s per shape (median of interleaved rounds) + a checksum of every output (a knob must
+not change a single bit).  Run once per setting:  MM355_GEMM_GM=8 python tools/bench_gemm_tail.py"""
 import os, sys, statistics, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
