@@ -212,6 +212,46 @@ def test_consolidated_optimizer_state_resumes_at_other_world_size(tmp_path):
     torch.testing.assert_close(got, torch.load(os.path.join(tmp_path, "params3.pt")), rtol=1e-5, atol=1e-6)
 
 
+def _resume_worker(rank, world, port, tmp, w1):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from metamorph_amd.checkpoint import load_consolidated_optimizer_state
+        from metamorph_amd.zero2 import Zero2AdamW
+        params = _make_params(torch.float32)
+        for p, key in zip(params, _SEGMENTS):
+            if key is not None:
+                p._mm_segment = key
+        with torch.no_grad():
+            for p in params:                                     # other starting weights: everything must come from the checkpoint
+                p.add_(0.25)
+        model = _Holder(params)
+        opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, shard_update=_oracle_update, sumsq=_oracle_sumsq,
+                         clip_coef=_oracle_clip)
+        load_consolidated_optimizer_state(opt, model, torch.load(os.path.join(tmp, "opt.pt")))
+        assert opt._step == 2
+        torch.testing.assert_close(torch.cat([p.data.reshape(-1) for p in params]), torch.load(os.path.join(tmp, "params2.pt")), rtol=0, atol=0)
+        # step 3: every rank of the NEW world brings the mean gradient of the OLD world's ranks, so the mean over ranks is that mean again
+        mean = [sum(gs) / w1 for gs in zip(*[_grads_for(r, 3, params) for r in range(w1)])]
+        for p, g in zip(params, mean):
+            p._mm_grad_buf.copy_(g); p.grad = p._mm_grad_buf
+        opt.step()
+        torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, f"resumed_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w1,w2", [(2, 4), (8, 2), (4, 8)])
+def test_consolidated_optimizer_state_moves_between_world_sizes(tmp_path, w1, w2):
+    """w1 ranks train two steps and consolidate; w2 ranks (other shard boundaries, other starting weights) load the checkpoint, take step 3
+    and must hold what the w1 ranks hold after their step 3 -- the role DeepSpeed's zero_to_fp32 + a fresh launch play for the reference."""
+    mp.spawn(_ckpt_worker, args=(w1, _free_port(), str(tmp_path)), nprocs=w1, join=True)
+    mp.spawn(_resume_worker, args=(w2, _free_port(), str(tmp_path), w1), nprocs=w2, join=True)
+    want = torch.load(os.path.join(tmp_path, "params3.pt"))
+    for r in range(w2):
+        torch.testing.assert_close(torch.load(os.path.join(tmp_path, f"resumed_rank{r}.pt")), want, rtol=2e-5, atol=2e-6)
+
+
 # ------------------------------------------------------------------ the real module tree: segments, hook wiring, overlap
 def _model_worker(rank, world, port, tmp, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
