@@ -108,18 +108,20 @@ def _worker(rank, world, port, tmp):
             dist.destroy_process_group()
 
 
-def test_trainer_two_ranks_no_ddp_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_trainer_n_ranks_no_ddp_equals_one_rank(tmp_path, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(a, b)
-    # one rank, micro-batches of 4 = the union of what the two ranks saw per micro-step (accelerate hands batch 2k to rank 0 and
-    # 2k+1 to rank 1); mean loss over equal-sized halves == mean over the union
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / "rank0.pt")
+    for r in range(1, world):
+        assert torch.equal(a, torch.load(tmp_path / f"rank{r}.pt"))
+    # one rank, micro-batches of 2 * world = the union of what the ranks saw per micro-step (accelerate hands batch world * k + r to
+    # rank r); mean loss over equal-sized parts == mean over the union
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         os.environ.pop(k, None)
     os.environ["ACCELERATE_USE_CPU"] = "true"
     try:
-        one = _train(str(tmp_path / "one"), per_device_bs=4, accum=2, steps=3)
+        one = _train(str(tmp_path / "one"), per_device_bs=2 * world, accum=2, steps=3)
     finally:
         os.environ.pop("ACCELERATE_USE_CPU", None)
     torch.testing.assert_close(a, one, rtol=1e-5, atol=1e-6)
