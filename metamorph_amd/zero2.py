@@ -97,6 +97,9 @@ class Zero2AdamW(torch.optim.Optimizer):
         # collectives are skipped at world size 1 unless MM355_ZERO2_FORCE_COLLECTIVES=1 (exercises the RCCL call pattern --
         # in-place reduce-scatter / all-gather, async handles, side streams -- on a single-GPU box)
         self._coll = self.distributed and (self.world > 1 or os.environ.get("MM355_ZERO2_FORCE_COLLECTIVES") == "1")
+        # the RCCL form of the exchange: in-place reduce_scatter_tensor / all_gather_into_tensor on slices of the flat buffers.
+        # MM355_ZERO_TENSOR_COLLECTIVES=1 runs the SAME calls on another backend (the gloo tests drive this branch at world 2-8 on CPU)
+        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or os.environ.get("MM355_ZERO_TENSOR_COLLECTIVES") == "1")
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq
         self._clip_coef = clip_coef or _hip_clip_coef
@@ -234,7 +237,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         """Sum segment i over the ranks; this rank's slice ends up in place (the other slices are don't-care afterwards)."""
         sg = self.segs[i]
         self._settle_grads(sg["params"])
-        if dist.get_backend(self.pg) == "nccl":           # RCCL: in-place reduce-scatter (output = input + rank * count)
+        if self._tensor_coll:                             # RCCL: in-place reduce-scatter (output = input + rank * count)
             w = dist.reduce_scatter_tensor(sg["my_grad"], sg["grad"], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
             self._pending[i] = _Pending(w if async_op else None)
         else:                                             # gloo (CPU tests): no reduce_scatter -> all_reduce in fp32
@@ -288,7 +291,7 @@ class Zero2AdamW(torch.optim.Optimizer):
     def _all_gather_params(self):
         if not self._coll:
             return
-        if dist.get_backend(self.pg) == "nccl":
+        if self._tensor_coll:
             works = [dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg, async_op=True) for sg in self.segs]
             for w in works:
                 w.wait()
@@ -323,7 +326,7 @@ class Zero2AdamW(torch.optim.Optimizer):
         side = self._upd_stream
         side.wait_stream(main)                               # gradients, norm and clip coefficient are final
         self._ready, self._waited = {}, set()
-        nccl = self._coll and dist.get_backend(self.pg) == "nccl"
+        nccl = self._tensor_coll
         with torch.cuda.stream(side):
             prev = None                                      # (segment, all-gather work) one step behind the update kernels
             for i in self._update_order():

@@ -79,6 +79,8 @@ class Zero3AdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
         self._coll = self.distributed and (self.world > 1 or os.environ.get("MM355_ZERO2_FORCE_COLLECTIVES") == "1")
+        # RCCL form (tensor collectives on slices); MM355_ZERO_TENSOR_COLLECTIVES=1 runs the same calls on gloo in the CPU tests
+        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or os.environ.get("MM355_ZERO_TENSOR_COLLECTIVES") == "1")
         self.max_grad_norm = max_grad_norm
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq
@@ -194,7 +196,7 @@ class Zero3AdamW(torch.optim.Optimizer):
         sg = self.segs[i]
         full = slot.buf[:sg["n"]]
         if self._coll:
-            if dist.get_backend(self.pg) == "nccl":
+            if self._tensor_coll:
                 mine = full[self.rank * sg["m"]:(self.rank + 1) * sg["m"]]
                 mine.copy_(sg["p_shard"])
                 slot.work = dist.all_gather_into_tensor(full, mine, group=self.pg, async_op=True)
@@ -271,7 +273,7 @@ class Zero3AdamW(torch.optim.Optimizer):
             mine = full[self.rank * sg["m"]:(self.rank + 1) * sg["m"]]
             first = not sg["g_live"]
             sg["g_live"] = True
-            if self._coll and dist.get_backend(self.pg) == "nccl":
+            if self._tensor_coll:
                 w = dist.reduce_scatter_tensor(mine, full, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
                 def finish(w=w, sg=sg, mine=mine, first=first):
@@ -355,7 +357,7 @@ class Zero3AdamW(torch.optim.Optimizer):
                 elif p.grad.data_ptr() != p._mm_grad_buf.data_ptr():
                     p._mm_grad_buf.copy_(p.grad)
             if self._coll:
-                if dist.get_backend(self.pg) == "nccl":
+                if self._tensor_coll:
                     dist.reduce_scatter_tensor(sg["my_grad"], sg["grad"], op=dist.ReduceOp.SUM, group=self.pg)
                 else:
                     g32 = sg["grad"].float()
@@ -391,7 +393,7 @@ class Zero3AdamW(torch.optim.Optimizer):
         for sg in self.segs:
             if sg["sharded"] or not self._coll:
                 continue
-            if dist.get_backend(self.pg) == "nccl":
+            if self._tensor_coll:
                 dist.all_gather_into_tensor(sg["param"], sg["my_param"], group=self.pg)
             else:
                 parts = [torch.empty_like(sg["my_param"]) for _ in range(self.world)]
@@ -412,7 +414,13 @@ class Zero3AdamW(torch.optim.Optimizer):
         self._pslot_of = {}
 
     def synchronize(self):
+        """Everything this optimizer started has finished: gradient reductions folded in, prefetched all-gathers complete (a gather that
+        nobody consumed -- the neighbour prefetched by the last ensure_params() -- must not be in flight when the process group goes away)."""
         self._drain_grad_slots()
+        for slot in self._pslots:
+            if slot.work is not None:
+                slot.work.wait()
+                slot.work = None
         if self.master.is_cuda:
             torch.cuda.current_stream().synchronize()
 
@@ -433,7 +441,7 @@ class Zero3AdamW(torch.optim.Optimizer):
                 buf = torch.empty(max(self.segs[j]["n"] for j in self.layer_order), device=sg["p_shard"].device, dtype=sg["p_shard"].dtype)
             full = buf[:sg["n"]]
             if self._coll:
-                if dist.get_backend(self.pg) == "nccl":
+                if self._tensor_coll:
                     dist.all_gather_into_tensor(full, sg["p_shard"], group=self.pg)
                 else:
                     parts = [torch.empty_like(sg["p_shard"]) for _ in range(self.world)]

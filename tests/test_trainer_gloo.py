@@ -103,6 +103,7 @@ def _worker(rank, world, port, tmp):
     try:
         flat = _train(os.path.join(tmp, f"r{rank}"), per_device_bs=2, accum=2, steps=3)
         torch.save(flat, os.path.join(tmp, f"rank{rank}.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -186,6 +187,7 @@ def _zero3_save_worker(rank, world, port, tmp):
         with pytest.raises(RuntimeError):
             tr._save(os.path.join(tmp, "bad"))
         torch.save(torch.ones(1), os.path.join(tmp, f"ok{rank}.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

@@ -43,8 +43,10 @@ def _grads_for(rank, step, params):
 _SEGMENTS = [("layer", 0), ("layer", 0), ("layer", 0), ("layer", 1), ("layer", 1), None]
 
 
-def _worker(rank, world, port, dtype, steps, tmp, overlap=False):
+def _worker(rank, world, port, dtype, steps, tmp, overlap=False, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if tensor_coll:     # the RCCL form of the exchange (in-place reduce_scatter_tensor / all_gather_into_tensor on buffer slices), run on gloo
+        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd.zero2 import Zero2AdamW
@@ -54,7 +56,7 @@ def _worker(rank, world, port, dtype, steps, tmp, overlap=False):
                 p._mm_segment = key
         opt = Zero2AdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=1.0,
                          shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip, overlap=overlap)
-        assert opt.world == world and opt.shard * world == opt.padded and len(opt.segs) == 3
+        assert opt.world == world and opt.shard * world == opt.padded and len(opt.segs) == 3 and opt._tensor_coll == bool(tensor_coll)
         assert all(sg["n"] % (world * 256) == 0 for sg in opt.segs)
         # fused blocks stay contiguous in the flat buffer (q/k/v -> one GEMM operand)
         assert params[1].data_ptr() == params[0].data_ptr() + params[0].numel() * params[0].element_size()
@@ -78,6 +80,7 @@ def _worker(rank, world, port, dtype, steps, tmp, overlap=False):
             assert all(p.grad is None for p in params)
         flat = torch.cat([p.data.reshape(-1) for p in params])
         torch.save(flat, os.path.join(tmp, f"rank{rank}.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 
@@ -90,15 +93,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,dtype,overlap", [(2, torch.float32, False), (2, torch.float32, True), (2, torch.bfloat16, False),
-                                                 (2, torch.bfloat16, True), (3, torch.float32, True), (4, torch.float32, True),
-                                                 (4, torch.bfloat16, True), (8, torch.float32, True), (8, torch.bfloat16, False)])
-def test_n_ranks_equal_one_rank(tmp_path, world, dtype, overlap):
+@pytest.mark.parametrize("world,dtype,overlap,tensor_coll", [
+    (2, torch.float32, False, False), (2, torch.bfloat16, True, False), (3, torch.float32, True, False), (4, torch.bfloat16, True, False),
+    (8, torch.float32, True, False), (8, torch.bfloat16, False, False),
+    # the branch RCCL runs on a node: in-place tensor collectives on slices of the flat gradient / parameter buffers
+    (2, torch.float32, True, True), (3, torch.float32, False, True), (4, torch.float32, True, True), (8, torch.float32, True, True)])
+def test_n_ranks_equal_one_rank(tmp_path, world, dtype, overlap, tensor_coll):
     """overlap=True: each "layer" segment is reduced asynchronously as soon as it is announced (the RCCL reduce-scatter /
     backward overlap of the product, here gloo all-reduce), the rest at step(); the result must not depend on it.
     world 2 / 4 / 8 are the sizes of the one-node scaling run (`bench.py --gpus N`), 3 a size that divides nothing."""
     steps = 3
-    mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), dtype, steps, str(tmp_path), overlap, tensor_coll), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     for r in range(1, world):
         assert torch.equal(r0, torch.load(os.path.join(tmp_path, f"rank{r}.pt"))), "ranks must hold identical parameters after the all-gather"
@@ -180,6 +185,7 @@ def _ckpt_worker(rank, world, port, tmp):
         opt.step()
         if rank == 0:
             torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, "params3.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 
@@ -237,6 +243,7 @@ def _resume_worker(rank, world, port, tmp, w1):
             p._mm_grad_buf.copy_(g); p.grad = p._mm_grad_buf
         opt.step()
         torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, f"resumed_rank{rank}.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 
@@ -253,8 +260,10 @@ def test_consolidated_optimizer_state_moves_between_world_sizes(tmp_path, w1, w2
 
 
 # ------------------------------------------------------------------ the real module tree: segments, hook wiring, overlap
-def _model_worker(rank, world, port, tmp, overlap):
+def _model_worker(rank, world, port, tmp, overlap, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if tensor_coll:
+        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd import functional as F
@@ -291,16 +300,17 @@ def _model_worker(rank, world, port, tmp, overlap):
             opt.zero_grad()
         torch.save(opt.flat_param.clone(), os.path.join(tmp, f"model_rank{rank}_ov{int(overlap)}.pt"))
         F.set_layer_grad_hook(None)
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_overlap_on_the_real_module_tree(tmp_path, world):
+@pytest.mark.parametrize("world,tensor_coll", [(2, False), (8, True)])
+def test_overlap_on_the_real_module_tree(tmp_path, world, tensor_coll):
     """tag_segments + enable_overlap on the actual MetaMorph module tree (CPU parameters, gloo): one segment per decoder
     layer, announcements start that layer's reduction, and the result is bit-identical to the non-overlapped schedule."""
     for ov in (False, True):
-        mp.spawn(_model_worker, args=(world, _free_port(), str(tmp_path), ov), nprocs=world, join=True)
+        mp.spawn(_model_worker, args=(world, _free_port(), str(tmp_path), ov, tensor_coll), nprocs=world, join=True)
     a = [torch.load(os.path.join(tmp_path, f"model_rank{r}_ov0.pt")) for r in range(world)]
     b = [torch.load(os.path.join(tmp_path, f"model_rank{r}_ov1.pt")) for r in range(world)]
     assert all(torch.equal(a[0], x) for x in a[1:] + b)
@@ -360,6 +370,7 @@ def _group_worker(rank, world, port, tmp):
             opt.step()
             opt.zero_grad()
         torch.save(torch.cat([p.data.reshape(-1) for p in params]), os.path.join(tmp, f"grp_rank{rank}.pt"))
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 

@@ -68,8 +68,10 @@ def _walk(model, opt, step, micro, rank, F, zero3):
         F._LAYER_GRAD_HOOK(layer)
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if tensor_coll:     # the RCCL form (all_gather_into_tensor into the slot, reduce_scatter_tensor out of the gradient slot) on gloo
+        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd import functional as F
@@ -80,6 +82,7 @@ def _worker(rank, world, port, tmp):
                          sumsq=_oracle_sumsq, clip_coef=_oracle_clip, accumulate=_accum, param_slots=2, grad_slots=1, min_shard_numel=1).enable_hooks()
         layers = model.get_model().layers
         assert len(opt.layer_order) == 4 and all(opt.segs[i]["m"] * world == opt.segs[i]["n"] for i in opt.layer_order)
+        assert opt._tensor_coll == bool(tensor_coll)
         # released layers hold no storage; resident tensors do
         assert all(p.data.numel() == 0 for l in layers for p in l.parameters())
         assert model.lm_head.weight.data.numel() == model.lm_head.weight.numel()
@@ -116,13 +119,16 @@ def _worker(rank, world, port, tmp):
         assert att.k_proj.weight.data_ptr() == att.q_proj.weight.data_ptr() + att.q_proj.weight.numel() * att.q_proj.weight.element_size()
         F.set_param_ready_hook(None)
         F.set_layer_grad_hook(None)
+        opt.synchronize()                                      # the prefetch of layer 2 started by params_ready(layers[1]) above
+        dist.barrier()                                         # no rank tears its sockets down while a peer is still inside a collective
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_zero3_n_ranks_equal_zero2_one_rank(tmp_path, world):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,tensor_coll", [(2, False), (8, False), (2, True), (4, True), (8, True)])
+def test_zero3_n_ranks_equal_zero2_one_rank(tmp_path, world, tensor_coll):
+    """tensor_coll: the branch RCCL runs (tensor collectives straight into / out of the parameter and gradient slots), driven on gloo."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), tensor_coll), nprocs=world, join=True)
     a = torch.load(tmp_path / "z3_rank0.pt")
     for r in range(1, world):
         assert torch.equal(a, torch.load(tmp_path / f"z3_rank{r}.pt"))
