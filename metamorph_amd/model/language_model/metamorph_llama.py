@@ -687,7 +687,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
                 L0 = int(inputs_embeds.shape[1])
                 new = kwargs.get("max_new_tokens")
                 if new is None and kwargs.get("max_length") is not None:
-                    new = max(int(kwargs["max_length"]), 1)              # with inputs_embeds HF counts max_length over NEW tokens
+                    new = max(int(kwargs["max_length"]) - L0, 1)         # HF subtracts the inputs_embeds length from max_length itself
                 if new is None:
                     gc = kwargs.get("generation_config") or self.generation_config
                     new = getattr(gc, "max_new_tokens", None) or getattr(gc, "max_length", 20) or 20

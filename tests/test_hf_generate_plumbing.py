@@ -75,6 +75,14 @@ def test_hf_generate_greedy_and_sampling_reproduce_reference_ids():
         out = model.generate(inputs=ids, use_customize_greedy=False, do_sample=True, temperature=0.7, top_p=0.9,
                              max_new_tokens=int(g["max_new_tokens"]), eos_token_id=128009, pad_token_id=128001)
         assert out[0].tolist() == g["sampled_tokens"].tolist() == want
+    # `max_length` instead of `max_new_tokens`: HF counts the prompt rows in (it subtracts the inputs_embeds length itself); sizes the cache too
+    L0 = ids.shape[1]
+    full = model.generate(inputs=ids, use_customize_greedy=False, do_sample=False, max_length=L0 + int(g["max_new_tokens"]), eos_token_id=128009,
+                          pad_token_id=128001, return_dict_in_generate=True)
+    assert full.sequences[0].tolist() == want and full.past_key_values.capacity == L0 + int(g["max_new_tokens"]) + 2
+    cut = model.generate(inputs=ids, use_customize_greedy=False, do_sample=False, max_length=L0 + 3, eos_token_id=128009, pad_token_id=128001,
+                         return_dict_in_generate=True)
+    assert cut.sequences[0].tolist() == want[:3] and cut.past_key_values.capacity == L0 + 3 + 2
 
 
 def test_hf_generate_beam_search_reproduces_reference_beams():
