@@ -97,6 +97,7 @@ class _SeqState:
         self.kv = None                    # functional.KVCache
         self.stepper = None               # functional.DecodeStepGraph
         self.meta = None
+        self.pad = 0                      # left-padding rows of this sequence in the batch HF sees (never cached: kv.length counts real rows)
 
 
 class HipKVCache(DynamicCache):
@@ -116,7 +117,8 @@ class HipKVCache(DynamicCache):
         return self.states[0].kv if self.states else None
 
     def get_seq_length(self, layer_idx=0):
-        return 0 if not self.states else int(self.states[0].kv.length)
+        # the length HF counts: padded prompt + generated tokens, the same for every row of a left-padded batch
+        return 0 if not self.states else int(self.states[0].kv.length) + self.states[0].pad
 
     def get_max_cache_shape(self, layer_idx=0):
         return -1 if not self.states else int(self.states[0].kv.max_len)
@@ -130,12 +132,16 @@ class HipKVCache(DynamicCache):
         moved = [(i, j) for i, j in enumerate(idx) if i != j]
         if not moved:
             return
-        n = self.get_seq_length()
-        snap = {j: (self.states[j].kv.k[:, :, :n].clone(), self.states[j].kv.v[:, :, :n].clone()) for j in {j for _, j in moved}}
+        snap = {}
+        for j in {j for _, j in moved}:
+            n = int(self.states[j].kv.length)
+            snap[j] = (n, self.states[j].pad, self.states[j].kv.k[:, :, :n].clone(), self.states[j].kv.v[:, :, :n].clone())
         for i, j in moved:
-            self.states[i].kv.k[:, :, :n].copy_(snap[j][0])
-            self.states[i].kv.v[:, :, :n].copy_(snap[j][1])
+            n, pad, k, v = snap[j]
+            self.states[i].kv.k[:, :, :n].copy_(k)
+            self.states[i].kv.v[:, :, :n].copy_(v)
             self.states[i].kv.set_length(n)
+            self.states[i].pad = pad
 
     def crop(self, max_length):
         for st in self.states:
@@ -633,8 +639,6 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         if inputs_embeds.dtype != BF16:
             raise TypeError(f"inputs_embeds must be bf16, got {inputs_embeds.dtype}")
         B, n, h = inputs_embeds.shape
-        if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
-            raise NotImplementedError("cached decoding takes un-padded prompts (attention_mask all ones)")
         cache = past_key_values
         if cache is None:
             cache = HipKVCache()
@@ -646,10 +650,27 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         first = not cache.states
         if first:
             cache.states = [_SeqState() for _ in range(B)]    # batch rows / beams are independent sequences, each with its own cache
+            # A batch of prompts of different lengths arrives LEFT-padded with its attention mask (the reference: HF generate derives
+            # position_ids = cumsum(mask) - 1 from it, so every row is decoded exactly as it would be alone).  Here the padding rows are never
+            # computed or cached: each sequence keeps its own length, `pad` only restores the common length HF counts.
+            if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
+                m = attention_mask.to(torch.bool).cpu()
+                if tuple(m.shape) != (B, n):
+                    raise ValueError(f"attention_mask {tuple(m.shape)} does not match the prompt batch {(B, n)}")
+                for b, st in enumerate(cache.states):
+                    nb = int(m[b].sum())
+                    if nb == 0 or not bool(m[b, n - nb:].all()):
+                        raise NotImplementedError("cached decoding takes LEFT-padded prompts (valid rows at the end); right padding puts pad rows "
+                                                  "between the prompt and the generated tokens in the reference as well")
+                    st.pad = n - nb
         elif len(cache.states) != B:
             raise ValueError(f"cache holds {len(cache.states)} sequences, the step brings {B}")
         rows = []
         for b, st in enumerate(cache.states):
+            if first and st.pad:
+                r = self._prefill_rows(inputs_embeds[b, st.pad:].reshape(n - st.pad, h).contiguous(), st, cache.capacity)
+                rows.append(torch.cat([r.new_zeros((st.pad, h)), r], 0))     # padding positions: rows nobody reads (HF takes logits[:, -1])
+                continue
             x2d = inputs_embeds[b].reshape(n, h).contiguous()
             rows.append(self._prefill_rows(x2d, st, cache.capacity) if first else self._decode_rows(x2d, st))
         rows = rows[0] if B == 1 else torch.cat(rows, 0)

@@ -1110,6 +1110,21 @@ def gen_hfgen():
             beams[tag] = (bo.sequences.clone(), bo.sequences_scores.float().clone())
         assert beams["f32"][0].tolist() == beams["bf16"][0].tolist(), (beams["f32"][0].tolist(), beams["bf16"][0].tolist())
         assert beams["f32"][0][0].tolist()[:len(toks)] == toks
+        # a BATCH of two prompts, the shorter one left-padded, with its attention mask (text case): HF derives position_ids from the mask, so
+        # each row generates what it generates alone
+        batch = {}
+        if images is None:
+            model = build_reference(cfg, sd2, torch.float32)
+            model.eval()
+            short = ids[0][:2] + ids[0][4:]
+            rows2 = torch.tensor([ids[0], [128001] * (len(ids[0]) - len(short)) + short])
+            with torch.no_grad():
+                b_out = model.generate(inputs=rows2, images=None, attention_mask=rows2.ne(128001), use_customize_greedy=False, do_sample=False,
+                                       max_new_tokens=6, eos_token_id=128009, pad_token_id=128001)
+                alone = model.generate(inputs=torch.tensor([short]), images=None, use_customize_greedy=False, do_sample=False,
+                                       max_new_tokens=6, eos_token_id=128009, pad_token_id=128001)
+            batch = dict(batch_input_ids=rows2, batch_attention_mask=rows2.ne(128001), batch_sequences=b_out, short_alone_sequence=alone[0])
+            print(f"    {name}: batched left-padded generate {b_out.tolist()}; the short prompt alone {alone[0].tolist()}")
         print(f"    {name}: beams {beams['f32'][0].tolist()} scores {beams['f32'][1].tolist()} (bf16 {beams['bf16'][1].tolist()})")
         save_npz(f"hfgen_{name}.npz", beam_sequences=beams["f32"][0], beam_scores=beams["f32"][1], beam_scores_bf16=beams["bf16"][1],
                  seed=np.int64(seed), input_ids=ids_t, images=images if images is not None else torch.zeros(0),
@@ -1117,7 +1132,7 @@ def gen_hfgen():
                  row_values=torch.stack(list(rows.values())), tokens=np.array(toks, dtype=np.int64), margins=margins,
                  top_prob_at_T07=probs, sampled_tokens=np.array(sampled[0], dtype=np.int64),
                  active_logits=torch.stack([l[DECODE_ACTIVE] for l in logits]),
-                 active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]), max_new_tokens=np.int64(10))
+                 active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]), max_new_tokens=np.int64(10), **batch)
         print(f"    {name}: seed {seed} tokens {toks} min margin {float(margins.min()):.2f} min top prob at T=0.7 {float(probs.min()):.4f}")
 
 

@@ -99,6 +99,37 @@ def test_hf_generate_beam_search_reproduces_reference_beams():
     assert len(out.past_key_values.states) == 2
 
 
+def test_hf_generate_batch_of_left_padded_prompts_reproduces_reference():
+    """Two prompts of different lengths, the shorter LEFT-padded, with their attention mask (the reference: HF derives position_ids from the
+    mask, each row generates what it generates alone -- recorded in hfgen_text.npz).  Here the padding rows are never computed or cached:
+    each sequence is prefilled on its own rows, and the cache reports the common padded length HF counts."""
+    g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
+    model, calls = _cpu_model(g)
+    ids, mask = torch.from_numpy(g["batch_input_ids"]), torch.from_numpy(g["batch_attention_mask"])
+    assert not bool(mask[1, 0]) and bool(mask[1, -1])             # row 1 is left-padded
+    out = model.generate(inputs=ids, attention_mask=mask, use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009,
+                         pad_token_id=128001, return_dict_in_generate=True)
+    assert out.sequences.tolist() == g["batch_sequences"].tolist(), (out.sequences.tolist(), g["batch_sequences"].tolist())
+    assert out.sequences[1].tolist() == g["short_alone_sequence"].tolist()
+    st = out.past_key_values.states
+    n_pad = int((~mask[1]).sum())
+    assert [s.pad for s in st] == [0, n_pad] and st[0].kv.length == st[1].kv.length + n_pad      # pad rows were never cached
+    assert calls["prefill"] == 2
+    # the short prompt alone walks through exactly the same per-step computation
+    alone = model.generate(inputs=ids[1:, n_pad:], use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009,
+                           pad_token_id=128001, return_dict_in_generate=True, output_scores=True)
+    both = model.generate(inputs=ids, attention_mask=mask, use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009,
+                          pad_token_id=128001, return_dict_in_generate=True, output_scores=True)
+    assert alone.sequences[0].tolist() == both.sequences[1].tolist()
+    for a, b in zip(alone.scores, both.scores):                   # (the stand-in lm_head is a CPU matmul over all rows of the call: last-bit differences)
+        torch.testing.assert_close(a[0], b[1], rtol=1e-5, atol=1e-5)
+    # right padding is refused (it would put pad rows between the prompt and the generated tokens)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        model.generate(inputs=ids.flip(1), attention_mask=mask.flip(1), use_customize_greedy=False, do_sample=False, max_new_tokens=2,
+                       eos_token_id=128009, pad_token_id=128001)
+
+
 def test_hip_kv_cache_is_a_transformers_cache():
     from transformers.cache_utils import Cache
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
@@ -107,7 +138,7 @@ def test_hip_kv_cache_is_a_transformers_cache():
     def seq(n, fill):
         kv = SimpleNamespace(k=torch.full((2, 1, 32, 4), fill), v=torch.full((2, 1, 32, 4), -fill), length=n, max_len=32)
         kv.set_length = lambda m, kv=kv: setattr(kv, "length", m)
-        return SimpleNamespace(kv=kv, stepper=None, meta=None)
+        return SimpleNamespace(kv=kv, stepper=None, meta=None, pad=0)
     c.states = [seq(7, 1.0), seq(7, 2.0), seq(7, 3.0)]
     assert c.get_seq_length() == 7 and c.get_max_cache_shape() == 32
     c.reorder_cache(torch.tensor([1, 1, 0]))                      # row 1 is source AND target, row 0 both as well: snapshot semantics
