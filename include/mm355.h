@@ -201,6 +201,15 @@ int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v
                    mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
                    int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, void* stream);
 
+/* mm355_attn_fwd with the kernel generation chosen by the caller -- for tests and tools/ (A/B timing, the serialised debugging stream);
+ * the product calls mm355_attn_fwd.  variant: 0 = as mm355_attn_fwd; 3 = the two-waves-per-SIMD d == 128 kernels; 4 = the one-wave-per-SIMD
+ * hand-placed stream (d == 128); 41 = the same stream serialised (every LDS read waited for at once, 32 wait states behind every MFMA:
+ * bit-identical to 4 by construction).  MM355_EUNSUPPORTED when the variant does not cover the geometry.  Same reference call site as
+ * mm355_attn_fwd (torch SDPA reached at metamorph_llama.py:349-359). */
+int mm355_attn_fwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
+                           mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
+                           int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, int variant, void* stream);
+
 /* delta[b][h][l] = sum_dd dO*O  (softmax-backward row term). */
 int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta,
                         int64_t B, int64_t L, int64_t Hq, int64_t d, void* stream);

@@ -10,8 +10,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "decode.hip", "losses.hip"]
-HEADERS = ["mm355_common.h", "attn2.h", "attn3_kernels.h"]
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn4.hip", "decode.hip", "losses.hip"]
+HEADERS = ["mm355_common.h", "attn2.h", "attn3_kernels.h"] + sorted(
+    os.path.join("attn4_gen", f) for f in os.listdir(os.path.join(CSRC, "attn4_gen")) if f.endswith(".inc"))   # tools/gen_attn4.py output
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD): no accumulator <-> VGPR moves around the VALU phases
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]

@@ -66,16 +66,36 @@ bool fast128(int64_t d, int64_t ld_k) {
 
 }  // namespace
 
-extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
-                              int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
-                              int64_t d, float scale, int causal, void* stream) {
+namespace {
+// variant: 0 = the product's choice, 3 = the two-waves-per-SIMD kernels of attn3.hip, 4 = the one-wave-per-SIMD stream of attn4.hip,
+// 41 = attn4's serialised debugging stream (bit-identical to 4 by construction; tests / tools only)
+int attn_fwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
+                  int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
+                  int64_t d, float scale, int causal, int variant, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !o || !lse || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7)) return MM355_EINVAL;
     attn2::Args a{q, k, v, nullptr, ld_q, ld_k, ld_o, o, lse, nullptr, nullptr, nullptr, 0, seqlens,
                   nullptr, nullptr, nullptr, nullptr, 0, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
+    const bool can4 = d == 128 && L * ld_k * 2 < 0x7fffffffll;          // 32-bit descriptor offsets inside one sample
+    if (variant == 4 || variant == 41) return can4 ? mm355_attn4_fwd_launch(a, variant == 41, (hipStream_t)stream) : MM355_EUNSUPPORTED;
+    if (variant == 3) return fast128(d, ld_k) ? mm355_attn3_fwd_launch(a, (hipStream_t)stream) : MM355_EUNSUPPORTED;
+    if (variant != 0) return MM355_EINVAL;
     if (fast128(d, ld_k)) return mm355_attn3_fwd_launch(a, (hipStream_t)stream);
     return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
+                              int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
+                              int64_t d, float scale, int causal, void* stream) {
+    return attn_fwd_impl(q, k, v, ld_q, ld_k, o, ld_o, lse, seqlens, B, L, Hq, Hkv, d, scale, causal, 0, stream);
+}
+
+extern "C" int mm355_attn_fwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
+                                      int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
+                                      int64_t d, float scale, int causal, int variant, void* stream) {
+    return attn_fwd_impl(q, k, v, ld_q, ld_k, o, ld_o, lse, seqlens, B, L, Hq, Hkv, d, scale, causal, variant, stream);
 }
 
 extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta, int64_t B, int64_t L,

@@ -369,8 +369,9 @@ def gemm_rope(x, wqkv, B, L, Hq, Hkv, d, cos, sin, pos_offset=None):
     return qkv
 
 
-def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None):
-    """q2d/k2d/v2d: [B*L, ld] views starting at the q / k / v column blocks (k and v share the leading dimension)."""
+def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=None, variant=0):
+    """q2d/k2d/v2d: [B*L, ld] views starting at the q / k / v column blocks (k and v share the leading dimension).
+    variant != 0 (tests / tools only) picks the kernel generation: mm355_attn_fwd_variant in include/mm355.h."""
     _chk_dev(q2d, k2d, v2d)
     pq, M, _, ldq = _rows2d(q2d)
     pk, _, _, ldk = _rows2d(k2d)
@@ -379,6 +380,10 @@ def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=N
     if out is None:
         out = torch.empty((M, Hq * d), device=q2d.device, dtype=BF16)
     lse = torch.empty((B, Hq, L), device=q2d.device, dtype=torch.float32)
+    if variant:
+        _lib.check(_L().mm355_attn_fwd_variant(pq, pk, pv, ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
+                                               B, L, Hq, Hkv, d, scale, int(causal), int(variant), _stream()), "mm355_attn_fwd_variant")
+        return out, lse
     _lib.check(_L().mm355_attn_fwd(pq, pk, pv, ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
                                    B, L, Hq, Hkv, d, scale, int(causal), _stream()), "mm355_attn_fwd")
     return out, lse
