@@ -81,6 +81,7 @@ int attn_fwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
     if (variant == 4 || variant == 41) return can4 ? mm355_attn4_fwd_launch(a, variant == 41, (hipStream_t)stream) : MM355_EUNSUPPORTED;
     if (variant == 3) return fast128(d, ld_k) ? mm355_attn3_fwd_launch(a, (hipStream_t)stream) : MM355_EUNSUPPORTED;
     if (variant != 0) return MM355_EINVAL;
+    if (can4 && fast128(d, ld_k)) return mm355_attn4_fwd_launch(a, 0, (hipStream_t)stream);
     if (fast128(d, ld_k)) return mm355_attn3_fwd_launch(a, (hipStream_t)stream);
     return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
 }

@@ -18,6 +18,14 @@
 // Replaces torch SDPA as driven by HF LlamaModel (reference call site metamorph_llama.py:349-359).
 #include "attn3_kernels.h"
 
+// the generated streams; timing-only ablation builds (tools/gen_attn4.py --abl ...) compile with -DATTN4_GEN_DIR=attn4_gen_<name>
+#ifndef ATTN4_GEN_DIR
+#define ATTN4_GEN_DIR attn4_gen
+#endif
+#define ATTN4_STR2(x) #x
+#define ATTN4_STR(x) ATTN4_STR2(x)
+#define ATTN4_INC(f) ATTN4_STR(ATTN4_GEN_DIR/f)
+
 namespace attn4 {
 using namespace attn2;
 using attn3::block_coords;
@@ -28,7 +36,6 @@ constexpr int TILE = 16384;                                  // [64 rows][128] b
 constexpr int VRING = 2 * TILE;                              // K slots 0, 1 | V slots 0, 1
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float THR = 6.0f;                                  // log2 units: the running maximum stays while no row grew by more than 2^6
-constexpr uint32_t DMA_SKIP = 0x7fff0000u;                   // a voffset beyond every descriptor: the piece arrives as zeros, no memory access
 
 MM_DEV float half_swap_max(float m) {                        // max over the two lanes (l, l ^ 32) that share a query row
     float a = m, b = m;
@@ -44,14 +51,23 @@ MM_DEV float half_swap_sum(float m) {
 }
 
 #define ATTN4_BARRIER() do { if (do_bar) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
-#define ATTN4_DMA_K(i) do { if (do_bar) { const uint32_t vo_ = kvo[i] + kdma_off; __builtin_amdgcn_sched_barrier(0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + kdst + (i) * 1024), 16, vo_, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define ATTN4_DMA_V(i) do { if (do_bar) { const uint32_t vo_ = vvo[i] + vdma_off; __builtin_amdgcn_sched_barrier(0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(smem + vdst + (i) * 1024), 16, vo_, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } } while (0)
+// one 1-KiB piece of the tile the step's descriptor points at (base = the tile's first row, num_records = what is left of the sample from
+// there, 0 for a tile nobody needs: every lane out of range, zeros, no memory access); the lane part of the address never changes
+#define ATTN4_DMA_K(i) do { __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lptr_t)(smem + kdst + (i) * 1024), 16, kvo[i], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN4_DMA_V(i) do { if (do_bar) { __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(smem + vdst + (i) * 1024), 16, vvo[i], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); } } while (0)
 template <bool SAFE>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void fwd_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
     asm volatile("" ::: "v255", "a255");                   // the stream's literal registers: the descriptor must allocate the whole file
+#ifdef MM355_ATTN4_TIMING                                    // TIMING-ONLY build (tools/): phase stamps of waves 0 and 3 overwrite the block's lse rows
+    const long long tm0 = __builtin_readcyclecounter();
+    long long tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0, tm5 = 0;
+#define ATTN4_STAMP(x) x = __builtin_readcyclecounter()
+#else
+#define ATTN4_STAMP(x) do {} while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hi = lane >> 5;
@@ -83,8 +99,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
     const uint16_t* kbase = a.k + row_base * a.ld_k + (int64_t)hk * 128;
     const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * 128;
     const uint32_t nrec = (uint32_t)(seqlen - 1) * ldb + 256u;                             // rows >= seqlen are out of range: zeros
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, nrec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, nrec, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsK, rsV;
+#define ATTN4_TILE_RSRC(base_, tile_) __builtin_amdgcn_make_buffer_rsrc((void*)((base_) + (int64_t)(tile_) * 64 * a.ld_k), 0, \
+    (tile_) < T ? nrec - (uint32_t)(tile_) * 64u * ldb : 0u, 0x00020000)
     // piece i of this wave = tile rows 16*wave + 4*i + (lane >> 4); LDS side lane-linear, swizzle on the source chunk
     uint32_t kvo[4], vvo[4];
     {
@@ -96,36 +113,30 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
             vvo[i] = row * ldb + (uint32_t)((pc ^ (r4 << 2)) << 4);
         }
     }
+    // raw Q rows first (HBM latency is the prologue's critical path): lane holds Q[q = qb*32 + c][d = ks*16 + hi*8 .. + 8] -> v[128:191]
+    const float sl2 = a.scale * LOG2E;
+    {
+        const uint16_t* qp0_ = a.q + (row_base + min(qw0 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
+        const uint16_t* qp1_ = a.q + (row_base + min(qw0 + 32 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
+#include ATTN4_INC(q_load.inc)
+    }
     bool do_bar = true;
-    uint32_t kdma_off, vdma_off;
     int kdst, vdst;
-    // prologue: K(0), V(0) -> slot 0, K(1) -> slot 1
-    kdma_off = 0; vdma_off = 0; kdst = wave * 4096; vdst = VRING + wave * 4096;
+    // K(0), V(0) -> slot 0, K(1) -> slot 1
+    rsK = ATTN4_TILE_RSRC(kbase, 0); rsV = ATTN4_TILE_RSRC(vbase, 0); kdst = wave * 4096; vdst = VRING + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ATTN4_DMA_V(i); }
-    kdma_off = 1 < T ? 64u * ldb : DMA_SKIP; kdst = TILE + wave * 4096;
+    rsK = ATTN4_TILE_RSRC(kbase, 1); kdst = TILE + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
-
-    // Q~ fragments (B operands): lane holds Q[q = qb*32 + c][d = ks*16 + hi*8 .. + 8] * scale * log2(e), rounded to bf16
-    const float sl2 = a.scale * LOG2E;
-#pragma unroll
-    for (int qb_ = 0; qb_ < 2; ++qb_) {
-        const uint16_t* qp = a.q + (row_base + min(qw0 + qb_ * 32 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
-#pragma unroll
-        for (int ks_ = 0; ks_ < 8; ++ks_) {
-            const u32x4 w = *(const u32x4*)(qp + ks_ * 16);
-            uint32_t w_[4];
-            w_[0] = pack2bf(bflo(w.x) * sl2, bfhi(w.x) * sl2); w_[1] = pack2bf(bflo(w.y) * sl2, bfhi(w.y) * sl2);
-            w_[2] = pack2bf(bflo(w.z) * sl2, bfhi(w.z) * sl2); w_[3] = pack2bf(bflo(w.w) * sl2, bfhi(w.w) * sl2);
-#include "attn4_gen/q_write.inc"
-        }
-    }
-#include "attn4_gen/zero_o.inc"
-    float LS[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // [qb][kb] row sums of this lane's keys
-    float MX[2][2];
+#include ATTN4_INC(zero_o.inc)
+    float LS[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // [qb][r & 3] partial row sums of this lane's keys
+    float MX[2][2], rm_[2], rt_[2];
+    uint64_t grow_ = 0;
+    float thr_ = THR;
+    asm volatile("" : "+v"(thr_));
     const float ninf = -INFINITY;
     // LDS read addresses: K rows (b128), logical chunk ks*2 + hi of row c at physical chunk ^ (c & 15); V gathers (tr_b64): lane i of a
     // 16-lane group g supplies row 4*hi + (i >> 2), columns db*32 + (g & 1)*16 + (i & 3)*4 .. + 3, 64-B slot db ^ (row & 3)
@@ -151,70 +162,82 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
             lim2[qb] = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - tw * 64 - 4 * hi;
         }
     }
+    // Q~ = bf16(q * scale * log2 e): d-steps 0 and 1 here (the 16 row loads precede the 12 DMA pieces in the memory queue), 2..7 inside the head
+    float t0_, t1_;
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#include ATTN4_INC(q_pre01.inc)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+// step s moves K(s + 2) (phase A, before barrier s: its slot was K(s)'s, whose last reader passed barrier s - 1) and V(s + 2) (behind barrier s)
 #define ATTN4_STEP_VARS(s_) do { const int s__ = (s_); \
-    kdma_off = s__ + 3 < T ? (uint32_t)(s__ + 3) * 64u * ldb : DMA_SKIP; vdma_off = s__ + 2 < T ? (uint32_t)(s__ + 2) * 64u * ldb : DMA_SKIP; \
-    kdst = ((s__ + 3) & 1) * TILE + wave * 4096; vdst = VRING + (s__ & 1) * TILE + wave * 4096; } while (0)
+    rsK = ATTN4_TILE_RSRC(kbase, s__ + 2); rsV = ATTN4_TILE_RSRC(vbase, s__ + 2); \
+    kdst = (s__ & 1) * TILE + wave * 4096; vdst = VRING + (s__ & 1) * TILE + wave * 4096; } while (0)
 
+    ATTN4_STAMP(tm1);
     if (tw >= 0) {
         bool mask_next = tw == 0;
         ATTN4_STEP_VARS(-1);
         if constexpr (SAFE) {
-#include "attn4_gen/safe_head.inc"
+#include ATTN4_INC(safe_head.inc)
         } else {
-#include "attn4_gen/head.inc"
+#include ATTN4_INC(head.inc)
         }
+        ATTN4_STAMP(tm2);
         int t = 0;
         for (;;) {
             if (t >= tw) break;
             mask_next = t + 1 == tw;
             ATTN4_STEP_VARS(t);
             if constexpr (SAFE) {
-#include "attn4_gen/safe_loop0.inc"
+#include ATTN4_INC(safe_loop0.inc)
             } else {
-#include "attn4_gen/loop0.inc"
+#include ATTN4_INC(loop0.inc)
             }
             ++t;
             if (t >= tw) break;
             mask_next = t + 1 == tw;
             ATTN4_STEP_VARS(t);
             if constexpr (SAFE) {
-#include "attn4_gen/safe_loop1.inc"
+#include ATTN4_INC(safe_loop1.inc)
             } else {
-#include "attn4_gen/loop1.inc"
+#include ATTN4_INC(loop1.inc)
             }
             ++t;
         }
+        ATTN4_STAMP(tm3);
         do_bar = tw <= T - 2;
         ATTN4_STEP_VARS(tw);
         if (tw & 1) {
             if constexpr (SAFE) {
-#include "attn4_gen/safe_tail1.inc"
+#include ATTN4_INC(safe_tail1.inc)
             } else {
-#include "attn4_gen/tail1.inc"
+#include ATTN4_INC(tail1.inc)
             }
         } else {
             if constexpr (SAFE) {
-#include "attn4_gen/safe_tail0.inc"
+#include ATTN4_INC(safe_tail0.inc)
             } else {
-#include "attn4_gen/tail0.inc"
+#include ATTN4_INC(tail0.inc)
             }
         }
     }
+    ATTN4_STAMP(tm4);
     // a wave that is done keeps moving its quarter of every remaining tile and meets the barriers of steps <= T - 2
     do_bar = true;
     for (int s = tw < 0 ? -1 : tw + 1; s <= T - 2; ++s) {
         ATTN4_STEP_VARS(s);
-        ATTN4_BARRIER();
+        if (s >= 0) {                                        // (K(1) left with the prologue)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
+            for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
+        }
+        ATTN4_BARRIER();
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ATTN4_DMA_V(i); }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // last P V MFMAs, stray DMA
     __syncthreads();                                         // every wave is done with the rings: they become the output staging area
+    ATTN4_STAMP(tm5);
 
     // epilogue: O = O^T / l -> bf16 [q][d] in this wave's 16 KiB (16-B chunk ^ (row & 15)) -> row-contiguous 16-B stores
     unsigned char* so = smem + wave * TILE;
@@ -222,12 +245,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
     for (int qb_ = 0; qb_ < 2; ++qb_) {
         const int qg = qw0 + qb_ * 32 + c;
         const bool valid = qg < seqlen && tw >= 0;
-        const float l_run = half_swap_sum(LS[qb_][0] + LS[qb_][1]);
+        const float l_run = half_swap_sum((LS[qb_][0] + LS[qb_][1]) + (LS[qb_][2] + LS[qb_][3]));
         const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
         for (int db_ = 0; db_ < 4; ++db_) {
             float x_[16];
-#include "attn4_gen/epi_read.inc"
+#include ATTN4_INC(epi_read.inc)
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 u32x2 w;
@@ -247,6 +270,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
         const int qg = qw0 + r;
         if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + j * 8) = *(const u32x4*)(so + r * 256 + ((j ^ (r & 15)) << 4));
     }
+#ifdef MM355_ATTN4_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tm6 = __builtin_readcyclecounter();
+    if (lane == 0 && (wave == 0 || wave == 3) && q0 + 64 <= L) {
+        long long* w = (long long*)(lse_base + q0) + (wave == 3 ? 8 : 0);
+        w[0] = tm1 - tm0; w[1] = tm2 - tm1; w[2] = tm3 - tm2; w[3] = tm4 - tm3; w[4] = tm5 - tm4; w[5] = tm6 - tm5; w[6] = tw; w[7] = T;
+    }
+#endif
 }
 
 }  // namespace attn4

@@ -24,12 +24,15 @@ Emitted blocks (included inside attn4::fwd_kernel, which declares the few compil
     head         QK(0), row maxima + first maximum                                   (step -1)
     loop<p>      QK(t + 1) || softmax-finish(t)   then   PV(t) || row maxima(t + 1)     (step t, parity p = t & 1)
     tail<p>      softmax-finish(tw) then PV(tw)                                      (a wave's last tile)
-    zero_o, q_write, epi_read   accumulator initialisation / Q~ placement / read-out
+    zero_o, q_load, q_pre01, epi_read   accumulator initialisation / raw Q rows -> v[128:191] / Q~ of d-steps 0, 1 / read-out
+                 (the Q~ fragments of d-steps 2..7 are scaled and placed under the head's score MFMAs)
 `safe_*` are the same streams with every LDS read waited for at once and every MFMA followed by 32 wait states: the debugging build that
 separates a placement / hazard defect from a logic defect (tools/bench_attn4.py runs both).
 """
 import os
+import sys
 
+ABL = set()                                                  # timing-only ablations (--abl a,b,...): the build is WRONG by construction
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metamorph_amd", "csrc", "attn4_gen")
 TILE = 16384
 O_A, Q_A, KRING_A, VRING_A = 0, 128, 192, 224
@@ -101,7 +104,7 @@ class Stream:
         return self.issued
 
     def wait(self, ident):
-        if ident <= self.done:
+        if ident <= self.done or "nolds" in ABL:
             return
         n = min(self.issued - ident, 15)
         self.asm("s_waitcnt lgkmcnt(%d)" % n)
@@ -133,14 +136,30 @@ def emit_mask(st, nxt):
     st.raw("}")
 
 
+def emit_dec_step(st, i):
+    """row maxima of tile t + 1 across the two lanes of a row, and the wave-wide "some row grew by more than 2^THR" mask: five small steps
+    placed under the last P V MFMAs (a v_permlane32_swap needs its operands two wait states old; the branch reads an SGPR pair written long before)"""
+    if i == 0:
+        st.asm("v_max_f32 %0, %2, %3\\n\\tv_max_f32 %1, %4, %5", '"=&v"(rm_[0]), "=&v"(rm_[1])', '"v"(MX[0][0]), "v"(MX[0][1]), "v"(MX[1][0]), "v"(MX[1][1])')
+    elif i == 1:
+        st.asm("v_mov_b32 %0, %2\\n\\tv_mov_b32 %1, %3", '"=&v"(rt_[0]), "=&v"(rt_[1])', '"v"(rm_[0]), "v"(rm_[1])')
+    elif i == 2:
+        st.asm("v_permlane32_swap_b32 %0, %1\\n\\tv_permlane32_swap_b32 %2, %3", '"+v"(rm_[0]), "+v"(rt_[0]), "+v"(rm_[1]), "+v"(rt_[1])', "")
+    elif i == 3:
+        st.asm("v_max_f32 %0, %0, %2\\n\\tv_max_f32 %1, %1, %3", '"+v"(rm_[0]), "+v"(rm_[1])', '"v"(rt_[0]), "v"(rt_[1])')
+    else:
+        st.asm("v_max_f32 %1, %2, %3\\n\\ts_nop 0\\n\\tv_cmp_lt_f32 %0, %4, %1", '"=s"(grow_), "=&v"(rt_[0])', '"v"(rm_[0]), "v"(rm_[1]), "v"(thr_)')
+
+
 def emit_decide(st, nxt, head):
-    st.raw("{ float rm_[2];")
-    st.raw("  rm_[0] = half_swap_max(max2_raw(MX[0][0], MX[0][1])); rm_[1] = half_swap_max(max2_raw(MX[1][0], MX[1][1]));")
+    st.raw("{")
+    if head:
+        st.raw("  rm_[0] = half_swap_max(max2_raw(MX[0][0], MX[0][1])); rm_[1] = half_swap_max(max2_raw(MX[1][0], MX[1][1]));")
     if head:                                                 # first tile: the running maximum becomes the tile's row maximum (the chain ran with C = 0)
         st.raw("  rm_[0] = rm_[0] == -INFINITY ? 0.f : rm_[0]; rm_[1] = rm_[1] == -INFINITY ? 0.f : rm_[1];")
         st.raw("  {")
     else:                                                    # later tiles: s' is relative to the running maximum; move it only when a row grew by > 2^THR
-        st.raw("  if (__builtin_amdgcn_ballot_w64(rm_[0] > THR || rm_[1] > THR) != 0) {")
+        st.raw("  if (grow_ != 0) {")
         st.raw("    rm_[0] = fmaxf(rm_[0], 0.f); rm_[1] = fmaxf(rm_[1], 0.f);")
         st.raw("    const float al_[2] = {__builtin_amdgcn_exp2f(-rm_[0]), __builtin_amdgcn_exp2f(-rm_[1])};")
         st.asm("s_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15")    # the P V MFMAs drain
@@ -152,7 +171,7 @@ def emit_decide(st, nxt, head):
                     st.asm("v_accvgpr_read_b32 %%0, a%d\\n\\tv_accvgpr_read_b32 %%1, a%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
                            "v_accvgpr_write_b32 a%d, %%0\\n\\tv_accvgpr_write_b32 a%d, %%1" % (a0, a0 + 1, a0, a0 + 1),
                            '"=&v"(t0_), "=&v"(t1_)', '"v"(al_[%d])' % qb)
-            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d];" % (qb, qb, qb, qb))
+            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d]; LS[%d][2] *= al_[%d]; LS[%d][3] *= al_[%d];" % ((qb, qb) * 4))
     for qb in range(2):
         for kb in range(2):
             for r in range(16):
@@ -211,6 +230,8 @@ def gen(mode, par, safe):
 
     def do_filler(f):
         kind = f[0]
+        if ("no" + kind) in ABL or (kind in ("kread", "vread", "kpre") and "nolds" in ABL):
+            return
         if kind == "exp":
             _, kb, qb, r = f
             v = s_blk(par, kb, qb) + r
@@ -227,7 +248,7 @@ def gen(mode, par, safe):
             vstmt(f[1], f[2])
         elif kind == "add":
             _, kb, qb, r = f
-            st.asm("v_add_f32 %%0, %%0, v%d" % (s_blk(par, kb, qb) + r), '"+v"(LS[%d][%d])' % (qb, kb), "")
+            st.asm("v_add_f32 %%0, %%0, v%d" % (s_blk(par, kb, qb) + r), '"+v"(LS[%d][%d])' % (qb, r & 3), "")    # four partial sums: no dependent chain
         elif kind == "max":
             _, qb, kb, step = f
             s = s_blk(nxt, kb, qb)
@@ -243,6 +264,10 @@ def gen(mode, par, safe):
             kread(ks, kb, par * TILE)                        # K(t + 2) lives in ring slot t & 1
         elif kind == "dma":
             st.raw("ATTN4_DMA_%s(%d);" % (f[1], f[2]))
+        elif kind == "pre":
+            emit_prescale(st, f[1], f[2], f[3])
+        elif kind == "dec":
+            emit_dec_step(st, f[1])
         else:
             raise ValueError(kind)
 
@@ -255,24 +280,34 @@ def gen(mode, par, safe):
                 a_fill[a].append(("exp", kb, qb, r))
             if a >= 1:
                 a_fill[a].append(("cvt", a - 1))
+                kstep, qb, kb, r = elem(a - 1)               # row sums of elements 0..30: one per gap, behind their exponentials
+                a_fill[a].append(("add", kb, qb, r))
     if qk:
         for j in range(4):
             for kb in range(2):
                 a_fill[4 * j + 5 + kb].append(("kread", 4 + j, kb))
+    if head:                                                 # Q~ fragments of d-steps 2..7 are prepared under the first score MFMAs
+        for f in range(12):
+            for i in range(4):
+                a_fill[2 * f + (i >> 1)].append(("pre", f % 2, 2 + f // 2, i))
     if pv:
         for db, g in enumerate((20, 23, 26, 29)):
             a_fill[g].append(("vread", 0, db))
+    if not head:                                             # K(t + 2) -> the slot K(t) has left (its last reader passed barrier t - 1)
+        for i in range(4):
+            a_fill[1 + i].append(("dma", "K", i))
 
     counts = []
     for a in range(32):
         n0 = len(st.lines)
         if qk:
             ks, kb, qb = a >> 2, (a >> 1) & 1, a & 1
-            if qb == 0:
-                st.wait(kread_id[(ks, kb)])
+            if qb == 0 and kb == 0:                          # one wait per d-step: both key blocks' fragments
+                st.wait(kread_id.get((ks, 1), 0))
             d = vreg(s_blk(nxt, kb, qb), 16)
             src_c = d if ks else ("0" if head else vreg(nm_blk(qb), 16))
-            st.asm("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (d, areg(k_frag(ks, kb), 4), areg(q_frag(qb, ks), 4), src_c))
+            if "nomfma" not in ABL:
+                st.asm("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (d, areg(k_frag(ks, kb), 4), areg(q_frag(qb, ks), 4), src_c))
             st.mfma_pad()
         for f in a_fill[a]:
             do_filler(f)
@@ -281,10 +316,10 @@ def gen(mode, par, safe):
 
     # ------------------------------------------------------------------ phase B: 32 gaps
     b_fill = [[] for _ in range(32)]
-    if sm:                                                   # row sums: 64 adds over gaps 0..23 (two beside a V statement, four otherwise)
-        e = 0
+    if sm:                                                   # row sums: elements 31..63 here (0..30 went beside their exponentials in phase A)
+        e = 31
         for b in range(24):
-            for _ in range(2 if (pv and b % 2 == 0) else 4):
+            for _ in range(1 if (pv and b % 2 == 0) else 2):
                 if e < 64:
                     kstep, qb, kb, r = elem(e)
                     b_fill[b].append(("add", kb, qb, r))
@@ -296,15 +331,19 @@ def gen(mode, par, safe):
                 b_fill[8 * (k - 1) + 2 * db].append(("vread", k, db))
     if mx:
         ops = [("max", qb, kb, step) for step in range(8) for qb in range(2) for kb in range(2)]
-        gaps = sorted(list(range(2, 32)) + [3, 5])           # 32 operations over gaps 2..31
+        if head:
+            gaps = sorted(list(range(2, 32)) + [3, 5])       # 32 operations over gaps 2..31
+        else:                                                # ... over gaps 2..26; the cross-lane step and the decision mask under gaps 27..31
+            gaps = sorted(list(range(2, 27)) + [3, 7, 11, 15, 19, 23, 25])
+            for i in range(5):
+                b_fill[27 + i].append(("dec", i))
         for op, g in zip(ops, gaps):
             b_fill[g].append(op)
         for ks in range(4):
             for kb in range(2):
                 b_fill[24 + ks * 2 + kb].append(("kpre", ks, kb))
-    for i in range(4):
-        b_fill[24 + i].append(("dma", "K", i))
-        b_fill[28 + i].append(("dma", "V", i))
+    for i in range(4):                                       # V(t + 2) behind the barrier; K(t + 2) went out in phase A (gaps 1..4)
+        b_fill[24 + i].append(("dma", "V", i))
 
     if sm:                                                   # the last pair's packing
         do_filler(("cvt", 31))
@@ -313,14 +352,15 @@ def gen(mode, par, safe):
     counts = []
     for b in range(32):
         n0 = len(st.lines)
-        if b == 24:
+        if b == 24 and "nobar" not in ABL:
             st.raw("ATTN4_BARRIER();")
         if pv:
             kstep, db, qb = b >> 3, (b >> 1) & 3, b & 1
-            if qb == 0:
-                st.wait(vread_id[(kstep, db)])
+            if qb == 0 and db % 2 == 0:                      # one wait per pair of d-blocks
+                st.wait(vread_id.get((kstep, db + 1), 0))
             d = areg(o_blk(db, qb), 16)
-            st.asm("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (d, areg(v_frag(kstep, db), 4), vreg(p_frag(kstep, qb), 4), d))
+            if "nomfma" not in ABL:
+                st.asm("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (d, areg(v_frag(kstep, db), 4), vreg(p_frag(kstep, qb), 4), d))
             st.mfma_pad()
         if b == 1 and mx:
             emit_mask(st, nxt)
@@ -328,7 +368,7 @@ def gen(mode, par, safe):
             do_filler(f)
         counts.append(len(st.lines) - n0)
     st.stats.append(("B", counts))
-    if mx:
+    if mx and not ("nodecide" in ABL and not head):
         emit_decide(st, nxt, head)
     return st
 
@@ -348,19 +388,44 @@ def gen_epi_read(qb, db):
     return st
 
 
-def gen_q_write():
-    """Q~ fragment words w_[0..3] of (qb_, ks_) -> a[128 + 4*(qb_*8 + ks_) ..]: one switch-free block per fragment"""
-    out = {}
+QRAW_V = S_V + 64                                            # raw Q rows land in the registers of score tile 1 (first written in step 0)
+
+
+def q_raw(qb, ks):
+    return QRAW_V + 4 * (qb * 8 + ks)
+
+
+def emit_prescale(st, qb, ks, i):
+    """word i of fragment (qb, ks): two bf16 -> * scale*log2(e) -> bf16 pair -> accumulator register (t0_, t1_: compiler temporaries)"""
+    v, a = q_raw(qb, ks) + i, q_frag(qb, ks) + i
+    st.asm("v_lshlrev_b32 %%0, 16, v%d\\n\\tv_and_b32 %%1, 0xffff0000, v%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
+           "v_cvt_pk_bf16_f32 %%0, %%0, %%1\\n\\tv_accvgpr_write_b32 a%d, %%0" % (v, v, a), '"=&v"(t0_), "=&v"(t1_)', '"v"(sl2)')
+
+
+def gen_q_load():
+    """the wave's 64 query rows, 16 B per lane and fragment: two base pointers (qp0_, qp1_), immediates over d"""
+    st = Stream(False)
     for qb in range(2):
-        for ks in range(8):
-            st = Stream(False)
+        text = "\\n\\t".join("global_load_dwordx4 %s, %%0, off offset:%d" % (vreg(q_raw(qb, ks), 4), ks * 32) for ks in range(8))
+        st.asm(text, "", '"v"(qp%d_)' % qb, '"memory"')
+    return st
+
+
+def gen_q_pre01():
+    st = Stream(False)
+    for ks in range(2):
+        for qb in range(2):
             for i in range(4):
-                st.asm("v_accvgpr_write_b32 a%d, %%0" % (q_frag(qb, ks) + i), "", '"v"(w_[%d])' % i)
-            out[(qb, ks)] = st
-    return out
+                emit_prescale(st, qb, ks, i)
+    return st
 
 
 def main():
+    global OUT
+    if "--abl" in sys.argv:
+        names = sys.argv[sys.argv.index("--abl") + 1]
+        ABL.update(names.split(","))
+        OUT = OUT + "_" + names.replace(",", "_")
     os.makedirs(OUT, exist_ok=True)
     report = []
     for safe in (False, True):
@@ -380,9 +445,10 @@ def main():
         for qb in range(2):
             for db in range(4):
                 f.write("if (qb_ == %d && db_ == %d) {\n%s\n}\n" % (qb, db, "\n".join(gen_epi_read(qb, db).lines)))
-    with open(os.path.join(OUT, "q_write.inc"), "w") as f:
-        for (qb, ks), st in gen_q_write().items():
-            f.write("if (qb_ == %d && ks_ == %d) {\n%s\n}\n" % (qb, ks, "\n".join(st.lines)))
+    with open(os.path.join(OUT, "q_load.inc"), "w") as f:
+        f.write("\n".join(gen_q_load().lines) + "\n")
+    with open(os.path.join(OUT, "q_pre01.inc"), "w") as f:
+        f.write("\n".join(gen_q_pre01().lines) + "\n")
     print("\n".join(report))
 
 
