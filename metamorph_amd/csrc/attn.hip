@@ -58,17 +58,14 @@ bool bad_geom(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d) {
     return B <= 0 || L <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || d <= 0 || d > 128 || (d & 7) || L > 0x7fffffff;
 }
 
-// d == 128 goes to the LDS-DMA kernels of attn3.hip (MM355_ATTN_GEN2=1 forces the generic kernels: A/B and test knob)
-bool fast128(int64_t d, int64_t ld_k) {
-    static const bool gen2 = [] { const char* e = std::getenv("MM355_ATTN_GEN2"); return e && e[0] == '1'; }();
-    return d == 128 && !gen2 && ld_k * 2 * 64 < 0x7fffffff;
-}
+// d == 128 goes to the LDS-DMA kernels (the generic ones stay reachable through the *_variant entries, variant 2: A/B and tests)
+bool fast128(int64_t d, int64_t ld_k) { return d == 128 && ld_k * 2 * 64 < 0x7fffffff; }
 
 }  // namespace
 
 namespace {
-// variant: 0 = the product's choice, 3 = the two-waves-per-SIMD kernels of attn3.hip, 4 = the one-wave-per-SIMD stream of attn4.hip,
-// 41 = attn4's serialised debugging stream (bit-identical to 4 by construction; tests / tools only)
+// variant: 0 = the product's choice, 2 = the generic-d kernels of attn2.hip, 3 = the two-waves-per-SIMD kernels of attn3.hip,
+// 4 = the one-wave-per-SIMD stream of attn4.hip, 41 = attn4's serialised debugging stream (bit-identical to 4 by construction; tests / tools only)
 int attn_fwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
                   int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
                   int64_t d, float scale, int causal, int variant, void* stream) {
@@ -80,6 +77,7 @@ int attn_fwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
     const bool can4 = d == 128 && L * ld_k * 2 < 0x7fffffffll;          // 32-bit descriptor offsets inside one sample
     if (variant == 4 || variant == 41) return can4 ? mm355_attn4_fwd_launch(a, variant == 41, (hipStream_t)stream) : MM355_EUNSUPPORTED;
     if (variant == 3) return fast128(d, ld_k) ? mm355_attn3_fwd_launch(a, (hipStream_t)stream) : MM355_EUNSUPPORTED;
+    if (variant == 2) return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
     if (variant != 0) return MM355_EINVAL;
     if (can4 && fast128(d, ld_k)) return mm355_attn4_fwd_launch(a, 0, (hipStream_t)stream);
     if (fast128(d, ld_k)) return mm355_attn3_fwd_launch(a, (hipStream_t)stream);
@@ -109,7 +107,8 @@ extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, i
 }
 
 extern "C" int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, int64_t ld_max) {
-    if (Hq == Hkv || fast128(d, ld_max)) return 0;           // no GQA, or the d == 128 kernels (group summed in registers)
+    if (fast128(d, ld_max)) return 2 * B * Hq * L;           // d == 128: -lse * log2(e) and -delta, the C operands of the score chains
+    if (Hq == Hkv) return 0;                                 // no GQA
     return 2 * B * L * Hq * d;
 }
 
@@ -118,12 +117,24 @@ int attn_bwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
                   int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
                   mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                   float scale, int causal, float* workspace, const uint16_t* rope_cos, const uint16_t* rope_sin, const int32_t* rope_pos,
-                  void* stream) {
+                  int variant, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (ld_dq & 7)) return MM355_EINVAL;
-    const bool fast = fast128(d, std::max(std::max(ld_q, ld_k), ld_o));
+    const int64_t ld_max = std::max(std::max(ld_q, ld_k), ld_o);
+    const bool fast = fast128(d, ld_max) && variant != 2;    // (variant 2: the generic-d kernels; GQA then needs the 2*B*L*Hq*d workspace)
     if (rope_cos && !fast) return MM355_EUNSUPPORTED;        // the fused inverse rotation lives in the d == 128 kernels' epilogues
+    // variant: 0 = the product's choice, 2 = attn2.hip (generic d), 3 = attn3.hip (two waves per SIMD), 4 = attn4_bwd.hip (one wave per SIMD, hand-placed streams; needs
+    // the workspace), 41 = its serialised debugging streams
+    if (variant != 0 && variant != 2 && variant != 3 && variant != 4 && variant != 41) return MM355_EINVAL;
+    const bool can4 = fast && workspace && L * ld_max * 2 < 0x7fffffffll;
+    if ((variant == 4 || variant == 41) && !can4) return MM355_EUNSUPPORTED;
+    if (variant == 3 && !fast) return MM355_EUNSUPPORTED;
+    if (variant == 4 || variant == 41 || (variant == 0 && can4)) {
+        attn2::Args a4{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
+                       dk, dv, nullptr, nullptr, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal, rope_cos, rope_sin, rope_pos};
+        return mm355_attn4_bwd_launch(a4, workspace, variant == 41, (hipStream_t)stream);
+    }
     // GQA on the generic kernels: the group is summed from fp32 partials in the workspace (the d == 128 kernel sums in registers)
     if (Hq != Hkv && !fast && !workspace) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -154,7 +165,7 @@ extern "C" int mm355_attn_bwd(const mm355_bf16* q, const mm355_bf16* k, const mm
                               mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                               float scale, int causal, float* workspace, void* stream) {
     return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, workspace,
-                         nullptr, nullptr, nullptr, stream);
+                         nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
@@ -164,5 +175,15 @@ extern "C" int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, con
                                    void* stream) {
     if (!cos_t || !sin_t) return MM355_EINVAL;
     return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, nullptr,
-                         cos_t, sin_t, pos_offset, stream);
+                         cos_t, sin_t, pos_offset, 0, stream);
+}
+
+extern "C" int mm355_attn_bwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, const mm355_bf16* d_o,
+                                      int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
+                                      mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
+                                      float scale, int causal, const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset,
+                                      float* workspace, int variant, void* stream) {
+    if ((cos_t == nullptr) != (sin_t == nullptr)) return MM355_EINVAL;
+    return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, workspace,
+                         cos_t, sin_t, pos_offset, variant, stream);
 }

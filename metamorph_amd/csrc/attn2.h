@@ -113,3 +113,5 @@ int mm355_attn3_dq_launch(const attn2::Args& a, hipStream_t s);
 int mm355_attn3_dkdv_launch(const attn2::Args& a, hipStream_t s);
 // d == 128 forward, one wave per SIMD, hand-placed stream (attn4.hip); variant 1 = the serialised debugging stream
 int mm355_attn4_fwd_launch(const attn2::Args& a, int variant, hipStream_t s);
+// d == 128 backward (dK / dV then dQ), same construction (attn4_bwd.hip); workspace: 2 * B * Hq * L floats
+int mm355_attn4_bwd_launch(const attn2::Args& a, float* workspace, int variant, hipStream_t s);

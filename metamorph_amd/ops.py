@@ -391,12 +391,13 @@ def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=N
 
 def attn_bwd_rope_supported(d):
     """The d == 128 kernels can rotate dq / dk back through RoPE in their epilogues (mm355_attn_bwd_rope)."""
-    return d == 128 and os.environ.get("MM355_ATTN_GEN2", "0") != "1"
+    return d == 128
 
 
-def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlens, dq2d, dk2d, dv2d, rope=None):
+def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlens, dq2d, dk2d, dv2d, rope=None, variant=0):
     """Writes dq / dk / dv (bf16) into the given column-block views.  rope = (cos, sin, pos_offset | None): q / k are post-RoPE and dq /
-    dk are wanted as gradients of the PRE-RoPE projections -- the inverse rotation runs in the kernels' epilogues (d == 128 only)."""
+    dk are wanted as gradients of the PRE-RoPE projections -- the inverse rotation runs in the kernels' epilogues (d == 128 only).
+    variant != 0 (tests / tools only) picks the kernel generation: mm355_attn_bwd_variant in include/mm355.h."""
     _chk_dev(q2d, k2d, v2d, o, d_o, dq2d, dk2d, dv2d)
     pq, M, _, ldq = _rows2d(q2d)
     pk, _, _, ldk = _rows2d(k2d)
@@ -407,21 +408,19 @@ def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlen
     _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), B, L, Hq, d, _stream()),
                "mm355_attn_bwd_prep")
     n_ws = int(_L().mm355_attn_bwd_ws_floats(B, L, Hq, Hkv, d, max(ldq, ldk, d_o.stride(0))))
-    ws = torch.empty(n_ws, device=o.device, dtype=torch.float32) if n_ws else None     # generic-d GQA only; d = 128 sums in registers
+    ws = torch.empty(n_ws, device=o.device, dtype=torch.float32) if n_ws else None     # d = 128: per-row constants; generic-d GQA: partials
     pdq, _, _, lddq = _rows2d(dq2d)
     pdk, _, _, lddk = _rows2d(dk2d)
     pdv, _, _, lddv = _rows2d(dv2d)
     assert lddk == lddv
+    cos = sin = pos_offset = None
     if rope is not None:
         cos, sin, pos_offset = rope
         _chk_dev(cos, sin, pos_offset)
         assert cos.shape[1] == d and cos.shape[0] >= L and (pos_offset is None or (pos_offset.dtype == torch.int32 and pos_offset.numel() == B))
-        _lib.check(_L().mm355_attn_bwd_rope(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), lse.data_ptr(), delta.data_ptr(), _p(seqlens),
-                                            pdq, lddq, pdk, pdv, lddk, B, L, Hq, Hkv, d, scale, int(causal), cos.data_ptr(), sin.data_ptr(),
-                                            _p(pos_offset), _stream()), "mm355_attn_bwd_rope")
-        return
-    _lib.check(_L().mm355_attn_bwd(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), lse.data_ptr(), delta.data_ptr(), _p(seqlens),
-                                   pdq, lddq, pdk, pdv, lddk, B, L, Hq, Hkv, d, scale, int(causal), _p(ws), _stream()), "mm355_attn_bwd")
+    _lib.check(_L().mm355_attn_bwd_variant(pq, pk, pv, ldq, ldk, d_o.data_ptr(), d_o.stride(0), lse.data_ptr(), delta.data_ptr(), _p(seqlens),
+                                           pdq, lddq, pdk, pdv, lddk, B, L, Hq, Hkv, d, scale, int(causal), _p(cos), _p(sin), _p(pos_offset),
+                                           _p(ws), int(variant), _stream()), "mm355_attn_bwd_variant")
 
 
 def cast_f32_to_bf16_2d(src_f32, dst2d):

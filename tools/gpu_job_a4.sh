@@ -1,17 +1,11 @@
 mkdir -p gpurun_out/a4
-( timeout 200 python tools/bench_attn4.py --quick | grep -v "OK$" | tail -8
-for n in base; do
-  MM355_LIB_PATH=build/ablate_a4_$n/libmm355.so SUMMARY=1 TAG=$n CAUSAL=0 B=2 L=4096 timeout 60 python tools/attn4_timing.py 2>&1 | grep "^\["
-  MM355_LIB_PATH=build/ablate_a4_$n/libmm355.so SUMMARY=1 TAG=$n-causal timeout 60 python tools/attn4_timing.py 2>&1 | grep "^\["
-done
-python - <<'PY'
-import sys; sys.argv=['x']
-sys.path.insert(0,'tools'); sys.path.insert(0,'.')
-import bench_attn4 as b
-b.bench(16, 2048, 32, 8, variants=(3, 4))
-b.bench(16, 2048, 32, 8, variants=(3, 4))
-b.bench(8, 4096, 32, 8, variants=(3, 4))
-b.bench(16, 2048, 64, 8, causal=False, variants=(3, 4))
-PY
-) > gpurun_out/a4/run.log 2>&1
-cat gpurun_out/a4/run.log
+( timeout 120 python tools/bench_attn4_bwd.py --quick ) > gpurun_out/a4/bwd2.log 2>&1
+grep -c " OK$" gpurun_out/a4/bwd2.log; grep "MISMATCH\|False\|EXC\|ALL\|SOME" gpurun_out/a4/bwd2.log | cut -c1-200
+grep -q "ALL CASES OK" gpurun_out/a4/bwd2.log || exit 1
+MM355_LIB_PATH=build/ablate_a4_base/libmm355.so TAG=base timeout 60 python tools/attn4_bwd_timing.py 2>&1 | grep "^\["
+REPO=$PWD; cd /tmp; export TMPDIR=/tmp
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/a4/prof -o p -- python $REPO/tools/prof_attn4.py > $REPO/gpurun_out/a4/prof.log 2>&1
+cd $REPO
+S=$(find gpurun_out/a4/prof -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/a4/attn_kernel_stats.csv
+find gpurun_out/a4/prof -name "*kernel_trace.csv" -delete; find gpurun_out/a4/prof -name "*.db" -delete
+cut -d, -f1-4 gpurun_out/a4/attn_kernel_stats.csv | head -7
