@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--host-inputs", action="store_true", help="ids / labels / mask / fp32 pixels start every step in pinned HOST memory (PCIe-inclusive "
                     "rate for DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
     ap.add_argument("--zero2-async", type=int, default=None, choices=(0, 1), help="1: AdamW shard update + parameter all-gather per segment on a side "
-                    "stream, the next forward waits segment by segment (hides the all-gather at world > 1); default: MM355_ZERO2_ASYNC or 0")
+                    "stream, the next forward waits segment by segment (hides the all-gather at world > 1); default 0")
+    ap.add_argument("--zero2-overlap", type=int, default=1, choices=(0, 1), help="0: the gradient reduce-scatters all start at step() instead of from "
+                    "inside backward (driver-side A/B of the overlap; default 1)")
+    ap.add_argument("--pool", type=int, default=8, help="distinct seeded batches rotated through the steps (the loss is then a training loss, not a memorised batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -198,6 +201,47 @@ class GemmTimer:
         return len(self.records), t, fl
 
 
+class HbmTimer:
+    """HIP-event timing of the step's HBM-bound kernels (RMSNorm, transposes, AdamW): algorithmic bytes over launch duration."""
+
+    def __init__(self):
+        from metamorph_amd import ops
+        self.ops = ops
+        self.records = {}
+        self.enabled = False
+
+    def _wrap(self, name, nbytes):
+        orig = getattr(self.ops, name)
+
+        def timed(*a, **kw):
+            if not self.enabled:
+                return orig(*a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **kw)
+            e.record()
+            self.records.setdefault(name, []).append((s, e, float(nbytes(*a, **kw))))
+            return r
+        setattr(self.ops, name, timed)                        # functional.py / zero2.py reach the kernels through this module object
+
+    def install(self):
+        nb = lambda t: t.numel() * t.element_size()
+        self._wrap("rmsnorm_fwd", lambda x, w, eps, out=None, want_rstd=False: 2 * nb(x) + nb(w))                    # 2 M h 2 B (+ h 2 B)
+        self._wrap("rmsnorm_apply_t", lambda x, w, rstd, Rp=None: 2 * nb(x) + nb(w) + nb(rstd))
+        self._wrap("transpose", lambda x, out=None, ld_out=None: 2 * nb(x))                                         # 2 R C 2 B
+        self._wrap("adamw_shard_", lambda p32, m, v, g, p_out, *a, **kw: 2 * (nb(p32) + nb(m) + nb(v)) + nb(g) + nb(p_out))   # 28 B / parameter
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            t = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+            by = sum(r[2] for r in recs)
+            out[name.rstrip("_")] = {"launches_per_step": round(len(recs) / steps, 1), "ms_per_step": round(t / steps * 1e3, 2),
+                                     "achieved_tb_s": round(by / t / 1e12, 2), "frac_of_8_tb_s": round(by / t / 8e12, 3)}
+        return out
+
+
 def _cpu_threads():
     try:
         avail = len(os.sched_getaffinity(0))
@@ -209,16 +253,17 @@ def _cpu_threads():
 def cpu_baseline(args):
     """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: ONE sample built like the bench's
     (one 256-token image + text, labels as in make_batch) at the workload's own length (2048 spliced tokens), LLaMA-3-8B / SO400M layer
-    geometry with TWO of 32 decoder layers and TWO of 27 tower layers actually run plus the full 128258-entry lm_head and both loss
+    geometry with FOUR of 32 decoder layers and TWO of 27 tower layers actually run plus the full 128258-entry lm_head and both loss
     heads, fp32, forward+backward with the stage-2 freeze policy.  Every stage is timed on its own -- each decoder layer's forward
-    separately (so the per-layer cost is measured twice, not assumed), the heads' forward, the heads' backward and the decoder's
+    separately (so the per-layer cost is a mean of four measurements, not a difference of two), the heads' forward, the heads' backward and the decoder's
     backward as two separate autograd passes -- and the per-layer figures are scaled to the full depth to quote tokens/s."""
     from oracle.ref_model import OracleConfig, init_state_dict
     from oracle import ref_model as RM, ref_ops as R
     threads = _cpu_threads()
     torch.set_num_threads(threads)
-    NL = 2                                           # decoder / tower layers actually run (scaled to 32 / 27 below)
-    cfg = OracleConfig(num_hidden_layers=NL, v_layers=NL, num_image_tokens=args.image_tokens, tokenizer_model_max_length=4096)
+    NL = 4                                           # decoder layers actually run (per-layer cost = mean of four separately timed layers)
+    NV = 2                                           # tower layers actually run (frozen: forward only, scaled to 27)
+    cfg = OracleConfig(num_hidden_layers=NL, v_layers=NV, num_image_tokens=args.image_tokens, tokenizer_model_max_length=4096)
     sd = init_state_dict(cfg, seed=1, fast_big=True)
     for k, v in sd.items():
         if "vision_tower" not in k and "vision_proj" not in k:
@@ -258,22 +303,22 @@ def cpu_baseline(args):
     n_ce = int((lab[:, 1:] != -100).sum())
     per_layer = (sum(t_layers) + t_dec_b) / NL
     t_head = t_head_f + t_head_b + t_splice + t_emb_b
-    full = per_layer * 32 + t_head + t_vit * (27 / NL)
+    full = per_layer * 32 + t_head + t_vit * (27 / NV)
     return {"value": round(L / full, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": (f"oracle/ref_model.py fp32 fwd+bwd, 1 sample of {L} spliced tokens ({args.image_tokens} image + {L - args.image_tokens} text; "
                        f"{n_ce} CE rows, {args.image_tokens} regression rows), LLaMA-3-8B + SO400M layer geometry with {NL}/32 decoder and "
-                       f"{NL}/27 tower layers + full lm_head; measured per stage: decoder layer forward " + " / ".join(f"{t:.2f}s" for t in t_layers)
-                       + f", decoder backward ({NL} layers) {t_dec_b:.2f}s, heads fwd {t_head_f:.2f}s bwd {t_head_b:.2f}s, embedding + projector bwd {t_emb_b:.2f}s, tower ({NL} layers) {t_vit:.2f}s; "
-                       f"per-layer cost {per_layer:.2f}s x 32 + heads + tower x 27/{NL} = {full:.1f}s per {L} tokens"),
+                       f"{NV}/27 tower layers + full lm_head; measured per stage: decoder layer forward " + " / ".join(f"{t:.2f}s" for t in t_layers)
+                       + f", decoder backward ({NL} layers) {t_dec_b:.2f}s, heads fwd {t_head_f:.2f}s bwd {t_head_b:.2f}s, embedding + projector bwd {t_emb_b:.2f}s, tower ({NV} layers) {t_vit:.2f}s; "
+                       f"per-layer cost {per_layer:.2f}s (mean of {NL} separately timed layers) x 32 + heads + tower x 27/{NV} = {full:.1f}s per {L} tokens"),
             "measured_seconds": round(sum(t_layers) + t_dec_b + t_head + t_vit, 2),
             "decoder_layer_forward_seconds": [round(t, 3) for t in t_layers]}
 
 
-def cpu_baseline_c1(budget_s=40.0):
+def cpu_baseline_c1(budget_s=60.0):
     """BASELINE configs[0] / BASELINE.md section 3 as planned: TinyLlama-1.1B geometry (22 layers, h 2048, 32/4 heads, I 5632, V 32002)
     + SigLIP-SO400M/14-384 (27 layers), 1 prompt image -> 256 tokens + 128 text ids (spliced L = 383), B = 1, stage-1 freeze policy
     (only mm_projector + embed_tokens train, reference train.py:1515-1519), the FULL model, directly timed forward+backward on the host
-    cores: fp32 (1 warm-up + 1 timed step) and bf16 (1 step, skipped when a probe GEMM shows the host has no fast bf16 path)."""
+    cores: fp32 and bf16, each 1 warm-up + 3 timed steps (bf16 skipped when a probe GEMM shows the host has no fast bf16 path)."""
     from oracle.ref_model import OracleConfig, forward, init_state_dict
     threads = _cpu_threads()
     torch.set_num_threads(threads)
@@ -293,7 +338,7 @@ def cpu_baseline_c1(budget_s=40.0):
            "cores": threads, "unit": "tokens/s", "kind": "port"}
     t_all = time.time()
     sd32 = init_state_dict(cfg, seed=2, fast_big=True)
-    for dt, tag, warm, n in ((torch.float32, "fp32", 1, 1), (torch.bfloat16, "bf16", 0, 1)):
+    for dt, tag, warm, n in ((torch.float32, "fp32", 1, 3), (torch.bfloat16, "bf16", 1, 3)):
         if tag == "bf16":                                  # probe: one bf16 GEMM of the MLP shape; hosts without fast bf16 GEMMs skip
             a, b = torch.randn(383, 2048).to(dt), torch.randn(5632, 2048).to(dt)
             torch.nn.functional.linear(a, b)
@@ -318,8 +363,56 @@ def cpu_baseline_c1(budget_s=40.0):
             if i >= warm:
                 ts.append(time.time() - t0)
         step = sum(ts) / len(ts)
-        out[tag] = {"step_seconds": round(step, 3), "value": round(383 / step, 2), "steps_timed": n, "loss": round(float(r["loss"].detach()), 4)}
+        out[tag] = {"step_seconds": round(step, 3), "value": round(383 / step, 2), "steps_timed": n, "warmup_steps": warm,
+                    "step_seconds_each": [round(t, 3) for t in ts], "loss": round(float(r["loss"].detach()), 4)}
     return out
+
+
+def rccl_summary(path, opt, steps, world):
+    """What RCCL says it did (NCCL_DEBUG=INFO, rank 0's log): version, channels, per-collective algorithm / protocol lines, plus the
+    achieved bus bandwidth of the gradient reduce-scatters and parameter all-gathers from the optimizer's own HIP-event timing."""
+    import re
+    out = {"log": path}
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return out
+    m = re.search(r"(?:NCCL|RCCL) version ([^\n]+)", text)
+    if m:
+        out["version"] = m.group(1).strip()
+    ch = re.findall(r"(\d+) coll channels", text)
+    if ch:
+        out["coll_channels"] = int(ch[-1])
+    algo = {}
+    for line in text.splitlines():                           # TUNING / COLL lines: "ReduceScatter: ... Algo RING proto SIMPLE ... nchannels N"
+        m = re.search(r"(AllReduce|ReduceScatter|AllGather)[^\n]*?[Aa]lgo(?:rithm)? (\w+)[^\n]*?proto(?:col)? (\w+)(?:[^\n]*?(?:channels|nchannels|nChannels)[ =:{]*(\d+))?", line)
+        if m:
+            key = f"{m.group(1)}: algo {m.group(2)} proto {m.group(3)}" + (f" channels {m.group(4)}" if m.group(4) else "")
+            algo[key] = algo.get(key, 0) + 1
+    if algo:
+        out["collectives_seen"] = dict(sorted(algo.items(), key=lambda kv: -kv[1])[:8])
+    xgmi = len(re.findall(r"via P2P|XGMI|via SHM|via NET", text))
+    if xgmi:
+        out["transport_lines"] = {"p2p_or_xgmi": len(re.findall(r"via P2P|XGMI", text)), "shm": len(re.findall(r"via SHM", text)), "net": len(re.findall(r"via NET", text))}
+    if hasattr(opt, "comm_bytes_per_step"):
+        out["bytes_per_step"] = opt.comm_bytes_per_step()
+    return out
+
+
+def bus_bandwidth(rec_rccl, comm, world, overlap):
+    """Bus bandwidth (bytes * (world - 1) / world / time) of the collectives whose WHOLE duration sits in an exposed wait: the parameter
+    all-gather with the synchronous update, and the gradient reduce-scatter when the overlap is off (with the overlap on only its
+    un-hidden remainder is timed, so no rate can be quoted)."""
+    by = rec_rccl.get("bytes_per_step") if rec_rccl else None
+    if not by or not comm or world < 2:
+        return None
+    f = (world - 1) / world
+    out = {}
+    if comm.get("all_gather"):
+        out["all_gather_gb_s"] = round(by["all_gather_bytes"] * f / (comm["all_gather"] * 1e-3) / 1e9, 1)
+    if not overlap and comm.get("reduce_scatter_exposed"):
+        out["reduce_scatter_gb_s"] = round(by["reduce_scatter_bytes"] * f / (comm["reduce_scatter_exposed"] * 1e-3) / 1e9, 1)
+    return out or None
 
 
 def self_launch(n):
@@ -351,10 +444,20 @@ def main():
         return self_launch(args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # MM355_BENCH_FORCE_DIST=1 (+ MM355_ZERO2_FORCE_COLLECTIVES=1): drive the RCCL call pattern with a single rank under torchrun
+    # MM355_BENCH_FORCE_DIST=1: drive the RCCL call pattern with a single rank under torchrun (collectives forced at world size 1)
     force_dist = os.environ.get("MM355_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if force_dist:
+        from metamorph_amd.zero2 import set_collective_mode
+        set_collective_mode(force_collectives=True)
+    rccl_log = None
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's own account of what it chose (algorithm / protocol / channels per collective): NCCL_DEBUG=INFO into a per-rank file,
+        # rank 0's is summarised into the JSON line (the driver's 8-GPU run cannot be observed otherwise)
+        rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mm355_bench_rccl_{os.getpid()}_{rank}.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         # stdout carries exactly ONE line (the JSON record): RCCL prints its NCCL_DEBUG=VERSION banner with printf when the
         # communicator is created, so fd 1 points at stderr while that happens
         sys.stdout.flush()
@@ -394,25 +497,33 @@ def main():
         opt = Zero3AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_hooks()
     else:
         opt = Zero2AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                         async_update=None if args.zero2_async is None else bool(args.zero2_async)).enable_overlap()
+                         async_update=bool(args.zero2_async))
+        if args.zero2_overlap:
+            opt.enable_overlap()
     t_build = time.time() - t_build
 
-    ids, labels, mask, images = make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank,
-                                           frames=args.frames, all_generation=args.all_generation)
-    host = (ids, labels, mask, images) if args.host_inputs else None
-    host_bytes = sum(t.numel() * t.element_size() for t in host) if host else 0
+    # a pool of distinct seeded batches, all resident before the timed region, rotated through the steps
+    n_pool = max(1, args.pool)
+    pool = [make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank + 1000 * j,
+                       frames=args.frames, all_generation=args.all_generation) for j in range(n_pool)]
+    host_bytes = sum(t.numel() * t.element_size() for t in pool[0]) if args.host_inputs else 0
     timer = GemmTimer()
+    hbm_timer = HbmTimer()
     if not args.no_kernel_timing:
         timer.install()
+        hbm_timer.install()
+    step_no = [0]
 
     def step():
-        nonlocal ids, labels, mask, images
-        if host is not None:                                 # host -> HBM inside the step (HF Trainer._prepare_inputs), pixels cast on the device
-            ids, labels, mask = (t.to(dev, non_blocking=True) for t in host[:3])
-            images = host[3].to(dev, non_blocking=True).to(torch.bfloat16)
+        ids, labels, mask, images = pool[step_no[0] % n_pool]
+        step_no[0] += 1
+        if args.host_inputs:                                 # host -> HBM inside the step (HF Trainer._prepare_inputs), pixels cast on the device
+            ids, labels, mask = (t.to(dev, non_blocking=True) for t in (ids, labels, mask))
+            images = images.to(dev, non_blocking=True).to(torch.bfloat16)
         opt.zero_grad()
         out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images)
-        opt.arm_overlap()                                        # no accumulation: these gradients are final
+        if args.zero2_overlap:
+            opt.arm_overlap()                                    # no accumulation: these gradients are final
         out.loss.backward()
         opt.step()
         return out.loss
@@ -425,7 +536,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = hbm_timer.enabled = True
     dist_run = world > 1 or force_dist
     if dist_run and hasattr(opt, "comm_timing"):
         opt.comm_timing = True                                   # HIP events around the parts of step() that wait for RCCL
@@ -438,7 +549,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = hbm_timer.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -464,9 +575,9 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         params_equal = bool(torch.equal(lo, hi))
         # same-job A/B of the asynchronous update / all-gather (hidden behind the next forward pass) against the synchronous one:
-        # 3 steps each AFTER the headline measurement
-        # (opt-in, MM355_BENCH_AB_ASYNC=1: the default run does nothing after its timed region that could disturb the record)
-        if args.zero == 2 and os.environ.get("MM355_BENCH_AB_ASYNC", "0") == "1":
+        # 3 steps each AFTER the headline measurement (the timed region and the record above are closed; default at world > 1, where it
+        # is the only way to see the overlap on a node this build never runs on; MM355_BENCH_AB_ASYNC=1 forces it on one rank)
+        if args.zero == 2 and (world > 1 or os.environ.get("MM355_BENCH_AB_ASYNC", "0") == "1"):
             ab_async = {}
             for tag, on in (("sync_ms_per_step", False), ("async_ms_per_step", True)):
                 opt.set_async_update(on)
@@ -490,34 +601,44 @@ def main():
     n_gemm, t_gemm, fl_gemm, bytes_gemm = timer.summary(plain_only=True) if not args.no_kernel_timing else (0, 0.0, 0.0, 0.0)
     n_fused, t_fused, fl_fused = timer.fused_summary() if not args.no_kernel_timing else (0, 0.0, 0.0)
     roofline = None
-    if n_gemm:
-        ach = fl_gemm / t_gemm / 1e12
-        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
-        # the gfx950 x2 read correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed
-        # under profiles/; they only apply to the configuration they were taken on.
+    if n_all:
+        # The dominant kernel = the bf16 MFMA GEMM family: EVERY GEMM-bearing launch of the timed steps (plain ping-pong launches, their
+        # two-problem and RoPE-epilogue forms, the small-tile kernel, and the two fused MLP launches, whose GEMM flops are taken over their
+        # whole duration, fused element-wise epilogue included).  `plain` / `fused_mlp` split the same launches.
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with the gfx950 x2 read
+        # correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed under profiles/; they only
+        # apply to the configuration they were taken on.  Mean over all GEMM launches, weighted by launch count.
         traffic, traffic_src = None, None
-        tname = {12: "r1_step_b12_hbm_traffic_e.json", 16: "r3_step_b16_hbm_traffic_c.json"}.get(args.batch, "none")
-        tpath = os.path.join(REPO, "profiles", tname)
-        if args.layers == 32 and args.seq == 2048 and args.frames == 1 and os.path.exists(tpath):
-            for k in json.load(open(tpath))["kernels"]:
-                if k["kernel"].startswith("gemm_pp_kernel<false, false"):
-                    traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + tname
-        alg_bytes = bytes_gemm / n_gemm
-        roofline = {"bound": "mfma", "kernel": "gemm_pp_kernel (+ its two-problem form gemm_pp_pair_kernel, gemm_pp_rope_kernel = the same body with the RoPE rotation in the q|k|v epilogue, and the small-tile gemm_nt_kernel): the plain bf16 MFMA GEMM launches "
-                                               "of the timed steps -- the dominant kernel; the two fused MLP launches are listed under roofline_fused_mlp",
+        for tname in ("r4_step_b16_hbm_traffic.json", "r3_step_b16_hbm_traffic_c.json") if args.batch == 16 else ():
+            tpath = os.path.join(REPO, "profiles", tname)
+            if args.layers == 32 and args.seq == 2048 and args.frames == 1 and os.path.exists(tpath):
+                ks = [k for k in json.load(open(tpath))["kernels"] if k["kernel"].startswith("gemm_")]
+                if ks:
+                    traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / sum(k["launches"] for k in ks))
+                    traffic_src = "profiles/" + tname
+                    break
+        ach = fl_all / t_all_g / 1e12
+        bytes_all = sum(r[4] for r in timer.records)
+        roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family, ALL launches of the timed steps: gemm_pp_kernel, gemm_pp_pair_kernel (two problems, one grid), "
+                                               "gemm_pp_rope_kernel (RoPE in the q|k|v epilogue), gemm_nt_kernel (small tiles), gemm_pp_swiglu_kernel and "
+                                               "gemm_pp_swiglu_bwd_kernel (SwiGLU forward / backward in the MLP GEMMs' epilogues; GEMM flops over the whole launch)",
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over launches",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                    "launches": n_gemm, "gemm_seconds_per_step": round(t_gemm / args.steps, 4),
-                    "algorithmic_flops_per_step": fl_gemm / args.steps}
+                    "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over all GEMM launches",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_all / n_all),
+                    "launches": n_all, "gemm_seconds_per_step": round(t_all_g / args.steps, 4),
+                    "algorithmic_flops_per_step": fl_all / args.steps}
+        if n_gemm:
+            roofline["plain"] = {"kernel": "gemm_pp_kernel + gemm_pp_pair_kernel + gemm_pp_rope_kernel + gemm_nt_kernel", "launches": n_gemm,
+                                 "achieved": round(fl_gemm / t_gemm / 1e12, 1), "frac": round(fl_gemm / t_gemm / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                 "seconds_per_step": round(t_gemm / args.steps, 4), "algorithmic_flops_per_step": fl_gemm / args.steps,
+                                 "algorithmic_bytes_per_launch": round(bytes_gemm / n_gemm)}
         if n_fused:
-            # gate|up GEMM + SwiGLU and down_proj input-gradient GEMM + SwiGLU backward: GEMM flops over the WHOLE launch, whose epilogue also
-            # carries the element-wise pass it absorbed (HBM-bound there), so this is a floor for the MFMA part, not a like-for-like figure
-            roofline["roofline_fused_mlp"] = {"kernel": "gemm_pp_swiglu_kernel + gemm_pp_swiglu_bwd_kernel", "launches": n_fused,
-                                              "achieved": round(fl_fused / t_fused / 1e12, 1), "frac": round(fl_fused / t_fused / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                              "seconds_per_step": round(t_fused / args.steps, 4), "algorithmic_flops_per_step": fl_fused / args.steps}
-            roofline["all_gemm_launches"] = {"achieved": round(fl_all / t_all_g / 1e12, 1), "frac": round(fl_all / t_all_g / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                             "seconds_per_step": round(t_all_g / args.steps, 4), "algorithmic_flops_per_step": fl_all / args.steps}
+            # gate|up GEMM + SwiGLU and down_proj input-gradient GEMM + SwiGLU backward: the epilogue also carries the element-wise pass it
+            # absorbed (HBM-bound there), so this is a floor for the MFMA part, not a like-for-like figure
+            roofline["fused_mlp"] = {"kernel": "gemm_pp_swiglu_kernel + gemm_pp_swiglu_bwd_kernel", "launches": n_fused,
+                                     "achieved": round(fl_fused / t_fused / 1e12, 1), "frac": round(fl_fused / t_fused / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                     "seconds_per_step": round(t_fused / args.steps, 4), "algorithmic_flops_per_step": fl_fused / args.steps}
+        roofline["hbm_bound"] = hbm_timer.summary(args.steps)   # RMSNorm / transposes / AdamW: algorithmic bytes over launch time vs 8 TB/s
     # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
     h, V, L = 4096, 128258, args.seq
     per_tok = 3.0 * (args.layers * (436.2076e6 + 2.0 * L * h) + 2.0 * h * V)
@@ -530,7 +651,7 @@ def main():
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/pixels)" + (
-                f"; INPUTS FROM PINNED HOST MEMORY every step ({host_bytes} B/step over PCIe: not the headline configuration)" if host else ""),
+                f"; INPUTS FROM PINNED HOST MEMORY every step ({host_bytes} B/step over PCIe: not the headline configuration)" if args.host_inputs else ""),
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
@@ -538,7 +659,7 @@ def main():
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else "") + (
                            " +async-update" if getattr(opt, "async_update", False) else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
-            "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
+            "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "batch_pool": n_pool, "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }
@@ -548,6 +669,9 @@ def main():
         if dist_run:
             rec["params_equal_across_ranks"] = params_equal
             rec["comm_ms_per_step"] = comm                       # exposed (not overlapped) time per phase, rank 0's stream
+            rec["zero2_overlap"] = bool(args.zero2_overlap)
+            rec["rccl"] = rccl_summary(rccl_log, opt, args.steps, world)
+            rec["rccl"]["bus_bandwidth"] = bus_bandwidth(rec["rccl"], comm, world, bool(args.zero2_overlap) and getattr(opt, "overlap", True))
             if ab_async:
                 rec["zero2_async_ab"] = ab_async
         if world == 1 and not args.no_cpu_baseline:
@@ -556,6 +680,9 @@ def main():
         print(json.dumps(rec), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if dist_run and params_equal is False:                       # ranks diverged: the number above is not a training run
+        print("bench.py: parameters differ across ranks after the timed steps (params_equal_across_ranks = false)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

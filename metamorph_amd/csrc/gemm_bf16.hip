@@ -82,14 +82,12 @@ MM_DEV void gemm_epilogue(f32x4 (&acc)[FM][FN], const GemmArgs& a, unsigned char
         // the staging slab is private to this wave and the LDS executes one wave's instructions in order: a wave-level
         // fence (no s_barrier) is all the write -> read -> next write hand-over needs; the caller has already made sure
         // (block barrier) that nobody still reads the tile data this slab overlays
-        if (fl & 0x80000000u) __syncthreads();             // A/B knob MM355_GEMM_EPI_BARRIER=1: the old block barriers
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * TN + j * 16 + fr] = acc[i][j][r];
-        if (fl & 0x80000000u) __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int grow = m0 + wm * TM + i * 16 + row_l;
@@ -1241,10 +1239,7 @@ constexpr int PP_LDS = 2 * (256 + 256) * 128;               // 128 KiB
 int64_t pp_prepare(GemmArgs& a) {
     a.ntm = (a.M + 255) / 256;
     a.ntn = (a.N + 255) / 256;
-    static const int gm_env = [] { const char* e = std::getenv("MM355_GEMM_GM"); return e ? atoi(e) : 0; }();   // tuning knob
-    static const bool epi_bar = [] { const char* e = std::getenv("MM355_GEMM_EPI_BARRIER"); return e && e[0] == '1'; }();
-    if (epi_bar) a.flags |= 0x80000000u;
-    a.gm = gm_env > 0 ? gm_env : 4;                         // 4 x ntn raster groups: sweep on LLaMA-3-8B shapes (2/4/8/16/32)
+    a.gm = 4;                                               // 4 x ntn raster groups: sweep on LLaMA-3-8B shapes (2/4/8/16/32; profiles/r1_*)
     return (int64_t)a.ntm * a.ntn;
 }
 
@@ -1442,9 +1437,11 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 10: return launch_gemm_ring(a, s);
         case 11: return launch_gemm_pp(a, s);
         case 12: return launch_gemm_pp2(a, s);
-        case 91: return launch_gemm_pp_t<false, false, 1>(a, s);     // TIMING-ONLY ablations (wrong results): no DMA / no fragment reads
-        case 92: return launch_gemm_pp_t<false, false, 2>(a, s);
+#ifdef MM355_ABLATIONS                                       // TIMING-ONLY builds (tools/build_ablation.sh ... -DMM355_ABLATIONS): wrong results on purpose
+        case 91: return launch_gemm_pp_t<false, false, 1>(a, s);     // no DMA
+        case 92: return launch_gemm_pp_t<false, false, 2>(a, s);     // no fragment reads
         case 93: return launch_gemm_pp_t<false, false, 3>(a, s);     // every DMA issued, but always K tiles 0 / 1 (L2-resident sources)
+#endif
         default: return MM355_EUNSUPPORTED;
     }
 }

@@ -17,23 +17,27 @@ from torch.autograd import Function
 from . import ops
 
 BF16 = torch.bfloat16
-# MM355_DW_TN=1: weight / input gradients on the operands as they lie in memory (contraction-major ping-pong GEMM, no
-# transposed copies).  Measured on LLaMA-3-8B shapes: TN 1.04-1.10 PFLOP/s, NN 1.25-1.30 vs 1.45-1.5 for the row-major
-# kernel -- explicit transposes + NT are still faster end to end (1.22-1.25 PFLOP/s including the copies), so it is opt-in.
-_DW_TN = os.environ.get("MM355_DW_TN", "0") == "1"
-# MM355_DW_PAIR=0: launch every weight-gradient GEMM on its own.  Default: the down_proj and qkv weight gradients of a decoder
-# layer go out as ONE launch when that saves a wave of workgroups (LLaMA-3-8B: 896 + 384 tiles = 5 waves of 256 CUs instead
-# of 4 + 2).
-_DW_PAIR = os.environ.get("MM355_DW_PAIR", "1") != "0"
-# MM355_NORM_T=0: recompute the RMSNorm outputs in the backward pass and transpose them (two passes each) instead of rebuilding them
-# contraction-major from the saved rstd in one (rmsnorm_apply_t); A/B switch.
-_NORM_T = os.environ.get("MM355_NORM_T", "1") != "0"
-# MM355_FUSE_SWIGLU=0: gate|up GEMM and SwiGLU as two launches (A/B switch; the fused launch writes the same bits)
-_FUSE_SWIGLU = os.environ.get("MM355_FUSE_SWIGLU", "1") != "0"
-# MM355_FUSE_ROPE=0: q|k|v GEMM and RoPE as two launches (A/B switch; same bits)
-_FUSE_ROPE = os.environ.get("MM355_FUSE_ROPE", "1") != "0"
-# MM355_FUSE_SWIGLU_BWD=0: down_proj input-gradient GEMM and SwiGLU backward as two launches (A/B switch; same bits)
-_FUSE_SWIGLU_BWD = os.environ.get("MM355_FUSE_SWIGLU_BWD", "1") != "0"
+# Kernel-composition switches of the decoder layer.  The product runs the defaults (each one measured the winner on MI355X, DESIGN.md
+# section 4); tools/ and tests flip them through set_variant() for same-box A/B runs -- there is no environment switch.
+#   dw_tn           weight / input gradients on the operands as they lie in memory (contraction-major ping-pong GEMM, no transposed copies):
+#                   TN 1.04-1.10 PFLOP/s, NN 1.25-1.30 vs 1.45-1.5 for the row-major kernel + explicit transposes -> off
+#   dw_pair         down_proj and qkv weight gradients as ONE launch when that saves a wave of workgroups (896 + 384 tiles = 5 waves, not 4 + 2)
+#   norm_t          backward rebuilds the RMSNorm outputs contraction-major from the saved rstd in one pass (rmsnorm_apply_t)
+#   fuse_swiglu     SwiGLU in the gate|up GEMM's epilogue (same bits, one pass less)
+#   fuse_rope       RoPE in the q|k|v GEMM's epilogue / inverse RoPE in the attention backward epilogues (same bits)
+#   fuse_swiglu_bwd SwiGLU backward in the down_proj input-gradient GEMM's epilogue (same bits)
+#   decode_graph    the per-token decode step is captured once as a hipGraph and replayed
+VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True, "fuse_rope": True, "fuse_swiglu_bwd": True, "decode_graph": True}
+
+
+def set_variant(name, value):
+    """Flip one composition switch (tools / tests); returns the previous value."""
+    if name not in VARIANTS:
+        raise KeyError(f"unknown variant {name!r}: {sorted(VARIANTS)}")
+    old, VARIANTS[name] = VARIANTS[name], bool(value)
+    return old
+
+
 _CUS = 256                                                   # MI355X: one 256x256 tile per CU at a time
 
 
@@ -210,8 +214,8 @@ def _dw_operands(dy2d, x2d, dyT=None, xT=None):
 def weight_grad_gemm(dy2d, x2d, out, accumulate, dyT=None, xT=None):
     """out[N,K] (+)= dy[M,N]^T @ x[M,K].  Token counts that are whole pairs of 64-row tiles go straight through the
     contraction-major ping-pong kernel (operands as they lie in memory, fragments gathered by ds_read_b64_tr_b16); ragged
-    or small problems fall back to explicit transposes.  Opt-in (MM355_DW_TN=1): see the note at the top."""
-    if dyT is None and xT is None and _DW_TN:
+    or small problems fall back to explicit transposes.  Opt-in (MM355VARIANTS["dw_tn"]=1): see the note at the top."""
+    if dyT is None and xT is None and VARIANTS["dw_tn"]:
         big = ((dy2d.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) >= 128
         if big and ops.gemm_tn_supported(dy2d, x2d) and ops.gemm_pp_operands_ok(dy2d.shape[0], dy2d, x2d):
             ops.gemm_tn(dy2d, x2d, out, accumulate=accumulate)
@@ -234,7 +238,7 @@ def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
 
 def input_grad_gemm(dy2d, w, out=None, residual=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual); the weight is read untransposed whenever the ping-pong kernel applies"""
-    if _DW_TN and ops.gemm_nn_supported(dy2d, w):
+    if VARIANTS["dw_tn"] and ops.gemm_nn_supported(dy2d, w):
         return ops.gemm_nn(dy2d, w, out=out, residual=residual)
     return ops.gemm(dy2d, transpose_padded(w), out=out, residual=residual)
 
@@ -263,7 +267,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
     wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
     n1, rstd1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps, want_rstd=True)
-    if _FUSE_ROPE and ops.gemm_rope_supported(n1, wqkv, m.Hq, m.Hkv, m.d, m.cos):
+    if VARIANTS["fuse_rope"] and ops.gemm_rope_supported(n1, wqkv, m.Hq, m.Hkv, m.d, m.cos):
         qkv = ops.gemm_rope(n1, wqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)     # rotation in the GEMM epilogue: same bits
         del n1
     else:
@@ -274,7 +278,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
     n2, rstd2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps, want_rstd=True)
-    if _FUSE_SWIGLU and ops.gemm_swiglu_supported(n2, wgu, m.I):
+    if VARIANTS["fuse_swiglu"] and ops.gemm_swiglu_supported(n2, wgu, m.I):
         gu, act = ops.gemm_swiglu(n2, wgu, m.I)                # SiLU(gate) * up formed in the GEMM epilogue: same bits, one pass less
         del n2
     else:
@@ -326,10 +330,10 @@ class DecoderLayerFn(Function):
         # ---- MLP ----
         gu_params = [mlp.gate_proj.weight, mlp.up_proj.weight]
         # full fine-tune on whole 64-row tiles: SwiGLU backward writes act^T and dgu^T itself (no transpose passes over them)
-        fused_t = (not _DW_TN and dy.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
+        fused_t = (not VARIANTS["dw_tn"] and dy.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
                    and all(p.requires_grad for p in gu_params))
         wdT = None
-        if fused_t and _FUSE_SWIGLU_BWD:
+        if fused_t and VARIANTS["fuse_swiglu_bwd"]:
             wdT = transpose_padded(mlp.down_proj.weight)
             if not ops.gemm_swiglu_bwd_supported(dy, wdT, gu, m.I):
                 wdT = None
@@ -352,7 +356,7 @@ class DecoderLayerFn(Function):
         if mlp.down_proj.weight.requires_grad:
             wd = mlp.down_proj.weight
             buf, acc = grad_target(wd)
-            if (_DW_PAIR and not _DW_TN and all(p.requires_grad for p in qkv_params)
+            if (VARIANTS["dw_pair"] and not VARIANTS["dw_tn"] and all(p.requires_grad for p in qkv_params)
                     and _pair_saves_a_wave(wd.shape[0], wd.shape[1], sum(p.shape[0] for p in qkv_params), h, dy.shape[0])):
                 held = _dw_operands(dy, act, xT=actT) + (buf, acc)
             else:
@@ -363,7 +367,7 @@ class DecoderLayerFn(Function):
         dn2 = input_grad_gemm(dgu, wgu)                                         # [M, h]
         if any(p.requires_grad for p in gu_params):
             fb, acc, bufs = fused_grad_target(gu_params)
-            if _DW_TN or not _NORM_T:
+            if VARIANTS["dw_tn"] or not VARIANTS["norm_t"]:
                 weight_grad_gemm(dgu, ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps), fb, bool(acc), dyT=dguT)
             else:                                                              # norm output, contraction-major, from the saved rstd
                 rp = dguT.shape[1] if dguT is not None else _padded_rows(x2.shape[0], long_k=True)
@@ -382,7 +386,7 @@ class DecoderLayerFn(Function):
             weight_grad_gemm(dx2, o, buf, acc)
             commit_grad(att.o_proj.weight, buf)
         dqkv = torch.empty_like(qkv)
-        fuse_rope = _FUSE_ROPE and ops.attn_bwd_rope_supported(m.d)      # inverse RoPE of dq / dk in the attention kernels' epilogues
+        fuse_rope = VARIANTS["fuse_rope"] and ops.attn_bwd_rope_supported(m.d)      # inverse RoPE of dq / dk in the attention kernels' epilogues
         ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
                      m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:],
                      rope=(m.cos, m.sin, m.pos_offset) if fuse_rope else None)
@@ -393,7 +397,7 @@ class DecoderLayerFn(Function):
         dn1 = input_grad_gemm(dqkv, wqkv)
         if any(p.requires_grad for p in qkv_params):
             fb, acc, bufs = fused_grad_target(qkv_params)
-            if _DW_TN or not _NORM_T:
+            if VARIANTS["dw_tn"] or not VARIANTS["norm_t"]:
                 n1, n1T = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps), None
             else:
                 n1, n1T = None, ops.rmsnorm_apply_t(x, layer.input_layernorm.weight, rstd1, _padded_rows(x.shape[0], long_k=True))
@@ -738,7 +742,7 @@ class DecodeStepGraph:
         self.x_in = torch.zeros((1, h), device=device, dtype=BF16)
         self.x_out = None
         self.graph = None
-        if os.environ.get("MM355_DECODE_GRAPH", "1") == "0":
+        if not VARIANTS["decode_graph"]:
             return
         try:
             keep = cache.length

@@ -24,7 +24,6 @@ gloo backend in tests (the product default is the HIP kernels; there is no CPU f
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.distributed as dist
@@ -59,6 +58,25 @@ def tag_segments(model):
             p._mm_segment = ("layer", i)
 
 
+# How the exchange is driven when nothing else says so (constructor arguments override; tests / bench flip the module defaults through
+# set_collective_mode() -- there is no environment switch):
+#   force_collectives   run the collectives at world size 1 too (exercises the RCCL call pattern -- in-place reduce-scatter / all-gather,
+#                       async handles, side streams -- on a single-GPU box)
+#   tensor_collectives  use the RCCL form (in-place reduce_scatter_tensor / all_gather_into_tensor on slices of the flat buffers) on a
+#                       backend other than nccl (the gloo tests drive this branch at world 2-8 on CPU)
+_MODE = {"force_collectives": False, "tensor_collectives": False}
+
+
+def set_collective_mode(force_collectives=None, tensor_collectives=None):
+    """Change the module defaults; returns the previous ones (pass them back to restore)."""
+    old = dict(_MODE)
+    if force_collectives is not None:
+        _MODE["force_collectives"] = bool(force_collectives)
+    if tensor_collectives is not None:
+        _MODE["tensor_collectives"] = bool(tensor_collectives)
+    return old
+
+
 class _Pending:
     """One in-flight segment reduction (RCCL reduce-scatter, or the all-reduce stand-in of the gloo tests)."""
 
@@ -74,7 +92,8 @@ class _Pending:
 
 class Zero2AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=None, async_update=None):
+                 process_group=None, shard_update=None, sumsq=None, clip_coef=None, overlap=True, async_update=False,
+                 force_collectives=None, tensor_collectives=None):
         # `params`: an iterable of tensors, or of torch-style group dicts ({"params": [...], "lr": ..., "weight_decay": ...}) --
         # e.g. the reference's separate `vision_lr` group for the tower (metamorph_trainer.py:201-233)
         params = list(params)
@@ -94,27 +113,27 @@ class Zero2AdamW(torch.optim.Optimizer):
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
         self.max_grad_norm = max_grad_norm
-        # collectives are skipped at world size 1 unless MM355_ZERO2_FORCE_COLLECTIVES=1 (exercises the RCCL call pattern --
-        # in-place reduce-scatter / all-gather, async handles, side streams -- on a single-GPU box)
-        self._coll = self.distributed and (self.world > 1 or os.environ.get("MM355_ZERO2_FORCE_COLLECTIVES") == "1")
-        # the RCCL form of the exchange: in-place reduce_scatter_tensor / all_gather_into_tensor on slices of the flat buffers.
-        # MM355_ZERO_TENSOR_COLLECTIVES=1 runs the SAME calls on another backend (the gloo tests drive this branch at world 2-8 on CPU)
-        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or os.environ.get("MM355_ZERO_TENSOR_COLLECTIVES") == "1")
+        force = _MODE["force_collectives"] if force_collectives is None else bool(force_collectives)
+        tensor = _MODE["tensor_collectives"] if tensor_collectives is None else bool(tensor_collectives)
+        # collectives are skipped at world size 1 unless forced (see set_collective_mode)
+        self._coll = self.distributed and (self.world > 1 or force)
+        # the RCCL form of the exchange: in-place reduce_scatter_tensor / all_gather_into_tensor on slices of the flat buffers
+        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or tensor)
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq
         self._clip_coef = clip_coef or _hip_clip_coef
-        self.overlap = (os.environ.get("MM355_ZERO2_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self.overlap = True if overlap is None else bool(overlap)
         self._step = 0
         self._armed = False
         self._pending = {}                 # segment index -> _Pending
         self._flatten(params)
-        # asynchronous update (opt-in, MM355_ZERO2_ASYNC=1): the per-segment AdamW kernels and all-gathers run on a side stream
+        # asynchronous update (opt-in, async_update=True): the per-segment AdamW kernels and all-gathers run on a side stream
         # behind step(); the next forward pass waits per segment right before it reads that segment's parameters
         # (functional.params_ready).  On ONE GPU it buys nothing (measured: the HBM-bound update slows the concurrent GEMMs by
         # as much as it hides, 1014.9 vs 1012.7 ms/step); its purpose is hiding the all-gather at world > 1, which this round
         # could not measure, hence off by default.
         on_gpu = self.flat_param.is_cuda
-        self.async_update = on_gpu and ((os.environ.get("MM355_ZERO2_ASYNC", "0") == "1") if async_update is None else bool(async_update))
+        self.async_update = on_gpu and bool(async_update)
         self._upd_stream = torch.cuda.Stream(device=self.flat_param.device) if self.async_update else None
         self._ready = {}                   # segment index -> event recorded on the update stream
         self._waited = set()
@@ -164,6 +183,13 @@ class Zero2AdamW(torch.optim.Optimizer):
         out = {k: round(sum(s.elapsed_time(e) for s, e in v) / max(steps, 1), 3) for k, v in self._comm_events.items()}
         self._comm_events = {k: [] for k in self._comm_events}
         return out
+
+    def comm_bytes_per_step(self):
+        """Payload of one optimizer step's exchange, per rank: in-place reduce-scatter of the bf16 gradient buffer, all-gather of the bf16
+        parameter buffer (both `padded` elements, cut into `segments` collectives), one fp32 norm all-reduce."""
+        e = self.flat_param.element_size()
+        return {"reduce_scatter_bytes": int(self.padded) * e, "all_gather_bytes": int(self.padded) * e, "segments": len(self.segs),
+                "norm_all_reduce_bytes": 4, "world": self.world}
 
     # ------------------------------------------------------------------ layout
     def _flatten(self, params):

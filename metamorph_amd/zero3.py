@@ -32,12 +32,11 @@ world_size 1 degenerates to copies (shard -> slot); it exists so that the whole 
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.distributed as dist
 
-from .zero2 import ALIGN, BF16, _hip_clip_coef, _hip_shard_update, _hip_sumsq, tag_segments  # noqa: F401  (re-exported)
+from .zero2 import ALIGN, BF16, _MODE, _hip_clip_coef, _hip_shard_update, _hip_sumsq, tag_segments  # noqa: F401  (re-exported)
 
 
 def _hip_accumulate(dst, src, first):
@@ -63,7 +62,8 @@ class _Slot:
 
 class Zero3AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, process_group=None,
-                 shard_update=None, sumsq=None, clip_coef=None, accumulate=None, param_slots=3, grad_slots=2, min_shard_numel=1 << 20):
+                 shard_update=None, sumsq=None, clip_coef=None, accumulate=None, param_slots=3, grad_slots=2, min_shard_numel=1 << 20,
+                 force_collectives=None, tensor_collectives=None):
         params = list(params)
         if params and isinstance(params[0], dict):
             groups = [dict(g, params=[p for p in g["params"] if p.requires_grad]) for g in params]
@@ -78,9 +78,10 @@ class Zero3AdamW(torch.optim.Optimizer):
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(self.pg) if self.distributed else 1
         self.rank = dist.get_rank(self.pg) if self.distributed else 0
-        self._coll = self.distributed and (self.world > 1 or os.environ.get("MM355_ZERO2_FORCE_COLLECTIVES") == "1")
-        # RCCL form (tensor collectives on slices); MM355_ZERO_TENSOR_COLLECTIVES=1 runs the same calls on gloo in the CPU tests
-        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or os.environ.get("MM355_ZERO_TENSOR_COLLECTIVES") == "1")
+        force = _MODE["force_collectives"] if force_collectives is None else bool(force_collectives)
+        tensor = _MODE["tensor_collectives"] if tensor_collectives is None else bool(tensor_collectives)
+        self._coll = self.distributed and (self.world > 1 or force)       # (zero2.set_collective_mode: world-1 RCCL call pattern, gloo tests)
+        self._tensor_coll = self._coll and (dist.get_backend(self.pg) == "nccl" or tensor)
         self.max_grad_norm = max_grad_norm
         self._shard_update = shard_update or _hip_shard_update
         self._sumsq = sumsq or _hip_sumsq

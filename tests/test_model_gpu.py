@@ -9,6 +9,7 @@ regression of any of them fails.  Integer outputs are compared bit-exactly.
 """
 import glob
 import json
+import math
 import os
 
 import numpy as np
@@ -481,11 +482,12 @@ def test_greedy_decode_cached_equals_reprefill():
     same = (a == b).nonzero().numel()
     assert same >= a.numel() - 1 and int(a[0]) == int(b[0])     # bf16 near-ties may flip a late token, never the first
     # the hipGraph replay of the decode step and eager launches are the same kernels on the same data: identical tokens
-    os.environ["MM355_DECODE_GRAPH"] = "0"
+    from metamorph_amd import functional as F_
+    old = F_.set_variant("decode_graph", False)
     try:
         c = model.greedy_decode(None, None, emb, max_new_tokens=8, use_cache=True)[0]
     finally:
-        del os.environ["MM355_DECODE_GRAPH"]
+        F_.set_variant("decode_graph", old)
     assert torch.equal(a, c)
 
 
@@ -558,6 +560,68 @@ def test_hf_generate_matches_reference_recorded(name):
     # measured on MI355X: 1.5e-3 (text) / 1.11e-2 (image prompt, second beam: a -2.32 sum of log-probabilities) where the reference's own bf16
     # run is 3.1e-3 / 4.2e-3 off its fp32 run; floor = 1.5 x the larger measurement
     assert float((sc - ref32).abs().max()) <= max(3.0 * float((ref16 - ref32).abs().max()), 1.7e-2)
+
+
+def test_hf_generate_batch_of_left_padded_prompts_on_device():
+    """Batched `generate(use_customize_greedy=False)` (reference metamorph_llama.py:711-717): two prompts of different lengths, the shorter
+    LEFT-padded, with their attention mask -- on the device through the HIP kernels (round 3 ran this path only with the compute hooks
+    replaced by the oracle on the CPU).  Every row must emit what the reference recorded for the batch (hfgen_text.npz; each row
+    generates what it generates alone), the padding rows are never cached, the short prompt alone walks through the same per-step
+    arithmetic (bit-identical scores: one `_SeqState` per row, same kernels on the same data), right padding is refused."""
+    from oracle.ref_model import decode_fixture_state_dict
+    from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
+    g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, decode_fixture_state_dict(g, cfg, torch.bfloat16)).eval()
+    ids, mask = T(g["batch_input_ids"]).to(DEV), T(g["batch_attention_mask"]).to(DEV)
+    assert not bool(mask[1, 0]) and bool(mask[1, -1])             # row 1 is left-padded
+    kw = dict(use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009, pad_token_id=128001, return_dict_in_generate=True)
+    out = model.generate(inputs=ids, attention_mask=mask, output_scores=True, **kw)
+    assert out.sequences.tolist() == g["batch_sequences"].tolist(), (out.sequences.tolist(), g["batch_sequences"].tolist())
+    assert out.sequences[1].tolist() == g["short_alone_sequence"].tolist()
+    assert isinstance(out.past_key_values, HipKVCache)
+    st = out.past_key_values.states
+    n_pad = int((~mask[1]).sum())
+    assert [s_.pad for s_ in st] == [0, n_pad] and st[0].kv.length == st[1].kv.length + n_pad      # pad rows were never computed or cached
+    alone = model.generate(inputs=ids[1:, n_pad:], output_scores=True, **kw)
+    assert alone.sequences[0].tolist() == out.sequences[1].tolist()
+    for a, b in zip(alone.scores, out.scores):
+        assert torch.equal(a[0], b[1])
+    with pytest.raises(NotImplementedError):                      # right padding would put pad rows between the prompt and the generated tokens
+        model.generate(inputs=ids.flip(1), attention_mask=mask.flip(1), use_customize_greedy=False, do_sample=False, max_new_tokens=2,
+                       eos_token_id=128009, pad_token_id=128001)
+
+
+def test_bench_emits_the_driver_contract_on_device():
+    """`python bench.py --layers 2 --vit-layers 2 --steps 2 --warmup 1 --batch 2` really runs (a 2-layer debug geometry, NOT the headline
+    config) and its ONE stdout line carries the driver's contract: the required keys, value = tokens of the timed steps / their wall time,
+    `roofline` over ALL GEMM launches with the plain / fused split and the HBM-bound block, `cpu_baseline` with cores and sample."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--layers", "2", "--vit-layers", "2", "--steps", "2", "--warmup", "1", "--batch", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=repo)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["unit"] == "tokens/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16"
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and "workload" in r["config"] and "model" not in r["config"] and "synthetic" in r["data"]
+    tokens = r["config"]["global_batch"] * r["config"]["seq_len"]
+    assert abs(r["value"] - tokens / (r["ms_per_step"] * 1e-3)) <= 2e-3 * r["value"]
+    roof = r["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["launches"] == roof["plain"]["launches"] + roof["fused_mlp"]["launches"]
+    fl = roof["plain"]["algorithmic_flops_per_step"] + roof["fused_mlp"]["algorithmic_flops_per_step"]
+    assert abs(roof["algorithmic_flops_per_step"] - fl) <= 1e-6 * fl
+    assert {"rmsnorm_fwd", "transpose", "adamw_shard"} <= set(roof["hbm_bound"]) and all(0 < v["achieved_tb_s"] < 8.5 for v in roof["hbm_bound"].values())
+    cb = r["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert r["cpu_baseline_c1"]["fp32"]["steps_timed"] >= 3 and r["cpu_baseline_c1"]["fp32"]["warmup_steps"] >= 1
+    assert r["batch_pool"] >= 8 and math.isfinite(r["loss"])
 
 
 # ------------------------------------------------------------------ BASELINE configs[0] geometry class (TinyLlama: d = 64, GQA 8:1)

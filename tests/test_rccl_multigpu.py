@@ -76,8 +76,10 @@ def _worker(rank, world, port, stage, tmp, async_update):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
         from metamorph_amd import functional as F
-        from metamorph_amd.zero2 import Zero2AdamW, tag_segments
+        from metamorph_amd.zero2 import Zero2AdamW, set_collective_mode, tag_segments
         from metamorph_amd.zero3 import Zero3AdamW
+        if world == 1:
+            set_collective_mode(force_collectives=True)          # one rank: still run every collective (the RCCL call pattern)
         with torch.cuda.device(rank):
             model = _model()
             model.to(f"cuda:{rank}")
@@ -131,14 +133,13 @@ def test_n_ranks_over_rccl_equal_one_rank_on_the_mean_gradient(tmp_path, world, 
     _compare(tmp_path, world, stage, async_update)
 
 
-def test_one_rank_rccl_worker_path(tmp_path, monkeypatch):
+def test_one_rank_rccl_worker_path(tmp_path):
     """The same worker / comparison code with ONE rank and forced collectives (runs on the one-GPU boxes too): the spawn, the RCCL
     communicator, in-place reduce-scatter, all-gathers, the cross-rank equality check and the single-rank reference all execute;
     only the >1-rank arithmetic is left to the test above."""
     if _n_gpus() < 1:
         pytest.skip("no GPU")
-    monkeypatch.setenv("MM355_ZERO2_FORCE_COLLECTIVES", "1")
-    _compare(tmp_path, 1, 2, False)
+    _compare(tmp_path, 1, 2, False)                              # (a one-rank worker forces the collectives itself)
 
 
 def _compare(tmp_path, world, stage, async_update):

@@ -46,7 +46,7 @@ _SEGMENTS = [("layer", 0), ("layer", 0), ("layer", 0), ("layer", 1), ("layer", 1
 def _worker(rank, world, port, dtype, steps, tmp, overlap=False, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if tensor_coll:     # the RCCL form of the exchange (in-place reduce_scatter_tensor / all_gather_into_tensor on buffer slices), run on gloo
-        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
+        __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(tensor_collectives=True)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd.zero2 import Zero2AdamW
@@ -263,7 +263,7 @@ def test_consolidated_optimizer_state_moves_between_world_sizes(tmp_path, w1, w2
 def _model_worker(rank, world, port, tmp, overlap, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if tensor_coll:
-        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
+        __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(tensor_collectives=True)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd import functional as F

@@ -257,7 +257,7 @@ def test_async_update_equals_synchronous_update():
 def test_rccl_call_pattern_single_rank():
     """The collective call pattern of the multi-GPU path -- in-place reduce-scatter per segment launched asynchronously from
     DecoderLayerFn.backward, fp32 norm all-reduce, per-segment all-gather (synchronous and on the side stream) -- driven through
-    real RCCL with a one-rank process group (MM355_ZERO2_FORCE_COLLECTIVES=1): same losses as the collective-free run."""
+    real RCCL with a one-rank process group (zero2.set_collective_mode(force_collectives=True)): same losses as the collective-free run."""
     import os
     import socket
     import torch.distributed as dist
@@ -293,7 +293,7 @@ def test_rccl_call_pattern_single_rank():
     base, opt0 = train(False)
     assert not opt0._coll
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MM355_ZERO2_FORCE_COLLECTIVES"] = "1"
+    _old_mode = __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(force_collectives=True)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         for async_update in (False, True):
@@ -303,4 +303,4 @@ def test_rccl_call_pattern_single_rank():
                 assert abs(a - b) <= 2e-4 * abs(b), (async_update, losses, base)
     finally:
         dist.destroy_process_group()
-        del os.environ["MM355_ZERO2_FORCE_COLLECTIVES"]
+        __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(**_old_mode)

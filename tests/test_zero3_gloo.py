@@ -71,7 +71,7 @@ def _walk(model, opt, step, micro, rank, F, zero3):
 def _worker(rank, world, port, tmp, tensor_coll=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if tensor_coll:     # the RCCL form (all_gather_into_tensor into the slot, reduce_scatter_tensor out of the gradient slot) on gloo
-        os.environ["MM355_ZERO_TENSOR_COLLECTIVES"] = "1"
+        __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(tensor_collectives=True)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from metamorph_amd import functional as F

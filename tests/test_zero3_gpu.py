@@ -98,7 +98,7 @@ def test_zero3_rccl_call_pattern_single_rank():
     import torch.distributed as dist
     base, ebase, pbase, _ = _train(3)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MM355_ZERO2_FORCE_COLLECTIVES"] = "1"
+    _old_mode = __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(force_collectives=True)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         losses, ev, flat, opt = _train(3)
@@ -107,4 +107,4 @@ def test_zero3_rccl_call_pattern_single_rank():
         assert torch.equal(flat, pbase)
     finally:
         dist.destroy_process_group()
-        del os.environ["MM355_ZERO2_FORCE_COLLECTIVES"]
+        __import__("metamorph_amd.zero2", fromlist=["x"]).set_collective_mode(**_old_mode)
