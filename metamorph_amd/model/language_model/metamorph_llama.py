@@ -144,9 +144,15 @@ class HipKVCache(DynamicCache):
             self.states[i].pad = pad
 
     def crop(self, max_length):
+        """HF's convention: keep the first `max_length` positions of the PADDED sequence (what get_seq_length counts); negative = drop
+        the last -max_length positions.  Every row keeps max_length - pad real rows."""
+        max_length = int(max_length)
+        if max_length < 0:
+            max_length = self.get_seq_length() + max_length
         for st in self.states:
-            if 0 <= max_length < st.kv.length:
-                st.kv.set_length(int(max_length))
+            keep = max(max_length - st.pad, 0)
+            if keep < st.kv.length:
+                st.kv.set_length(keep)
 
 
 class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
@@ -313,9 +319,11 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         if past_key_values is not None or use_cache:
             # HF `generate()` (reference :711-717 -> GenerationMixin -> forward with a cache): prompt pass / one row per step on the
             # decode-shape kernels
-            if labels is not None or decoding or image_positions is not None:
+            if labels is not None or decoding:
                 raise NotImplementedError("past_key_values / use_cache together with labels or the image-AR head: the cached path is the "
                                           "generation path (no loss)")
+            # images handed through prepare_inputs_for_generation arrive spliced, with image_positions / image_features: without labels the
+            # reference computes no loss from them either (metamorph_llama.py:420-474 sits under `if labels is not None`), so they are dropped
             return self._cached_forward(input_ids, inputs_embeds, attention_mask, past_key_values, return_dict)
         if output_attentions:
             raise NotImplementedError("output_attentions: attention probabilities are never materialised by the flash kernel")
@@ -623,13 +631,15 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         outs = [state.stepper.step(x2d[i:i + 1]).clone() for i in range(x2d.shape[0])]
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
-    def _rows_logits(self, rows):
-        """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399)."""
+    def _rows_logits(self, rows, return_hidden=False):
+        """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399); return_hidden: (logits, normed rows)."""
         hid = self.model.norm(rows)
         if hid.shape[0] <= 8:
-            return ops.gemv(hid.contiguous(), self.lm_head.weight.data,
-                            out=torch.empty((hid.shape[0], self.lm_head.weight.shape[0]), device=rows.device, dtype=torch.float32))
-        return ops.gemm(hid, self.lm_head.weight.data, out_f32=True)
+            logits = ops.gemv(hid.contiguous(), self.lm_head.weight.data,
+                              out=torch.empty((hid.shape[0], self.lm_head.weight.shape[0]), device=rows.device, dtype=torch.float32))
+        else:
+            logits = ops.gemm(hid, self.lm_head.weight.data, out_f32=True)
+        return (logits, hid) if return_hidden else logits
 
     @torch.no_grad()
     def _cached_forward(self, input_ids, inputs_embeds, attention_mask, past_key_values, return_dict):
@@ -674,8 +684,8 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
             x2d = inputs_embeds[b].reshape(n, h).contiguous()
             rows.append(self._prefill_rows(x2d, st, cache.capacity) if first else self._decode_rows(x2d, st))
         rows = rows[0] if B == 1 else torch.cat(rows, 0)
-        logits = self._rows_logits(rows.contiguous()).view(B, n, -1)
-        hidden = self.model.norm(rows).view(B, n, h)
+        logits, hidden = self._rows_logits(rows.contiguous(), return_hidden=True)
+        logits, hidden = logits.view(B, n, -1), hidden.view(B, n, h)
         if return_dict is False:
             return (logits, cache)
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=cache, hidden_states=hidden, attentions=None)
@@ -711,7 +721,9 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
                     new = max(int(kwargs["max_length"]) - L0, 1)         # HF subtracts the inputs_embeds length from max_length itself
                 if new is None:
                     gc = kwargs.get("generation_config") or self.generation_config
-                    new = getattr(gc, "max_new_tokens", None) or getattr(gc, "max_length", 20) or 20
+                    new = getattr(gc, "max_new_tokens", None)
+                    if new is None:                                      # HF's max_length is a TOTAL that includes the inputs_embeds rows
+                        new = max(int(getattr(gc, "max_length", None) or 20) - L0, 1)
                 kwargs["past_key_values"] = HipKVCache(capacity=L0 + int(new) + 2)
             return GenerationMixin.generate(self, position_ids=position_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
                                             **kwargs)

@@ -469,7 +469,8 @@ class Zero3AdamW(torch.optim.Optimizer):
                 for d in shp:
                     n *= d
                 t = full[o:o + n].view(shp)
-                out[p] = t.to(device) if (device is not None and torch.device(device) != t.device) else t.clone()
+                u = t if device is None else t.to(device)
+                out[p] = u.clone() if u.data_ptr() == t.data_ptr() else u     # never alias the reusable gather buffer ("cuda" vs "cuda:0" compare unequal)
         return out
 
     # ------------------------------------------------------------------ checkpointing of the rank's shard

@@ -54,7 +54,11 @@ def _cpu_model(g):
 
     model._prefill_rows = prefill
     model._decode_rows = decode
-    model._rows_logits = lambda rows: R.linear(R.rmsnorm(rows.float(), sd["model.norm.weight"], cfg.rms_norm_eps), sd["lm_head.weight"]).float()
+    def rows_logits(rows, return_hidden=False):                   # final norm + lm_head (the product returns the normed rows on request)
+        hid = R.rmsnorm(rows.float(), sd["model.norm.weight"], cfg.rms_norm_eps)
+        logits = R.linear(hid, sd["lm_head.weight"]).float()
+        return (logits, hid) if return_hidden else logits
+    model._rows_logits = rows_logits
     model.model.norm.forward = lambda x: R.rmsnorm(x.float(), sd["model.norm.weight"], cfg.rms_norm_eps).bfloat16()
     model.model.embed_tokens.forward = lambda ids: sd["model.embed_tokens.weight"][ids].bfloat16()
     return model, calls
@@ -146,3 +150,11 @@ def test_hip_kv_cache_is_a_transformers_cache():
     assert float(c.states[0].kv.k[0, 0, 7, 0]) == 1.0            # rows beyond the length are left alone
     c.crop(5)
     assert c.get_seq_length() == 5
+    # a left-padded row counts its padding: HF's lengths are PADDED lengths; negative = drop the last k positions
+    c.states = [seq(7, 1.0), seq(4, 2.0)]
+    c.states[1].pad = 3
+    assert c.get_seq_length() == 7
+    c.crop(6)
+    assert [st.kv.length for st in c.states] == [6, 3] and c.get_seq_length() == 6
+    c.crop(-2)
+    assert [st.kv.length for st in c.states] == [4, 1] and c.get_seq_length() == 4
