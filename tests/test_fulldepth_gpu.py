@@ -67,11 +67,12 @@ def test_configs1_full_depth_against_streamed_oracle():
 
     ref16 = None
     if os.environ.get("MM355_FULLDEPTH_REF_BF16", "1") != "0":
-        # the yardstick for the depth-accumulated error (forward only, ~20 s): the SAME streamed oracle run in bf16 -- the reference
-        # stack's own bf16 arithmetic (HF modules in bf16 on the CPU) -- against its fp32 run
+        # the yardstick for the depth-accumulated error: the SAME streamed oracle run in bf16 -- the reference stack's own bf16
+        # arithmetic (HF modules in bf16 on the CPU) -- against its fp32 run, forward AND (round 4) backward: the same 28 gradient
+        # tensors, so that "within bf16 tolerance" has a measured meaning for every one of them
         t0 = time.time()
         ref16 = full_depth(lambda k: sdict[k].detach().cpu(), cfg, ids.cpu(), mask.cpu(), labels.cpu(), images.cpu(),
-                           probe_layers=PROBES, backward=False)
+                           probe_layers=PROBES, grad_layers=(0, layers - 1), backward=True)
         e16 = {n: rel(ref16["probes"][n][ref["attention_mask"]], ref["probes"][n][ref["attention_mask"]]) for n in PROBES if n <= layers}
         print(f"   oracle in bf16 vs oracle in fp32 ({time.time() - t0:.0f}s): tower {rel(ref16['raw_hidden'], ref['raw_hidden']):.3e}  hidden after n layers "
               + "  ".join(f"{n}: {e:.3e}" for n, e in e16.items())
@@ -84,10 +85,12 @@ def test_configs1_full_depth_against_streamed_oracle():
     errs = {n: rel(taps[n].view(2, 2048, -1)[valid], ref["probes"][n][valid]) for n in PROBES if n <= layers}
     e_fin = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"][valid])
     params = dict(model.named_parameters())
-    worst, per_tensor = {}, {}
+    worst, per_tensor, per_tensor16 = {}, {}, {}
     for k, g in ref["grads"].items():
         e = rel(params[k].grad, g) if params[k].grad is not None else float("inf")
         per_tensor[k] = e
+        if ref16 is not None and k in ref16.get("grads", {}):
+            per_tensor16[k] = rel(ref16["grads"][k], g)
         grp = "layer " + k.split(".")[2] if k.startswith("model.layers.") else "heads/projector"
         worst[grp] = max(worst.get(grp, (0.0, "")), (e, k))
     print(f"   tower hidden_states[-1] after {vit_layers} layers: rel err {e_raw:.3e}")
@@ -95,10 +98,14 @@ def test_configs1_full_depth_against_streamed_oracle():
     print(f"   loss hip={got_loss:.5f} oracle-fp32={ref['loss']:.5f}  lang {got_lang:.5f}/{ref['loss_language']:.5f}  "
           f"img {got_img:.5f}/{ref['loss_image_ar']:.5f}")
     print("   gradients, worst rel err: " + "  ".join(f"{g}: {e:.3e} ({k.split('.', 3)[-1] if g != 'heads/projector' else k})" for g, (e, k) in worst.items()))
+    if per_tensor16:
+        print("   gradients vs fp32, HIP | the oracle in bf16 (the reference stack's own arithmetic):")
+        for k in sorted(per_tensor, key=lambda k_: -per_tensor[k_]):
+            print(f"      {k}: {per_tensor[k]:.3e} | {per_tensor16.get(k, float('nan')):.3e}")
     record = dict(layers=layers, tower_layers=vit_layers, rows=ref["n_rows"], oracle_seconds=ref["seconds"], tower_rel_err=e_raw,
                   hidden_rel_err_after_layers=errs, final_norm_rel_err=e_fin, loss=dict(hip=got_loss, oracle=ref["loss"]),
                   loss_language=dict(hip=got_lang, oracle=ref["loss_language"]), loss_image_ar=dict(hip=got_img, oracle=ref["loss_image_ar"]),
-                  grad_rel_err=per_tensor)
+                  grad_rel_err=per_tensor, grad_rel_err_oracle_bf16=per_tensor16)
     if ref16 is not None:
         va = ref["attention_mask"]
         record["oracle_bf16_vs_fp32"] = dict(tower=rel(ref16["raw_hidden"], ref["raw_hidden"]), hidden_after_layers=e16,
@@ -134,11 +141,17 @@ def test_configs1_full_depth_against_streamed_oracle():
         assert abs(got_loss - ref["loss"]) <= max(3.0 * abs(ref16["loss"] - ref["loss"]), 2e-4 * abs(ref["loss"]))
     assert len(ref["grads"]) == 18 + 2 + 4 + 4
     for k, e in per_tensor.items():
-        # q / k projections of a random-weight model receive near-noise gradients (attention scores ~ uniform): measured 9.6e-2 in
-        # layer 31, 6.2e-2 in layer 0; everything else <= 5.7e-2 (the activations they are computed from carry 4e-2 by then)
-        assert e <= (GRAD_TOL_QK if ("q_proj" in k or "k_proj" in k) else GRAD_TOL), (k, e)
+        if per_tensor16:
+            # the yardstick: the reference stack's own bf16 run of the same backward chain; each HIP gradient within 1.5 x its distance from
+            # the fp32 truth (floor: bf16 resolution of a depth-32 chain, the 3.3e-2 of tests/test_model_gpu.py's 2-layer goldens)
+            assert e <= max(1.5 * per_tensor16[k], GRAD_FLOOR), (k, e, per_tensor16[k])
+        else:
+            # (MM355_FULLDEPTH_REF_BF16=0: no yardstick) q / k projections of a random-weight model receive near-noise gradients:
+            # measured 9.6e-2 in layer 31, 6.2e-2 in layer 0; everything else <= 5.7e-2
+            assert e <= (GRAD_TOL_QK if ("q_proj" in k or "k_proj" in k) else GRAD_TOL), (k, e)
 
 
 TOWER_TOL = 1.8e-2                                               # measured 1.18e-2 (oracle in bf16: 1.31e-2)
 HIDDEN_TOL = {1: 1.4e-2, 8: 3.0e-2, 16: 4.2e-2, 32: 5.9e-2, "final": 5.9e-2}     # measured 9.0e-3 / 2.0e-2 / 2.8e-2 / 3.9e-2 / 3.9e-2
 GRAD_TOL, GRAD_TOL_QK = 8.5e-2, 1.45e-1
+GRAD_FLOOR = 3.3e-2

@@ -11,6 +11,7 @@ import glob
 import json
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -918,6 +919,105 @@ def test_configs2_shape_8_frames_seq4096_against_oracle():
     n = _fullwidth_check(cfg, ids, labels, mask, images, seed=77, grad_tol=3.2e-2, hidden_tol=1.3e-2, what="configs[2] shape (8 frames, L=4096)",
                          check_embed_grad=False)
     assert n >= 20
+
+
+# ------------------------------------------------------------------ depth beyond two layers for configs[0] and configs[2] (round 4)
+def _depth_check(cfg, ids, labels, mask, images, seed, what):
+    """HIP model (bf16) vs the LAYER-STREAMED fp32 oracle (oracle/ref_stream.py, pinned to the plain oracle by tests/test_oracle_stream.py)
+    on the same bf16-rounded weights, with the SAME streamed oracle run in bf16 -- the reference stack's own arithmetic -- as the yardstick
+    for what depth does to bf16: loss at 1e-3 (north_star), final hidden rows no farther from the fp32 truth than 1.15 x the bf16
+    oracle, every gradient of the first and the last decoder layer, the final norm, lm_head, vision_head and mm_projector within
+    max(1.5 x the bf16 oracle's own distance, 3.3e-2)."""
+    from oracle.ref_stream import full_depth
+    sd16 = init_state_dict(cfg, seed=seed, dtype=torch.bfloat16, fast_big=True)
+    model = hip_model(cfg, sd16)
+    model.train()
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), images=images.to(DEV).bfloat16())
+    plan = model.prepare_inputs_labels_for_multimodal(ids.to(DEV), None, mask.to(DEV), None, labels.to(DEV), images.to(DEV).bfloat16())
+    out.loss.backward()
+    torch.cuda.synchronize()
+    NL = cfg.num_hidden_layers
+    img16 = images.bfloat16()
+    t0 = time.time()
+    ref = full_depth(lambda k: sd16[k].float(), cfg, ids, mask, labels, img16.float(), grad_layers=(0, NL - 1))
+    t1 = time.time()
+    ref16 = full_depth(lambda k: sd16[k], cfg, ids, mask, labels, img16, grad_layers=(0, NL - 1), backward=True)
+    print(f"\n   {what}: streamed oracle fp32 {t1 - t0:.0f}s, bf16 {time.time() - t1:.0f}s; rows per sample {ref['n_rows']}")
+    assert torch.equal(plan[5].cpu(), ref["labels"]) and torch.equal(plan[6].cpu(), ref["image_positions"])
+    assert torch.equal(plan[2].cpu().bool(), ref["attention_mask"])
+    got, want = float(out.loss.detach()), ref["loss"]
+    print(f"   loss hip={got:.5f} oracle-fp32={want:.5f} oracle-bf16={ref16['loss']:.5f}  lang {model.loss_language:.5f}/{ref['loss_language']:.5f}  "
+          f"img {model.loss_image_ar:.5f}/{ref['loss_image_ar']:.5f}")
+    assert abs(got - want) <= 1e-3 * abs(want), (got, want)
+    assert abs(model.loss_language - ref["loss_language"]) <= 1e-3 * abs(want)
+    assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 1e-3
+    valid = ref["attention_mask"]
+    e_h = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"][valid])
+    e_16 = rel(ref16["hidden_states"].float()[valid], ref["hidden_states"][valid])
+    print(f"   final hidden rows after {NL} layers vs fp32: hip {e_h:.3e}  oracle-bf16 {e_16:.3e}")
+    assert e_h <= max(1.15 * e_16, 8e-3), (e_h, e_16)
+    params = dict(model.named_parameters())
+    n, worst = 0, (0.0, "", 0.0)
+    for k, g in ref["grads"].items():
+        assert params[k].grad is not None, k
+        e, e16 = rel(params[k].grad, g), rel(ref16["grads"][k].float(), g)
+        worst = max(worst, (e, k, e16))
+        assert e <= max(1.5 * e16, 3.3e-2), (k, e, e16)
+        n += 1
+    print(f"   {n} gradient tensors (layers 0 and {NL - 1}, heads, projector), worst rel err vs fp32: hip {worst[0]:.3e} (oracle-bf16 {worst[2]:.3e}) {worst[1]}")
+    return n
+
+
+def test_configs0_tinyllama_full_depth_22_layers_against_streamed_oracle():
+    """BASELINE configs[0] at its REAL depth (round 3 ran 2 of the 22 decoder layers): TinyLlama-1.1B geometry (22 layers, h 2048,
+    32 query / 4 KV heads of size 64 -> the generic attention kernels, I 5632, V 32002, <image_start> = 32000) + the SO400M/14-384 tower
+    at its real 27 layers, 1 prompt image (256 tokens) + 128 text ids, plus a generation sample (answer-side image)."""
+    cfg = OracleConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=22, num_attention_heads=32, num_key_value_heads=4,
+                       vocab_size=32002, rope_theta=10000.0, v_layers=27, num_image_tokens=256, tokenizer_model_max_length=2048,
+                       image_start_id=32000)
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, 31999, (2, 129), generator=g)
+    ids[:, 0] = 1
+    ids[:, 21], ids[:, 22], ids[:, 23] = 32000, -200, 32001
+    labels = torch.full_like(ids, -100)
+    labels[0, -64:] = ids[0, -64:]
+    labels[1, 18:] = ids[1, 18:]
+    labels[1, 22] = -200
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    images = torch.randn(2, 3, 384, 384, generator=g)
+    assert _depth_check(cfg, ids, labels, mask, images, seed=33, what="configs[0] TinyLlama-1.1B, 22 + 27 layers") == 28
+
+
+def test_configs2_shape_8_frames_seq4096_eight_layers_against_streamed_oracle():
+    """BASELINE configs[2]'s shape beyond two layers: LLaMA-3-8B widths, spliced length exactly 4096 with EIGHT prompt-side frames of 256
+    tokens, EIGHT decoder layers (+ two tower layers), and a shorter second sample with an answer-side frame after two prompt frames."""
+    cfg = OracleConfig(num_hidden_layers=8, v_layers=2, num_image_tokens=256, tokenizer_model_max_length=4096)
+    g = torch.Generator().manual_seed(4321)
+    L, T_img = 4096, 256
+    n_ids = L - 8 * (T_img - 1)
+    ids = torch.full((2, n_ids), 128001, dtype=torch.long)
+    row = torch.randint(0, 127999, (n_ids,), generator=g)
+    row[0] = row[1] = 128000
+    for f in range(8):
+        p = 22 + 3 * f
+        row[p], row[p + 1], row[p + 2] = 128256, -200, 128257
+    ids[0] = row
+    lab0 = torch.full((n_ids,), -100, dtype=torch.long)
+    lab0[-512:] = row[-512:]
+    short = 604
+    r1 = torch.randint(0, 127999, (short,), generator=g)
+    r1[0] = r1[1] = 128000
+    for p in (10, 13):
+        r1[p], r1[p + 1], r1[p + 2] = 128256, -200, 128257
+    r1[600], r1[601], r1[602], r1[603] = 128256, -200, 128257, 128009
+    ids[1, :short] = r1
+    lab1 = torch.full((n_ids,), -100, dtype=torch.long)
+    lab1[300:604] = r1[300:604]
+    lab1[601] = -200
+    labels = torch.stack([lab0, lab1])
+    mask = ids.ne(128001)
+    images = torch.randn(8 + 3, 3, 384, 384, generator=g)
+    assert _depth_check(cfg, ids, labels, mask, images, seed=78, what="configs[2] shape (8 frames, L = 4096), 8 layers") == 28
 
 
 # ------------------------------------------------------------------ BASELINE configs[3]: generation-mode finetune (all samples regress an image)
