@@ -50,7 +50,9 @@ const char* mm355_strerror(int code);
  *             if ACCUMULATE v += C_old[m][n];  store as bf16 (or f32 with OUT_F32).
  * Requirements: K % 8 == 0, lda/ldb % 8 == 0 (ldc/ldr % 8 == 0 for bf16 vector stores, else scalar tail).
  * variant: 0 = auto (ping-pong 256x256 kernel, variant 11, once >= 200 tiles and K % 64 == 0; 128x128 LDS-DMA otherwise);
- *          1..mm355_gemm_num_variants() select a specific tile configuration / schedule (bench / tests).
+ *          1..mm355_gemm_num_variants() select a specific tile configuration / schedule (bench / tests); 13 = the one-wave-per-SIMD
+ *          kernel (csrc/gemm_st.hip: persistent 4-wave workgroups, 128 x 128 wave tiles, hand-placed stream; K % 128 == 0, K >= 256,
+ *          MM355_EUNSUPPORTED otherwise), 14 = the same stream serialised -- both bit-identical to 11.
  * ------------------------------------------------------------------------------------------------ */
 #define MM355_GEMM_BIAS        1u
 #define MM355_GEMM_GELU_ERF    2u    /* nn.GELU() default (projector, vision_head)         */

@@ -10,14 +10,14 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn4.hip", "attn4_bwd.hip", "decode.hip", "losses.hip"]
-HEADERS = ["mm355_common.h", "attn2.h", "attn3_kernels.h"] + sorted(
-    os.path.join(d, f) for d in ("attn4_gen", "attn4_bwd_gen") for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(".inc"))   # tools/gen_attn4*.py output
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn4.hip", "attn4_bwd.hip", "gemm_st.hip", "decode.hip", "losses.hip"]
+HEADERS = ["mm355_common.h", "gemm_common.h", "attn2.h", "attn3_kernels.h"] + sorted(
+    os.path.join(d, f) for d in ("attn4_gen", "attn4_bwd_gen", "gemm_st_gen") for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(".inc"))   # tools/gen_attn4*.py output
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD): no accumulator <-> VGPR moves around the VALU phases
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # the hand-placed streams own the accumulator file: hipcc must not park its own spills there (tools/audit_attn4.py checks the result)
-FLAGS_OF = {f: BASE_FLAGS + ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"] for f in ("attn4.hip", "attn4_bwd.hip")}
+FLAGS_OF = {f: BASE_FLAGS + ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"] for f in ("attn4.hip", "attn4_bwd.hip", "gemm_st.hip")}
 
 
 def _hipcc():

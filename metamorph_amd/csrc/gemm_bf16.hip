@@ -13,57 +13,11 @@
 //     residual / accumulate fused.
 //   * workgroup -> tile map: bijective XCD remap (block b runs on XCD b % 8) then grouped raster so the
 //     blocks sharing an XCD's L2 walk neighbouring tiles.
-#include "mm355_common.h"
+#include "gemm_common.h"
 #include <type_traits>
 #include <cstdlib>
 
 namespace {
-
-struct GemmArgs {
-    const uint16_t* A;
-    const uint16_t* B;
-    void* C;
-    const uint16_t* bias;
-    const uint16_t* res;
-    int64_t lda, ldb, ldc, ldr, res_mod;
-    int M, N, K;
-    uint32_t flags;
-    int ntm, ntn;
-    int gm;                                                  // raster group height in tiles (ping-pong kernel)
-    uint16_t* aux0;                                          // fused SwiGLU-backward epilogue: actT [I][ld_aux]
-    uint16_t* aux1;                                          //                                 dguT [2 I][ld_aux]
-    int64_t ld_aux;
-};
-
-// ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
-// so the unrolled fast path stays small.
-// (arguments by value: taking the address of the kernel-argument struct would push it into scratch memory)
-__device__ __attribute__((noinline)) void epi_scalar(void* C, int64_t ldc, const uint16_t* bias, const uint16_t* res, int64_t ldr,
-                                                     uint32_t fl, int N, int grow, int c, int64_t rr, float v0, float v1,
-                                                     float v2, float v3, float v4, float v5, float v6, float v7) {
-    const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-    for (int e = 0; e < 8; ++e) {
-        const int ce = c + e;
-        if (ce >= N) break;
-        float x = v[e];
-        if (fl & MM355_GEMM_BIAS) x += bf2f(bias[ce]);
-        if (fl & MM355_GEMM_GELU_ERF) x = gelu_erf_f(x);
-        else if (fl & MM355_GEMM_GELU_TANH) x = gelu_tanh_f(x);
-        if (fl & MM355_GEMM_RESIDUAL) x += bf2f(res[rr * ldr + ce]);
-        if (fl & MM355_GEMM_OUT_F32) {
-            float* p = (float*)C + (int64_t)grow * ldc + ce;
-            if (fl & MM355_GEMM_ACCUMULATE) x += *p;
-            *p = x;
-        } else {
-            uint16_t* p = (uint16_t*)C + (int64_t)grow * ldc + ce;
-            if (fl & MM355_GEMM_ACCUMULATE) x += bf2f(*p);
-            *p = f2bf(x);
-        }
-    }
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Shared epilogue: accumulators -> wave-private LDS slab -> row-contiguous 16-B stores with the fused epilogue.
 template <int TM, int TN, int FM, int FN>
@@ -102,49 +56,7 @@ MM_DEV void gemm_epilogue(f32x4 (&acc)[FM][FN], const GemmArgs& a, unsigned char
                 const f32x4 s1 = *(const f32x4*)(stg + row_l * TN + col_l + j * 8 + 4);
                 v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w;
                 v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
-                const bool full = (c + 8 <= N) && vec_ok;
-                if (full) {
-                    if (fl & MM355_GEMM_BIAS) {
-                        float b[8];
-                        unpack8(*(const u32x4*)(a.bias + c), b);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += b[e];
-                    }
-                    if (fl & MM355_GEMM_GELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-                    } else if (fl & MM355_GEMM_GELU_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
-                    }
-                    if (fl & MM355_GEMM_RESIDUAL) {
-                        float b[8];
-                        unpack8(*(const u32x4*)(a.res + rr * a.ldr + c), b);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += b[e];
-                    }
-                    if (fl & MM355_GEMM_OUT_F32) {
-                        float* p = Cf + (int64_t)grow * a.ldc + c;
-                        if (fl & MM355_GEMM_ACCUMULATE) {
-                            const f32x4 o0 = *(const f32x4*)p, o1 = *(const f32x4*)(p + 4);
-                            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
-                            v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
-                        }
-                        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    } else {
-                        uint16_t* p = Cb + (int64_t)grow * a.ldc + c;
-                        if (fl & MM355_GEMM_ACCUMULATE) {
-                            float b[8];
-                            unpack8(*(const u32x4*)p, b);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += b[e];
-                        }
-                        *(u32x4*)p = pack8(v);
-                    }
-                } else {
-                    epi_scalar(a.C, a.ldc, a.bias, a.res, a.ldr, fl, N, grow, c, rr, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-                }
+                epi_store8(a, fl, vec_ok, grow, rr, c, v);
             }
         }
     }
@@ -1399,7 +1311,14 @@ __global__ __launch_bounds__(1024) void colsum8_kernel(const uint16_t* __restric
 
 }  // namespace
 
-extern "C" int mm355_gemm_num_variants(void) { return 12; }
+extern "C" int mm355_gemm_num_variants(void) { return 14; }
+
+int mm355_gemm_st_launch(const void* args, int serialised, void* stream);   // gemm_st.hip: one wave per SIMD, hand-placed stream
+
+namespace {
+// the stream kernel moves whole pairs of K stages and fetches two stages ahead: K % 128 == 0, K >= 256, 31-bit tile-relative offsets
+bool st_eligible(const GemmArgs& a) { return a.K >= 256 && pp_eligible(a, false, false); }
+}  // namespace
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -1437,6 +1356,7 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         case 10: return launch_gemm_ring(a, s);
         case 11: return launch_gemm_pp(a, s);
         case 12: return launch_gemm_pp2(a, s);
+        case 13: case 14: return st_eligible(a) ? mm355_gemm_st_launch(&a, variant == 14, s) : MM355_EUNSUPPORTED;
 #ifdef MM355_ABLATIONS                                       // TIMING-ONLY builds (tools/build_ablation.sh ... -DMM355_ABLATIONS): wrong results on purpose
         case 91: return launch_gemm_pp_t<false, false, 1>(a, s);     // no DMA
         case 92: return launch_gemm_pp_t<false, false, 2>(a, s);     // no fragment reads

@@ -103,6 +103,39 @@ def test_gemm_pingpong_race_screen(ops, shape):
     close(ops.gemm(a.to(DEV), b.to(DEV), variant=11), a.float() @ b.float().t(), 1e-2, 0.02 * math.sqrt(K), f"gemm v11 {shape}")
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 256), (300, 520, 384), (2048, 2304, 256), (8192, 4096, 512), (8448, 2560, 384), (1024, 1028, 1152)])
+def test_gemm_one_wave_per_simd_stream_is_bit_identical(ops, shape):
+    """Variant 13 (csrc/gemm_st.hip: persistent workgroups of four waves, 128 x 128 wave tiles with all 256 accumulators in AGPRs, a
+    hand-placed instruction stream) and variant 14 (the same stream serialised: every LDS read / LDS-DMA piece waited for on the spot)
+    against the eight-wave ping-pong kernel: the same 16x16x32 MFMA per 32 k in ascending order and the same fused store, so every
+    output -- ragged edges, the N % 8 scalar tail, several tiles per workgroup (the persistent hand-over with the next tile's first two
+    K stages in flight during the epilogue), uneven per-XCD tile ranges, each epilogue flag -- is BIT-identical; two data sets (race screen)."""
+    M, N, K = shape
+    for rep in range(2):
+        a, b = rnd(M, K, seed=30 + rep).to(DEV), rnd(N, K, seed=40 + rep).to(DEV)
+        ref = ops.gemm(a, b, variant=11)
+        for v in (13, 14):
+            out = ops.gemm(a, b, variant=v)
+            assert torch.equal(out, ref), f"variant {v} differs from variant 11 at {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
+    a, b = rnd(M, K, seed=1, scale=0.3).to(DEV), rnd(N, K, seed=2, scale=0.3).to(DEV)
+    bias, res, c0 = rnd(N, seed=5).to(DEV), rnd(64, N, seed=6).to(DEV), rnd(M, N, seed=8).to(DEV)
+    for kw in (dict(bias=bias, gelu="erf"), dict(bias=bias, gelu="tanh"), dict(bias=bias, residual=res, res_row_mod=64), dict(accumulate=True),
+               dict(accumulate=True, out_f32=True)):
+        outs = []
+        for v in (11, 13, 14):
+            c = (c0.float() if kw.get("out_f32") else c0).clone()
+            ops.gemm(a, b, out=c, variant=v, **kw)
+            outs.append(c)
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), f"epilogue {sorted(kw)} at {shape}"
+
+
+def test_gemm_stream_variant_rejects_short_k(ops):
+    from metamorph_amd.lib import Mm355Error
+    a, b = rnd(256, 128, seed=1).to(DEV), rnd(256, 128, seed=2).to(DEV)
+    with pytest.raises(Mm355Error):
+        ops.gemm(a, b, variant=13)                              # two K stages: the stream fetches two stages ahead (K >= 256, K % 128 == 0)
+
+
 @pytest.mark.parametrize("shapes", [((512, 768, 256), (300, 520, 384)), ((256, 256, 128), (256, 256, 128)),
                                     ((1024, 2048, 1152), (2300, 264, 128)), ((8, 8, 128), (2048, 1280, 640))])
 def test_gemm_pair_equals_two_launches(ops, shapes):

@@ -36,7 +36,7 @@ def audit(path):
         if t.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        m = re.match(r"^(_ZN\d+attn4b?\d+\w+):", t)
+        m = re.match(r"^(_ZN\d+attn4b?\d+\w+|_ZN\d+_GLOBAL__N_\w*gemm_st_kernel\w+):", t)
         if m:
             kernel = m.group(1) if "nstat" not in m.group(1) else None      # (plain helper kernels own no stream)
             if kernel:
@@ -54,7 +54,7 @@ def audit(path):
         stats[kernel]["compiler_lines"] += 1
         if "scratch_" in code:
             bad.append((ln, t))
-        lim = 96 if "dkdv" in kernel else (80 if "dq_kernel" in kernel else 64)      # the kernel's amdgpu_num_vgpr
+        lim = 96 if ("dkdv" in kernel or "gemm_st" in kernel) else (80 if "dq_kernel" in kernel else 64)      # the kernel's amdgpu_num_vgpr
         for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
             if int(b) >= lim:
                 bad.append((ln, t))
@@ -67,7 +67,7 @@ def audit(path):
 
 
 if __name__ == "__main__":
-    paths = sys.argv[1:] if len(sys.argv) > 1 else [compile_s("attn4"), compile_s("attn4_bwd")]
+    paths = sys.argv[1:] if len(sys.argv) > 1 else [compile_s("attn4"), compile_s("attn4_bwd"), compile_s("gemm_st")]
     failed = False
     for path in paths:
         bad, stats = audit(path)
