@@ -266,6 +266,14 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
  *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
  *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
  *         upper bound of them (sizes the launch and the workspace of mm355_attn_decode_ws_floats floats); GQA groups 1/2/4/8.
+ *         ONE launch (round 4): the 256-key chunk that finishes last merges the partials of its heads; the arrival counters are the
+ *         last B*Hq words of the workspace -- zero them once before the first call (hipMemset), every call leaves them zero.
+ *   gemv_swiglu: act[M][I] = SiLU(g) * u with [g | u] = n . Wgu[2I][K]^T formed in the GEMV's epilogue (g, u rounded to bf16 first:
+ *         the bits of mm355_gemv_bf16 + mm355_swiglu_fwd); norm_w != NULL: n = RMSNorm(x; norm_w, eps) formed per workgroup on the
+ *         fly (the bits of mm355_rmsnorm_fwd), else n = x.  HF LlamaMLP / LlamaRMSNorm at decode shape (metamorph_llama.py:502-597).
+ *   gemv_rope_append: the fused q|k|v projection of M new rows with RoPE at positions[m] (device) and the KV-cache append in the
+ *         epilogue: q -> qkv[m][0 .. Hq*d), rotated k and v -> cache row positions[m] (the bits of mm355_gemv_bf16 +
+ *         mm355_rope_kv_append); the k | v columns of `qkv` are not written.  norm_w as above.
  * ------------------------------------------------------------------------------------------------ */
 int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* W, int64_t ldw, void* y, int64_t ldy,
                     int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr,
@@ -275,11 +283,23 @@ int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* W, int64
 int mm355_rope_kv_append(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t Hq, int64_t Hkv, int64_t d,
                          const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* positions,
                          mm355_bf16* k_cache, mm355_bf16* v_cache, int64_t ld_kv, int64_t batch_stride_kv, void* stream);
+int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* act, int64_t ld_act,
+                           int64_t M, int64_t I, int64_t K, const mm355_bf16* norm_w, float eps, void* stream);
+int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                                int64_t M, int64_t Hq, int64_t Hkv, int64_t d, int64_t K, const mm355_bf16* norm_w, float eps,
+                                const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* positions, mm355_bf16* k_cache,
+                                mm355_bf16* v_cache, int64_t ld_kv, int64_t batch_stride_kv, void* stream);
 int64_t mm355_attn_decode_ws_floats(int64_t B, int64_t Hq, int64_t d, int64_t max_kv_len);
 int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
                       int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,
                       mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,
                       float* workspace, void* stream);
+/* tests / tools: variant 0 = as mm355_attn_decode (one 1024-thread workgroup per sample, KV head and 1024 cached rows; the lone
+ * workgroup of a cache of <= 1024 rows writes the output itself), 1 = one 256-thread workgroup per 256-row chunk + merge by the last. */
+int mm355_attn_decode_variant(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
+                      int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,
+                      mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,
+                      float* workspace, int variant, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise: SwiGLU (HF LlamaMLP; K12), GELU (projector / vision_head), scaling helpers.

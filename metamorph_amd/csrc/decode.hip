@@ -121,6 +121,184 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused decode GEMVs
+// The decode step of one layer is nine tiny launches around four weight streams; three of them fold into the GEMVs that consume /
+// produce their rows (round 4):
+//   PRENORM  the RMSNorm in front of the qkv and gate|up projections: every workgroup reduces the M <= 8 input rows itself (8 KiB each,
+//            L2-resident) while its first weight loads are in flight, and forms bf16(w * bf16(x * rstd)) -- rmsnorm_fwd_kernel's
+//            arithmetic and reduction order, bit for bit -- as the x operand;
+//   MODE 1   SiLU(gate) * up in the epilogue: a wave owns gate rows c, c + 1 AND up rows I + c, I + 1 + c of the fused weight, rounds
+//            both to bf16 as the unfused GEMV would have stored them and applies swiglu_fwd_kernel's arithmetic; gu never exists;
+//   MODE 2   RoPE + KV-cache append in the epilogue: a wave owns the rotation partners j, j + 1, j + d/2, j + 1 + d/2 of one head (v rows:
+//            four neighbours), rotates the bf16-rounded q / k values at the DEVICE-side position as rope_kv_append_kernel does and
+//            writes q to the row buffer, k / v to the cache row.
+struct GemvFusedArgs {
+    const uint16_t* x; int64_t ldx;
+    const uint16_t* W; int64_t ldw;
+    int M, N, K;                                             // N = weight rows
+    const uint16_t* norm_w; float eps;                       // PRENORM
+    uint16_t* out; int64_t ld_out;                           // MODE 1: act [M][I]; MODE 2: qkv row buffer [M][N]
+    int I;                                                   // MODE 1
+    int Hq, Hkv, d;                                          // MODE 2
+    const uint16_t* cos_t; const uint16_t* sin_t; const int32_t* positions;
+    uint16_t* kc; uint16_t* vc; int64_t ld_kv, bs_kv;
+};
+
+template <int MR, int MODE, bool PRENORM>
+__global__ __launch_bounds__(NT) void gemv_fused_kernel(GemvFusedArgs a) {
+    constexpr int R = 4;
+    __shared__ float red[NT / 64];
+    __shared__ float rstd_s[MR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * (NT / 64) + wave;          // four weight rows
+    const int K = a.K, M = a.M;
+    int rows[R];
+    bool live = true;
+    if constexpr (MODE == 1) {
+        const int c = unit * 2;
+        live = c < a.I;
+        rows[0] = c; rows[1] = c + 1; rows[2] = a.I + c; rows[3] = a.I + c + 1;
+    } else {
+        const int upd = a.d / 4, nrot = (a.Hq + a.Hkv) * upd;
+        if (unit < nrot) {
+            const int hd = unit / upd, j = (unit % upd) * 2;
+            rows[0] = hd * a.d + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + a.d / 2; rows[3] = rows[2] + 1;
+        } else {
+            const int b0 = (a.Hq + a.Hkv) * a.d + (unit - nrot) * 4;
+            rows[0] = b0; rows[1] = b0 + 1; rows[2] = b0 + 2; rows[3] = b0 + 3;
+        }
+        live = rows[3] < a.N;
+    }
+    const uint16_t* wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = a.W + (int64_t)min(rows[r], a.N - 1) * a.ldw;
+    // first two chunks of the weight stream go out before the norm reduction (its latency hides under them)
+    const int nch = (K + 511) / 512;
+    u32x4 w0[R], w1[R];
+    {
+        const int k = lane * 8;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            w0[r] = (live && k < K) ? *(const u32x4*)(wr[r] + k) : u32x4{0u, 0u, 0u, 0u};
+            w1[r] = (live && k + 512 < K) ? *(const u32x4*)(wr[r] + k + 512) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    if constexpr (PRENORM) {
+        // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order, block_sum<256>
+        const int nv = K >> 3;
+        for (int m = 0; m < M; ++m) {
+            float ss = 0.f;
+            for (int v = threadIdx.x; v < nv; v += NT) {
+                float xv[8];
+                unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + v * 8), xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[e] * xv[e];
+            }
+            ss = block_sum<NT>(ss, red);
+            if (threadIdx.x == 0) rstd_s[m] = rsqrtf(ss / (float)K + a.eps);
+        }
+        __syncthreads();
+    }
+    float acc[MR][R];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+    auto fma_chunk = [&](const u32x4 (&wv)[R], int k) {
+        float xf[MR][8];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < M) {
+                unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + k), xf[m]);
+                if constexpr (PRENORM) {
+                    float nw[8];
+                    unpack8(*(const u32x4*)(a.norm_w + k), nw);
+                    const float rs = rstd_s[m];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xf[m][e] = round_bf(nw[e] * round_bf(xf[m][e] * rs));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[m][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float wf[8];
+            unpack8(wv[r], wf);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
+        }
+    };
+    if (live) {                                              // chunk order and fma order = gemv_kernel<MR, 1>: the same bits
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+            const int k = c * 512 + lane * 8;
+            const bool in1 = k + 512 < K;
+            u32x4 n0[R], n1[R];
+            const int kn = k + 1024;
+            const bool more = c + 2 < nch;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {                    // the next trip's loads before this trip's arithmetic
+                n0[r] = (more && kn < K) ? *(const u32x4*)(wr[r] + kn) : u32x4{0u, 0u, 0u, 0u};
+                n1[r] = (more && kn + 512 < K) ? *(const u32x4*)(wr[r] + kn + 512) : u32x4{0u, 0u, 0u, 0u};
+            }
+            if (k < K) fma_chunk(w0, k);
+            if (in1) fma_chunk(w1, k + 512);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
+        }
+        if (c < nch) {
+            const int k = c * 512 + lane * 8;
+            if (k < K) fma_chunk(w0, k);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
+    if (!live || lane >= M) return;
+    // lane m finishes the unit's outputs of row m
+    float v4[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < MR; ++mm)
+            if (mm == lane) t = acc[mm][r];
+        v4[r] = round_bf(t);                                 // what the unfused GEMV stores
+    }
+    const int m = lane;
+    if constexpr (MODE == 1) {
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) o[e] = round_bf(v4[e] / (1.0f + __expf(-v4[e]))) * v4[2 + e];
+        *(uint32_t*)(a.out + (int64_t)m * a.ld_out + rows[0]) = pack2bf(o[0], o[1]);
+    } else {
+        const int nqk = (a.Hq + a.Hkv) * a.d;
+        const int pos = a.positions[m];
+        if (rows[0] < nqk) {
+            const int hd = rows[0] / a.d, j = rows[0] % a.d;
+            float y1[2], y2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float c = bf2f(a.cos_t[(int64_t)pos * a.d + j + e]), sn = bf2f(a.sin_t[(int64_t)pos * a.d + j + e]);
+                y1[e] = round_bf(v4[e] * c) + round_bf(-v4[2 + e] * sn);
+                y2[e] = round_bf(v4[2 + e] * c) + round_bf(v4[e] * sn);
+            }
+            uint16_t* dst = hd < a.Hq ? a.out + (int64_t)m * a.ld_out + rows[0]
+                                      : a.kc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (int64_t)(hd - a.Hq) * a.d + j;
+            *(uint32_t*)dst = pack2bf(y1[0], y1[1]);
+            *(uint32_t*)(dst + a.d / 2) = pack2bf(y2[0], y2[1]);
+        } else {
+            uint16_t* dst = a.vc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (rows[0] - nqk);
+            *(u32x2*)dst = u32x2{pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ RoPE + cache append
 // One new qkv row per sample: rotate q and k at position positions[b] (HF rounding order, as rope_qk_kernel), leave q in
 // place and write the rotated k and the v row into cache row positions[b].  Positions come from DEVICE memory so that the
@@ -174,7 +352,8 @@ template <int G>
 __global__ __launch_bounds__(NT) void attn_decode_split_kernel(const uint16_t* __restrict__ q, int64_t ld_q, const uint16_t* __restrict__ kc,
                                                                const uint16_t* __restrict__ vc, int64_t ld_kv, int64_t bs_kv,
                                                                const int32_t* __restrict__ kv_lens, float* __restrict__ ws, int nsplit,
-                                                               int Hq, int Hkv, int d, float scale) {
+                                                               int Hq, int Hkv, int d, float scale, uint16_t* __restrict__ o, int64_t ld_o,
+                                                               int* __restrict__ counters) {
     __shared__ float sq[G][128];                             // query rows (fp32, pre-scaled)
     __shared__ float sp[G][CH];                              // probabilities of this chunk
     __shared__ float red[G][NT / 64];
@@ -185,10 +364,10 @@ __global__ __launch_bounds__(NT) void attn_decode_split_kernel(const uint16_t* _
     const int rec = d + 2;
     float* wrec = ws + (((int64_t)b * Hq + hk * G) * nsplit + s) * rec;      // record of q head hk*G + g: + g * nsplit * rec
     const int k0 = s * CH;
+    __shared__ int last_s;
     if (k0 >= kv_len) {                                      // chunk beyond the cache: empty partial
         if (tid < G) { float* w = wrec + (int64_t)tid * nsplit * rec; w[0] = -INFINITY; w[1] = 0.f; }
-        return;
-    }
+    } else {
     for (int i = tid; i < G * d; i += NT) {
         const int g = i / d, c = i % d;
         sq[g][c] = bf2f(q[(int64_t)b * ld_q + (int64_t)(hk * G + g) * d + c]) * scale;
@@ -304,31 +483,244 @@ __global__ __launch_bounds__(NT) void attn_decode_split_kernel(const uint16_t* _
         w[0] = mx[tid];
         w[1] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
     }
+    }
+    // ---- the chunk that arrives last merges the partials of its G query heads (round 4: no second launch).  Device-scope fences on
+    //      both sides of the counter: the other chunks ran on other XCDs (their records sit in other L2s until written back)
+    if (counters == nullptr) return;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = atomicAdd(&counters[b * Hkv + hk], 1);
+        last_s = prev == nsplit - 1;
+        if (last_s) counters[b * Hkv + hk] = 0;              // ready for the next launch (graph replay)
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    for (int i = tid; i < G * d; i += NT) {                   // attn_decode_merge_kernel's arithmetic and order
+        const int g = i / d, c = i % d;
+        const float* w = ws + (((int64_t)b * Hq + hk * G + g) * nsplit) * rec;
+        float Mx = -INFINITY;
+        for (int t = 0; t < nsplit; ++t) Mx = fmaxf(Mx, __builtin_nontemporal_load(w + (int64_t)t * rec));
+        float l = 0.f, acc1 = 0.f;
+        for (int t = 0; t < nsplit; ++t) {
+            const float mm = __builtin_nontemporal_load(w + (int64_t)t * rec);
+            if (mm == -INFINITY) continue;
+            const float f = __expf(mm - Mx);
+            l += f * __builtin_nontemporal_load(w + (int64_t)t * rec + 1);
+            acc1 += f * __builtin_nontemporal_load(w + (int64_t)t * rec + 2 + c);
+        }
+        o[(int64_t)b * ld_o + (int64_t)(hk * G + g) * d + c] = f2bf(l > 0.f ? acc1 / l : 0.f);
+    }
 }
 
-__global__ __launch_bounds__(128) void attn_decode_merge_kernel(const float* __restrict__ ws, uint16_t* __restrict__ o, int64_t ld_o, int nsplit,
-                                                                int Hq, int d) {
-    const int hq = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+// One workgroup of 1024 threads per (sample, KV head, 1024-key group): four sub-blocks of 256 threads take one 256-key chunk each (the
+// arithmetic of attn_decode_split_kernel), their partials meet in LDS, and while the cache holds <= 1024 rows the lone active workgroup
+// writes the output row itself -- no workspace round trip, no device-scope fence, no counter (round 4: 23 -> ~10 us per layer at a
+// 600-row cache).  Longer caches: one record per 1024-key group, merged by the group that arrives last (counters as above).
+template <int G>
+__global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* __restrict__ q, int64_t ld_q, const uint16_t* __restrict__ kc,
+                                                                const uint16_t* __restrict__ vc, int64_t ld_kv, int64_t bs_kv,
+                                                                const int32_t* __restrict__ kv_lens, float* __restrict__ ws, int ngroup,
+                                                                int Hq, int Hkv, int d, float scale, uint16_t* __restrict__ o, int64_t ld_o,
+                                                                int* __restrict__ counters) {
+    constexpr int SB = 4;
+    constexpr int NB = G >= 8 ? 2 : (G >= 4 ? 4 : 8);                       // K / V rows per lane in flight (128 registers per thread at 16 waves per CU)
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float (*sq)[128] = (float (*)[128])lds_f;                                   // [G][128] query rows (fp32, pre-scaled)
+    float (*sp)[G][CH] = (float (*)[G][CH])(lds_f + G * 128);                   // [SB][G][CH] scores, then probabilities
+    float (*redm)[G][4] = (float (*)[G][4])(lds_f + G * 128 + SB * G * CH);     // [SB][G][4] per-wave maxima
+    float (*reds)[G][4] = (float (*)[G][4])(lds_f + G * 128 + SB * G * CH + SB * G * 4);
+    float (*so)[G][128] = (float (*)[G][128])(lds_f + G * 128 + SB * G * CH + 2 * SB * G * 4);   // [SB * 4 waves][G][128]
+    __shared__ int last_s;
+    const int grp = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, sb = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
+    const int kv_len = kv_lens[b];
+    const int ngr_live = (kv_len + SB * CH - 1) / (SB * CH);                    // groups that hold keys
     const int rec = d + 2;
-    const float* w = ws + ((int64_t)b * Hq + hq) * nsplit * rec;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, w[(int64_t)s * rec]);
-    float l = 0.f, acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float m = w[(int64_t)s * rec];
-        if (m == -INFINITY) continue;
-        const float f = __expf(m - M);
-        l += f * w[(int64_t)s * rec + 1];
-        if (c < d) acc += f * w[(int64_t)s * rec + 2 + c];
+    float* wrec = ws + (((int64_t)b * Hq + hk * G) * ngroup + grp) * rec;
+    const int k0 = (grp * SB + sb) * CH;
+    const bool active = k0 < kv_len;                                            // this sub-block's chunk holds keys
+    if (grp * SB * CH < kv_len) {
+        for (int i = tid; i < G * d; i += 1024) {
+            const int g = i / d, c = i % d;
+            sq[g][c] = bf2f(q[(int64_t)b * ld_q + (int64_t)(hk * G + g) * d + c]) * scale;
+        }
+        __syncthreads();
+        // ---- scores (two batches of eight K rows per lane: 128 registers per thread at 16 waves per CU)
+        {
+            const int dc = lane & 15, kq = lane >> 4;
+            float qreg[G][8];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qreg[g][e] = (dc * 8 < d) ? sq[g][dc * 8 + e] : 0.f;
+#pragma unroll 1
+            for (int h = 0; h < 16 / NB; ++h) {
+                u32x4 kraw[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int kk = k0 + wave * 64 + (h * NB + i) * 4 + kq;
+                    kraw[i] = (kk < kv_len && dc * 8 < d) ? *(const u32x4*)(kc + (int64_t)b * bs_kv + (int64_t)kk * ld_kv + (int64_t)hk * d + dc * 8)
+                                                          : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int kl = wave * 64 + (h * NB + i) * 4 + kq;
+                    const int kk = k0 + kl;
+                    float kf[8];
+                    unpack8(kraw[i], kf);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v = fmaf(kf[e], qreg[g][e], v);
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+                        if (dc == 15) sp[sb][g][kl] = (kk < kv_len) ? v : -INFINITY;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int key = k0 + t;
+        float sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            sc[g] = sp[sb][g][t];
+            const float w = wave_max(sc[g]);
+            if (lane == 0) redm[sb][g][wave] = w;
+        }
+        __syncthreads();
+        float mx[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            mx[g] = fmaxf(fmaxf(redm[sb][g][0], redm[sb][g][1]), fmaxf(redm[sb][g][2], redm[sb][g][3]));
+            const float p = (key < kv_len) ? __expf(sc[g] - mx[g]) : 0.f;
+            sp[sb][g][t] = p;                                 // (own slot: read above by this thread only)
+            const float w = wave_sum(p);
+            if (lane == 0) reds[sb][g][wave] = w;
+        }
+        __syncthreads();
+        // ---- o = sum_key p[key] V[key]: thread = (16-B chunk of d, key group of 16), two batches of eight V rows
+        {
+            const int dc = t & 15, kg = t >> 4;
+            float acc[G][8];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+            const int kend = min(CH, kv_len - k0);
+#pragma unroll 1
+            for (int h = 0; h < 16 / NB; ++h) {
+                u32x4 vraw[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int kk = kg + (h * NB + i) * 16;
+                    vraw[i] = (kk < kend && dc * 8 < d) ? *(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)hk * d + dc * 8)
+                                                        : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int kk = kg + (h * NB + i) * 16;
+                    float vf[8];
+                    unpack8(vraw[i], vf);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float p = (kk < kend) ? sp[sb][g][kk] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[g][e];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (lane < 16 && dc * 8 < d) so[sb * 4 + wave][g][dc * 8 + e] = v;
+                }
+        }
+        __syncthreads();
+        // ---- the four chunks of this group -> one (m, l, o[d]) per query head, in a fixed order
+        for (int i = tid; i < G * d; i += 1024) {
+            const int g = i / d, c = i % d;
+            float M4[SB], Mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const bool on = (grp * SB + u) * CH < kv_len;
+                M4[u] = on ? fmaxf(fmaxf(redm[u][g][0], redm[u][g][1]), fmaxf(redm[u][g][2], redm[u][g][3])) : -INFINITY;
+                Mx = fmaxf(Mx, M4[u]);
+            }
+            float l = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                if (M4[u] == -INFINITY) continue;
+                const float f = __expf(M4[u] - Mx);
+                l += f * ((reds[u][g][0] + reds[u][g][1]) + (reds[u][g][2] + reds[u][g][3]));
+                acc1 += f * ((so[u * 4 + 0][g][c] + so[u * 4 + 1][g][c]) + (so[u * 4 + 2][g][c] + so[u * 4 + 3][g][c]));
+            }
+            if (ngr_live == 1) {                              // the whole cache was this group's: done
+                o[(int64_t)b * ld_o + (int64_t)(hk * G + g) * d + c] = f2bf(l > 0.f ? acc1 / l : 0.f);
+            } else {
+                float* w = wrec + (int64_t)g * ngroup * rec;
+                w[2 + c] = acc1;
+                if (c == 0) { w[0] = Mx; w[1] = l; }
+            }
+        }
+    } else if (ngr_live > 1 && tid < G) {                     // group beyond the cache: empty record
+        float* w = wrec + (int64_t)tid * ngroup * rec;
+        w[0] = -INFINITY; w[1] = 0.f;
     }
-    if (c < d) o[(int64_t)b * ld_o + (int64_t)hq * d + c] = f2bf(l > 0.f ? acc / l : 0.f);
+    (void)active;
+    if (ngr_live <= 1) return;                                // (uniform over the grid: kv_len is per sample, read by every group of it)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = atomicAdd(&counters[b * Hkv + hk], 1);
+        last_s = prev == ngroup - 1;
+        if (last_s) counters[b * Hkv + hk] = 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    for (int i = tid; i < G * d; i += 1024) {
+        const int g = i / d, c = i % d;
+        const float* w = ws + (((int64_t)b * Hq + hk * G + g) * ngroup) * rec;
+        float Mx = -INFINITY;
+        for (int u = 0; u < ngroup; ++u) Mx = fmaxf(Mx, __builtin_nontemporal_load(w + (int64_t)u * rec));
+        float l = 0.f, acc1 = 0.f;
+        for (int u = 0; u < ngroup; ++u) {
+            const float mm = __builtin_nontemporal_load(w + (int64_t)u * rec);
+            if (mm == -INFINITY) continue;
+            const float f = __expf(mm - Mx);
+            l += f * __builtin_nontemporal_load(w + (int64_t)u * rec + 1);
+            acc1 += f * __builtin_nontemporal_load(w + (int64_t)u * rec + 2 + c);
+        }
+        o[(int64_t)b * ld_o + (int64_t)(hk * G + g) * d + c] = f2bf(l > 0.f ? acc1 / l : 0.f);
+    }
+}
+
+template <int G>
+int launch_wide(const uint16_t* q, int64_t ld_q, const uint16_t* kc, const uint16_t* vc, int64_t ld_kv, int64_t bs_kv, const int32_t* kv_lens,
+                float* ws, int ngroup, int B, int Hq, int Hkv, int d, float scale, uint16_t* o, int64_t ld_o, int* counters, hipStream_t s) {
+    constexpr int LDS = (G * 128 + 4 * G * CH + 2 * 4 * G * 4 + 16 * G * 128) * 4;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (LDS > 65536 && mm_ensure_dynamic_lds((const void*)attn_decode_wide_kernel<G>, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    hipLaunchKernelGGL(attn_decode_wide_kernel<G>, dim3((unsigned)ngroup, (unsigned)Hkv, (unsigned)B), dim3(1024), LDS, s, q, ld_q, kc, vc, ld_kv,
+                       bs_kv, kv_lens, ws, ngroup, Hq, Hkv, d, scale, o, ld_o, counters);
+    return mm_launch_status();
 }
 
 template <int G>
 int launch_split(const uint16_t* q, int64_t ld_q, const uint16_t* kc, const uint16_t* vc, int64_t ld_kv, int64_t bs_kv, const int32_t* kv_lens,
-                 float* ws, int nsplit, int B, int Hq, int Hkv, int d, float scale, hipStream_t s) {
+                 float* ws, int nsplit, int B, int Hq, int Hkv, int d, float scale, uint16_t* o, int64_t ld_o, int* counters, hipStream_t s) {
     hipLaunchKernelGGL(attn_decode_split_kernel<G>, dim3((unsigned)nsplit, (unsigned)Hkv, (unsigned)B), dim3(NT), 0, s, q, ld_q, kc, vc, ld_kv,
-                       bs_kv, kv_lens, ws, nsplit, Hq, Hkv, d, scale);
+                       bs_kv, kv_lens, ws, nsplit, Hq, Hkv, d, scale, o, ld_o, counters);
     return mm_launch_status();
 }
 
@@ -377,12 +769,13 @@ extern "C" int mm355_rope_kv_append(mm355_bf16* qkv, int64_t ld, int64_t B, int6
 
 extern "C" int64_t mm355_attn_decode_ws_floats(int64_t B, int64_t Hq, int64_t d, int64_t max_kv_len) {
     if (B <= 0 || Hq <= 0 || d <= 0 || max_kv_len <= 0) return 0;
-    return B * Hq * ((max_kv_len + CH - 1) / CH) * (d + 2);
+    const int64_t Hkv_max = Hq;                              // one arrival counter per (sample, KV head); Hkv <= Hq
+    return B * Hq * ((max_kv_len + CH - 1) / CH) * (d + 2) + B * Hkv_max;
 }
 
-extern "C" int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache, int64_t ld_kv,
-                                 int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len, mm355_bf16* o, int64_t ld_o, int64_t B,
-                                 int64_t Hq, int64_t Hkv, int64_t d, float scale, float* workspace, void* stream) {
+static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache, int64_t ld_kv,
+                            int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len, mm355_bf16* o, int64_t ld_o, int64_t B,
+                            int64_t Hq, int64_t Hkv, int64_t d, float scale, float* workspace, int variant, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k_cache || !v_cache || !kv_lens || !o || !workspace || B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || max_kv_len <= 0)
         return MM355_EINVAL;
@@ -390,16 +783,81 @@ extern "C" int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_
     if (B > 65535 || Hkv > 65535) return MM355_EINVAL;
     const int G = (int)(Hq / Hkv);
     const int nsplit = (int)((max_kv_len + CH - 1) / CH);
+    const int ngroup = (nsplit + 3) / 4;                     // 1024-key groups: one workgroup each
     hipStream_t s = (hipStream_t)stream;
+    int* counters = (int*)(workspace + B * Hq * nsplit * (d + 2));   // zero on first use (caller), left zero by every launch
     int rc;
+#define AD(Gv) (variant == 1 ? launch_split<Gv>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, o, ld_o, counters, s) \
+                             : launch_wide<Gv>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, ngroup, (int)B, (int)Hq, (int)Hkv, (int)d, scale, o, ld_o, counters, s))
     switch (G) {
-        case 1: rc = launch_split<1>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, s); break;
-        case 2: rc = launch_split<2>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, s); break;
-        case 4: rc = launch_split<4>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, s); break;
-        case 8: rc = launch_split<8>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, s); break;
+        case 1: rc = AD(1); break;
+        case 2: rc = AD(2); break;
+        case 4: rc = AD(4); break;
+        case 8: rc = AD(8); break;
         default: return MM355_EUNSUPPORTED;                  // GQA group sizes 1, 2, 4, 8
     }
-    if (rc != MM355_OK) return rc;
-    hipLaunchKernelGGL(attn_decode_merge_kernel, dim3((unsigned)Hq, (unsigned)B), dim3(128), 0, s, workspace, o, ld_o, nsplit, (int)Hq, (int)d);
+#undef AD
+    return rc;
+}
+
+extern "C" int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache, int64_t ld_kv,
+                                 int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len, mm355_bf16* o, int64_t ld_o, int64_t B,
+                                 int64_t Hq, int64_t Hkv, int64_t d, float scale, float* workspace, void* stream) {
+    return attn_decode_impl(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, max_kv_len, o, ld_o, B, Hq, Hkv, d, scale, workspace, 0, stream);
+}
+extern "C" int mm355_attn_decode_variant(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache, int64_t ld_kv,
+                                         int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len, mm355_bf16* o, int64_t ld_o, int64_t B,
+                                         int64_t Hq, int64_t Hkv, int64_t d, float scale, float* workspace, int variant, void* stream) {
+    return attn_decode_impl(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, max_kv_len, o, ld_o, B, Hq, Hkv, d, scale, workspace, variant, stream);
+}
+
+namespace {
+template <int MODE>
+int launch_gemv_fused(const GemvFusedArgs& a, int units, bool prenorm, hipStream_t s) {
+    const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
+#define GF2(MR, PN) hipLaunchKernelGGL((gemv_fused_kernel<MR, MODE, PN>), dim3(grid), dim3(NT), 0, s, a)
+#define GF(MR) do { if (prenorm) GF2(MR, true); else GF2(MR, false); } while (0)
+    if (a.M == 1) GF(1);
+    else if (a.M == 2) GF(2);
+    else if (a.M <= 4) GF(4);
+    else GF(8);
+#undef GF
+#undef GF2
     return mm_launch_status();
+}
+}  // namespace
+
+extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* act, int64_t ld_act,
+                                      int64_t M, int64_t I, int64_t K, const mm355_bf16* norm_w, float eps, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !Wgu || !act || M <= 0 || I <= 0 || K <= 0) return MM355_EINVAL;
+    if (M > 8 || (I & 1)) return MM355_EUNSUPPORTED;
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || (ld_act & 1) || !mm_aligned16(x) || !mm_aligned16(Wgu) || (((uintptr_t)act) & 3u)) return MM355_EINVAL;
+    if (norm_w && !mm_aligned16(norm_w)) return MM355_EINVAL;
+    if (I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemvFusedArgs a = {};
+    a.x = x; a.ldx = ldx; a.W = Wgu; a.ldw = ldw; a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
+    a.out = act; a.ld_out = ld_act; a.I = (int)I;
+    return launch_gemv_fused<1>(a, (int)(I / 2), norm_w != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                                           int64_t M, int64_t Hq, int64_t Hkv, int64_t d, int64_t K, const mm355_bf16* norm_w, float eps,
+                                           const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* positions, mm355_bf16* k_cache,
+                                           mm355_bf16* v_cache, int64_t ld_kv, int64_t batch_stride_kv, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !Wqkv || !qkv || !cos_t || !sin_t || !positions || !k_cache || !v_cache || M <= 0 || Hq <= 0 || Hkv <= 0 || d <= 0 || K <= 0)
+        return MM355_EINVAL;
+    if (M > 8 || (d & 3)) return MM355_EUNSUPPORTED;         // rotation partners in pairs: d / 2 even
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || (ld_qkv & 1) || (ld_kv & 3) || (batch_stride_kv & 3) || !mm_aligned16(x) || !mm_aligned16(Wqkv) ||
+        (((uintptr_t)qkv) & 3u) || (((uintptr_t)k_cache) & 7u) || (((uintptr_t)v_cache) & 7u))
+        return MM355_EINVAL;
+    if (norm_w && !mm_aligned16(norm_w)) return MM355_EINVAL;
+    const int64_t N = (Hq + 2 * Hkv) * d;
+    if (N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemvFusedArgs a = {};
+    a.x = x; a.ldx = ldx; a.W = Wqkv; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
+    a.out = qkv; a.ld_out = ld_qkv; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.d = (int)d;
+    a.cos_t = cos_t; a.sin_t = sin_t; a.positions = positions; a.kc = k_cache; a.vc = v_cache; a.ld_kv = ld_kv; a.bs_kv = batch_stride_kv;
+    return launch_gemv_fused<2>(a, (int)(N / 4), norm_w != nullptr, (hipStream_t)stream);
 }

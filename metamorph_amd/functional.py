@@ -27,7 +27,7 @@ BF16 = torch.bfloat16
 #   fuse_rope       RoPE in the q|k|v GEMM's epilogue / inverse RoPE in the attention backward epilogues (same bits)
 #   fuse_swiglu_bwd SwiGLU backward in the down_proj input-gradient GEMM's epilogue (same bits)
 #   decode_graph    the per-token decode step is captured once as a hipGraph and replayed
-VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True, "fuse_rope": True, "fuse_swiglu_bwd": True, "decode_graph": True}
+VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True, "fuse_rope": True, "fuse_swiglu_bwd": True, "decode_graph": True, "decode_fused": True}
 
 
 def set_variant(name, value):
@@ -678,7 +678,7 @@ class KVCache:
         self.len_dev = torch.ones(1, device=device, dtype=torch.int32)        # = pos + 1: rows visible to that token
         self.ws = None
         if Hq is not None:
-            self.ws = torch.empty(int(ops._L().mm355_attn_decode_ws_floats(1, Hq, d, max_len)), device=device, dtype=torch.float32)
+            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(1, Hq, d, max_len)), device=device, dtype=torch.float32)   # arrival counters start at 0
 
     def set_length(self, n):
         self.length = n
@@ -715,6 +715,17 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
         att, mlp = layer.self_attn, layer.mlp
         wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
         wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
+        if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0 and x.shape[0] <= 8:
+            # five launches per layer: RMSNorm folded into the q|k|v and gate|up GEMVs' operand reads, RoPE + cache append and SwiGLU into
+            # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below)
+            qkv = ops.gemv_rope_append(x, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, cache.pos_dev, cache.k[i], cache.v[i],
+                                       norm_w=layer.input_layernorm.weight, eps=meta.eps)
+            o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, cache.max_len, meta.Hq, meta.Hkv, meta.d, meta.scale,
+                                workspace=cache.ws)
+            x2 = ops.gemv(o, att.o_proj.weight, residual=x)
+            act = ops.gemv_swiglu(x2, wgu, meta.I, norm_w=layer.post_attention_layernorm.weight, eps=meta.eps)
+            x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
+            continue
         n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
         qkv = ops.gemv(n1, wqkv)
         ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, cache.pos_dev, cache.k[i], cache.v[i])

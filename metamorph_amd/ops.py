@@ -188,6 +188,33 @@ def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
     return out
 
 
+def gemv_swiglu(x, wgu, I, norm_w=None, eps=0.0, out=None):
+    """act[M, I] = SiLU(g) * u, [g | u] = n . wgu^T, n = RMSNorm(x; norm_w, eps) (norm_w None: n = x); M <= 8 (decode shape)."""
+    _chk_dev(x, wgu, norm_w, out)
+    px, M, K, ldx = _rows2d(x)
+    pw, N, Kw, ldw = _rows2d(wgu)
+    assert K == Kw and N == 2 * I and x.dtype == BF16 and wgu.dtype == BF16
+    out = torch.empty((M, I), device=x.device, dtype=BF16) if out is None else out
+    _lib.check(_L().mm355_gemv_swiglu_bf16(px, ldx, pw, ldw, out.data_ptr(), out.stride(0), M, I, K, _p(norm_w), float(eps), _stream()),
+               "mm355_gemv_swiglu_bf16")
+    return out
+
+
+def gemv_rope_append(x, wqkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache, norm_w=None, eps=0.0, out=None):
+    """The fused q|k|v projection of M <= 8 new rows (optionally of RMSNorm(x)), RoPE at positions[m] (int32, device), rotated k and v
+    straight into cache row positions[m]; returns the row buffer [M, (Hq+2Hkv)*d] whose q columns are valid."""
+    _chk_dev(x, wqkv, norm_w, cos, sin, positions, k_cache, v_cache, out)
+    px, M, K, ldx = _rows2d(x)
+    pw, N, Kw, ldw = _rows2d(wqkv)
+    assert K == Kw and N == (Hq + 2 * Hkv) * d and positions.dtype == torch.int32
+    assert k_cache.stride() == v_cache.stride() and k_cache.stride(2) == 1
+    out = torch.empty((M, N), device=x.device, dtype=BF16) if out is None else out
+    _lib.check(_L().mm355_gemv_rope_append_bf16(px, ldx, pw, ldw, out.data_ptr(), out.stride(0), M, Hq, Hkv, d, K, _p(norm_w), float(eps),
+                                                cos.data_ptr(), sin.data_ptr(), positions.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                                k_cache.stride(1), k_cache.stride(0), _stream()), "mm355_gemv_rope_append_bf16")
+    return out
+
+
 def rope_kv_append_(qkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache):
     """qkv [B, (Hq+2Hkv)*d] new rows: rotate q (in place) and k at positions[b] (int32, device); k, v -> cache row positions[b]."""
     _chk_dev(qkv, cos, sin, positions, k_cache, v_cache)
@@ -199,7 +226,7 @@ def rope_kv_append_(qkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache):
     return qkv
 
 
-def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out=None, workspace=None):
+def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out=None, workspace=None, variant=0):
     """q [B, Hq*d]; caches [B, Lmax, Hkv*d]; kv_lens int32 [B] on the device (valid rows incl. the current one)."""
     _chk_dev(q, k_cache, v_cache, kv_lens)
     B = q.shape[0]
@@ -208,10 +235,10 @@ def attn_decode(q, k_cache, v_cache, kv_lens, max_kv_len, Hq, Hkv, d, scale, out
     out = torch.empty((B, Hq * d), device=q.device, dtype=BF16) if out is None else out
     ws = workspace
     if ws is None:
-        ws = torch.empty(int(_L().mm355_attn_decode_ws_floats(B, Hq, d, max_kv_len)), device=q.device, dtype=torch.float32)
-    _lib.check(_L().mm355_attn_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0),
-                                      kv_lens.data_ptr(), max_kv_len, out.data_ptr(), out.stride(0), B, Hq, Hkv, d, scale, ws.data_ptr(),
-                                      _stream()), "mm355_attn_decode")
+        ws = torch.zeros(int(_L().mm355_attn_decode_ws_floats(B, Hq, d, max_kv_len)), device=q.device, dtype=torch.float32)   # arrival counters start at 0
+    _lib.check(_L().mm355_attn_decode_variant(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0),
+                                              kv_lens.data_ptr(), max_kv_len, out.data_ptr(), out.stride(0), B, Hq, Hkv, d, scale, ws.data_ptr(),
+                                              int(variant), _stream()), "mm355_attn_decode")
     return out
 
 

@@ -855,16 +855,21 @@ def test_gemv_rejects_many_rows(ops):
         ops.gemv(rnd(9, 64, seed=1).to(DEV), rnd(16, 64, seed=2).to(DEV))
 
 
-@pytest.mark.parametrize("case", [(1, 8, 2, 128, [700]), (3, 4, 4, 64, [1, 256, 300]), (2, 32, 4, 128, [513, 77]), (1, 16, 16, 72, [40])])
-def test_attn_decode(ops, case):
-    """Last-row attention against a KV cache == the oracle's attention on the same prefix, last query row."""
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", [(1, 8, 2, 128, [700]), (3, 4, 4, 64, [1, 256, 300]), (2, 32, 4, 128, [513, 77]), (1, 16, 16, 72, [40]),
+                                  (2, 8, 2, 128, [2500, 1030]), (2, 16, 2, 128, [1024, 1025]), (1, 4, 2, 64, [4000])])
+def test_attn_decode(ops, case, variant):
+    """Last-row attention against a KV cache == the oracle's attention on the same prefix, last query row.  Variant 0 (product): one
+    1024-thread workgroup per 1024 cached rows -- caches of <= 1024 rows finish in it, longer ones through one record per group merged
+    by the group that arrives last; variant 1: 256-row chunks + merge by the last (round 3's split, one launch)."""
     B, Hq, Hkv, d, lens = case
     Lmax = max(lens) + 5
     g = torch.Generator().manual_seed(7)
     q = (torch.randn(B, Hq * d, generator=g) * 0.7).bfloat16()
     kc = (torch.randn(B, Lmax, Hkv * d, generator=g) * 0.7).bfloat16()
     vc = (torch.randn(B, Lmax, Hkv * d, generator=g) * 0.7).bfloat16()
-    out = ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), max(lens), Hq, Hkv, d, d ** -0.5)
+    out = ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), max(lens), Hq, Hkv, d, d ** -0.5,
+                          variant=variant)
     for b in range(B):
         n = lens[b]
         qq = q[b].view(Hq, 1, d).float()
@@ -872,6 +877,53 @@ def test_attn_decode(ops, case):
         vv = vc[b, :n].view(n, Hkv, d).transpose(0, 1).float().repeat_interleave(Hq // Hkv, dim=0)
         ref = (torch.softmax(qq @ kk.transpose(1, 2) * d ** -0.5, dim=-1) @ vv).reshape(Hq * d)
         close(out[b], ref, 1e-2, 1e-2, f"attn_decode {case} sample {b}")
+
+
+@pytest.mark.parametrize("M", [1, 3, 8])
+@pytest.mark.parametrize("IK", [(64, 512), (14336, 4096), (1000, 1032)])
+def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
+    """mm355_gemv_swiglu_bf16 (RMSNorm in the operand read, SiLU(g) * u in the epilogue) == rmsnorm_fwd -> gemv -> swiglu_fwd, bit for bit;
+    and without the norm == gemv -> swiglu_fwd."""
+    I, K = IK
+    x, w, nw = rnd(M, K, seed=1).to(DEV), rnd(2 * I, K, seed=2, scale=0.05).to(DEV), (1.0 + 0.1 * rnd(K, seed=3)).bfloat16().to(DEV)
+    ref = ops.swiglu_fwd(ops.gemv(ops.rmsnorm_fwd(x, nw, 1e-5), w), I)
+    assert torch.equal(ops.gemv_swiglu(x, w, I, norm_w=nw, eps=1e-5), ref)
+    assert torch.equal(ops.gemv_swiglu(x, w, I), ops.swiglu_fwd(ops.gemv(x, w), I))
+
+
+@pytest.mark.parametrize("geo", [(1, 8, 2, 128, 512), (3, 4, 4, 64, 1032), (2, 32, 8, 128, 4096), (8, 2, 1, 80, 256)])
+def test_gemv_rope_append_fused_equals_the_launch_sequence(ops, geo):
+    """mm355_gemv_rope_append_bf16 == rmsnorm_fwd -> gemv -> rope_kv_append: the q columns of the row buffer and the cache rows written
+    (and ONLY those cache rows) carry the same bits; positions differ per sample and come from device memory."""
+    B, Hq, Hkv, d, K = geo
+    N, Lmax = (Hq + 2 * Hkv) * d, 40
+    x, w, nw = rnd(B, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=0.05).to(DEV), (1.0 + 0.1 * rnd(K, seed=3)).bfloat16().to(DEV)
+    cos, sin = ops.rope_table(Lmax, d, 10000.0, DEV)
+    pos = torch.tensor([(7 * b + 3) % Lmax for b in range(B)], dtype=torch.int32, device=DEV)
+    base_k, base_v = rnd(B, Lmax, Hkv * d, seed=4).to(DEV), rnd(B, Lmax, Hkv * d, seed=5).to(DEV)
+    for norm in (True, False):
+        k0, v0, k1, v1 = base_k.clone(), base_v.clone(), base_k.clone(), base_v.clone()
+        qkv = ops.gemv(ops.rmsnorm_fwd(x, nw, 1e-5) if norm else x, w)
+        ops.rope_kv_append_(qkv, Hq, Hkv, d, cos, sin, pos, k0, v0)
+        got = ops.gemv_rope_append(x, w, Hq, Hkv, d, cos, sin, pos, k1, v1, norm_w=nw if norm else None, eps=1e-5)
+        assert torch.equal(got[:, :Hq * d], qkv[:, :Hq * d]), "q rows"
+        assert torch.equal(k1, k0) and torch.equal(v1, v0), "cache rows"
+
+
+@pytest.mark.parametrize("variant,lens", [(0, [2700, 300]), (0, [700, 300]), (1, [700, 300])])
+def test_attn_decode_counters_return_to_zero_and_replay(ops, variant, lens):
+    """The chunk that arrives last merges and re-arms its counter: the same workspace serves launch after launch (hipGraph replay)."""
+    B, Hq, Hkv, d = 2, 32, 8, 128
+    g = torch.Generator().manual_seed(9)
+    q = (torch.randn(B, Hq * d, generator=g) * 0.7).bfloat16().to(DEV)
+    kc = (torch.randn(B, 3072, Hkv * d, generator=g) * 0.7).bfloat16().to(DEV)
+    vc = (torch.randn(B, 3072, Hkv * d, generator=g) * 0.7).bfloat16().to(DEV)
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(B, Hq, d, 3072)), device=DEV, dtype=torch.float32)
+    first = ops.attn_decode(q, kc, vc, kv, 3072, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant).clone()
+    for _ in range(5):
+        assert torch.equal(ops.attn_decode(q, kc, vc, kv, 3072, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant), first)
+    assert int(ws[-B * Hq:].view(torch.int32).abs().max()) == 0
 
 
 # ------------------------------------------------------------------------------------------------ vision

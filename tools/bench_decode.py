@@ -12,7 +12,7 @@ model = build_model(dict(LLAMA3_8B, num_hidden_layers=layers), dict(num_hidden_l
 h = 4096
 L0, new = int(os.environ.get("PROMPT", 512)), int(os.environ.get("NEW", 64))
 emb = (torch.randn(1, L0, h, device=dev) * 0.02).bfloat16()
-for use_cache in (True, False):
+for use_cache in ((True,) if os.environ.get("CACHED_ONLY") else (True, False)):
     n = new if use_cache else min(new, 8)
     model.greedy_decode(None, None, emb, max_new_tokens=2, use_cache=use_cache, eos_token_id=())
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -21,3 +21,9 @@ for use_cache in (True, False):
     wbytes = sum(p.numel() for n_, p in model.named_parameters() if "vision_tower" not in n_ and "embed_tokens" not in n_) * 2
     print(f"use_cache={use_cache}: {out.numel()} tokens in {dt*1e3:.1f} ms = {dt/out.numel()*1e3:.2f} ms/token"
           f" (prompt {L0}; weights {wbytes/1e9:.1f} GB -> {wbytes*out.numel()/dt/1e12:.2f} TB/s if streamed once per token)", flush=True)
+    if use_cache:                                             # the per-token step alone: the difference of two run lengths (prompt pass cancels)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out2 = model.greedy_decode(None, None, emb, max_new_tokens=2 * n, use_cache=True, eos_token_id=())[0]
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+        per = (dt2 - dt) / max(out2.numel() - out.numel(), 1)
+        print(f"   decode step alone: {per*1e3:.3f} ms/token = {wbytes/per/1e12:.2f} TB/s of weights; prompt pass + first token ~ {(dt - per*out.numel())*1e3:.1f} ms", flush=True)
