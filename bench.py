@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--vit-layers", type=int, default=27)
     ap.add_argument("--zero", type=int, default=2, choices=(2, 3), help="3: decoder-layer parameters sharded (Zero3AdamW, BASELINE configs[4] machinery); NOT the headline config")
     ap.add_argument("--grad-checkpointing", action="store_true", help="per-layer recompute (reference --gradient_checkpointing True); NOT the headline config")
+    ap.add_argument("--ckpt-layers", default="all", help="with --grad-checkpointing: 'all' (the reference's behaviour), an integer n (only the first n "
+                    "decoder layers recompute, the others keep their activations), or 'auto' (the fewest layers that fit this GPU's HBM)")
     ap.add_argument("--host-inputs", action="store_true", help="ids / labels / mask / fp32 pixels start every step in pinned HOST memory (PCIe-inclusive "
                     "rate for DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
     ap.add_argument("--zero2-async", type=int, default=None, choices=(0, 1), help="1: AdamW shard update + parameter all-gather per segment on a side "
@@ -490,8 +492,29 @@ def main():
     if args.train_vision:
         vis = {id(p) for p in model.get_model().vision_tower.parameters()}
         params = [dict(params=[p for p in params if id(p) not in vis], lr=2e-5), dict(params=[p for p in params if id(p) in vis], lr=2e-6)]
+    ckpt_layers = None
     if args.grad_checkpointing:
         model.gradient_checkpointing_enable()
+        if args.ckpt_layers != "all":
+            nl_ = len(model.get_model().layers)
+            if args.ckpt_layers == "auto":
+                # what a decoder layer keeps for its backward when it is NOT recomputed: layer input, post-RoPE qkv, attention output,
+                # post-attention residual, gate|up (bf16 rows) + lse / rstd (fp32): DESIGN.md section 5; fixed state = parameters,
+                # bf16 gradients, fp32 Adam moments (+ the frozen tower) plus the step's transients (logits rows, backward buffers)
+                cfg_ = model.config
+                rows_ = args.batch * args.seq
+                hd_ = cfg_.hidden_size // cfg_.num_attention_heads
+                per_layer = rows_ * 2 * (3 * cfg_.hidden_size + (cfg_.num_attention_heads + 2 * cfg_.num_key_value_heads) * hd_
+                                         + 2 * cfg_.intermediate_size) + rows_ * 4 * (cfg_.num_attention_heads + 2)
+                fixed = 12 * n_params / max(world, 1) * (1 if args.zero else world) + 2 * n_params + 2.0e9
+                transient = rows_ * 2 * (6 * cfg_.intermediate_size + 8 * cfg_.hidden_size) + 8.0e9
+                total_mem = torch.cuda.get_device_properties(dev).total_memory
+                room = 0.90 * total_mem - fixed - transient - nl_ * rows_ * 2 * cfg_.hidden_size
+                keep = max(0, min(nl_, int(room // (per_layer - rows_ * 2 * cfg_.hidden_size))))
+                ckpt_layers = nl_ - keep
+            else:
+                ckpt_layers = max(0, min(nl_, int(args.ckpt_layers)))
+            model.get_model().checkpoint_layers = ckpt_layers
     if args.zero == 3:
         from metamorph_amd.zero3 import Zero3AdamW
         opt = Zero3AdamW(params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0).enable_hooks()
@@ -657,7 +680,7 @@ def main():
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
-                       "parallelism": f"dp{world} zero{args.zero}" + (" +recompute" if args.grad_checkpointing else "") + (
+                       "parallelism": f"dp{world} zero{args.zero}" + ((" +recompute" + ("" if ckpt_layers is None else f"(first {ckpt_layers} layers)")) if args.grad_checkpointing else "") + (
                            " +async-update" if getattr(opt, "async_update", False) else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
             "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "batch_pool": n_pool, "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),
             "mfu_vs_bf16_mfma_peak": round(mfu, 4), "build_seconds": round(t_build, 1),

@@ -733,6 +733,14 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     const int fr = lane & 15, fq = lane >> 4;
     const int M = a.M, N = a.N;
     const int nk = a.K >> 6;                                 // host guarantees K % 128 == 0, K >= 128
+#ifdef MM355_SWB_STAGGER                                     // experiment: the first wave of workgroups starts in MM355_SWB_PHASES phases
+    if constexpr (SWB) {
+        if (bid < 256) {
+            const int ph = (bid >> 3) % MM355_SWB_PHASES;
+            for (int i = 0; i < ph * MM355_SWB_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
 
     f32x4 acc[FM][FN];
 #pragma unroll

@@ -18,6 +18,7 @@ HIP) instead of transformers' LlamaModel + torch ops:
 from __future__ import annotations
 
 
+import copy
 import numpy as np
 import torch
 import torch.nn as nn
@@ -172,6 +173,10 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         # set by PreTrainedModel.gradient_checkpointing_enable() (HF looks for this attribute on the sub-modules): per-layer
         # recompute in DecoderLayerFn / SiglipLayerFn instead of torch.utils.checkpoint
         self.gradient_checkpointing = False
+        # MI355X extension of the checkpointing mode (288 GB of HBM rarely needs every layer recomputed): None = every decoder layer
+        # (the reference's behaviour), n = only the first n decoder layers keep just their input; the rest keep their activations.
+        # Recompute runs the same kernels on the same inputs, so gradients carry the same bits for any n (tests/test_trainer_gpu.py).
+        self.checkpoint_layers = None
         # optional fn(layer_index, rows [B*L, h]) called with every decoder layer's output (what the reference's forced
         # `output_hidden_states=True`, metamorph_llama.py:345, would collect); rows of a left-padded batch are in the moved
         # (right-padded) layout.  Used by the full-depth parity test; None costs nothing.
@@ -369,8 +374,13 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         if shift:
             x = F.RowsPermuteFn.apply(x, to_right_d, to_left_d)
         tap = self.model.layer_output_hook
+        n_ck = self.model.checkpoint_layers
+        meta_keep = meta
+        if meta.recompute and n_ck is not None:
+            meta_keep = copy.copy(meta)
+            meta_keep.recompute = False
         for li, layer in enumerate(self.model.layers):
-            x = F.decoder_layer(x, layer, meta)
+            x = F.decoder_layer(x, layer, meta if (n_ck is None or li < int(n_ck)) else meta_keep)
             if tap is not None:                                         # the reference's output_hidden_states tuple, one entry at a time
                 tap(li, x)
         if shift:

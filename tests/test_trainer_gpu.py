@@ -143,7 +143,7 @@ def test_gradient_checkpointing_recompute_is_bit_identical():
     batch = dict(input_ids=T(g["input_ids"]).to(DEV), attention_mask=T(g["attention_mask"]).to(DEV), labels=T(g["labels"]).to(DEV),
                  images=T(g["images"]).to(DEV).bfloat16())
     grads = []
-    for ckpt in (False, True):
+    for ckpt in (False, True, 1):                                  # no recompute / every layer (the reference's mode) / the first decoder layer only
         model = hip_model(cfg, init_state_dict(cfg, seed=int(g["seed"]), dtype=torch.bfloat16))
         model.train()
         tower = model.get_model().vision_tower                     # the trainable-tower layers recompute as well
@@ -152,6 +152,8 @@ def test_gradient_checkpointing_recompute_is_bit_identical():
             p.requires_grad_("post_layernorm" not in n)
         if ckpt:
             model.gradient_checkpointing_enable()
+            if ckpt is not True:                                   # MI355X extension: only the first n decoder layers keep just their input
+                model.get_model().checkpoint_layers = int(ckpt)
         torch.cuda.reset_peak_memory_stats()
         out = model(**batch)
         out.loss.backward()
@@ -160,6 +162,7 @@ def test_gradient_checkpointing_recompute_is_bit_identical():
     assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 40
     for n in grads[0][1]:
         assert torch.equal(grads[0][1][n], grads[1][1][n]), n
+        assert torch.equal(grads[0][1][n], grads[2][1][n]), n
     # eval / no_grad never recomputes and a disabled flag restores the saved-activation path
     model.gradient_checkpointing_disable()
     assert not model.model.gradient_checkpointing
