@@ -745,7 +745,7 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
 class DecodeStepGraph:
     """decoder_decode_row captured ONCE as a hipGraph (~13 launches x layers per token collapse into one graph launch; the
     per-token step is launch-bound otherwise) and replayed per token: copy the new row into `x_in`, replay, read `x_out`.
-    Falls back to eager launches if capture is not possible (MM355_DECODE_GRAPH=0 forces that)."""
+    Falls back to eager launches if capture is not possible (functional.set_variant("decode_graph", False) forces that)."""
 
     def __init__(self, layers, meta, cache, cos, sin, h, device):
         self.args = (layers, meta, cache, cos, sin)
