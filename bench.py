@@ -379,12 +379,15 @@ def rccl_summary(path, opt, steps, world):
         text = open(path, errors="replace").read()
     except OSError:
         return out
-    m = re.search(r"(?:NCCL|RCCL) version ([^\n]+)", text)
+    m = re.search(r"(?:NCCL|RCCL)[^\n]*?version[ :=]*([^\n]+)", text, flags=re.I)
     if m:
-        out["version"] = m.group(1).strip()
-    ch = re.findall(r"(\d+) coll channels", text)
+        out["version"] = m.group(1).strip()[:120]
+    ch = re.findall(r"(\d+) coll channels", text) or re.findall(r"[Cc]hannels?[ =:]+(\d+)", text)
     if ch:
         out["coll_channels"] = int(ch[-1])
+    # whatever the parse finds, the record carries the head of RCCL's own log (INIT lines: version, topology, channels, transports)
+    out["log_lines"] = len(text.splitlines())
+    out["log_head"] = [ln.strip()[:160] for ln in text.splitlines() if "NCCL INFO" in ln or "RCCL" in ln][:14]
     algo = {}
     for line in text.splitlines():                           # TUNING / COLL lines: "ReduceScatter: ... Algo RING proto SIMPLE ... nchannels N"
         m = re.search(r"(AllReduce|ReduceScatter|AllGather)[^\n]*?[Aa]lgo(?:rithm)? (\w+)[^\n]*?proto(?:col)? (\w+)(?:[^\n]*?(?:channels|nchannels|nChannels)[ =:{]*(\d+))?", line)

@@ -384,7 +384,7 @@ def test_paired_weight_gradient_launch_matches_separate_launches(monkeypatch):
     def grads(paired):
         calls = []
         orig = F.ops.gemm_pair
-        monkeypatch.setattr(F, "_DW_PAIR", paired)
+        monkeypatch.setitem(F.VARIANTS, "dw_pair", paired)
         monkeypatch.setattr(F, "_pair_saves_a_wave", lambda r0, c0, r1, c1, k: ((k + 7) // 8 * 8) % 128 == 0)
         monkeypatch.setattr(F.ops, "gemm_pair", lambda *a: (calls.append(1), orig(*a))[1])
         model = hip_model(cfg, sd)
@@ -568,7 +568,8 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
     LEFT-padded, with their attention mask -- on the device through the HIP kernels (round 3 ran this path only with the compute hooks
     replaced by the oracle on the CPU).  Every row must emit what the reference recorded for the batch (hfgen_text.npz; each row
     generates what it generates alone), the padding rows are never cached, the short prompt alone walks through the same per-step
-    arithmetic (bit-identical scores: one `_SeqState` per row, same kernels on the same data), right padding is refused."""
+    arithmetic (bit-identical scores from the first decoded token on: one `_SeqState` per row, same kernels on the same data), right
+    padding is refused."""
     from oracle.ref_model import decode_fixture_state_dict
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
     g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
@@ -586,8 +587,13 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
     assert [s_.pad for s_ in st] == [0, n_pad] and st[0].kv.length == st[1].kv.length + n_pad      # pad rows were never computed or cached
     alone = model.generate(inputs=ids[1:, n_pad:], output_scores=True, **kw)
     assert alone.sequences[0].tolist() == out.sequences[1].tolist()
-    for a, b in zip(alone.scores, out.scores):
-        assert torch.equal(a[0], b[1])
+    for step, (a, b) in enumerate(zip(alone.scores, out.scores)):
+        if step == 0:
+            # the prompt pass sends the batch's 2 x n rows through the MFMA GEMM of lm_head and the lone short prompt's <= 8 rows through the
+            # GEMV (ops dispatch on the row count): same products, different fp32 summation order
+            assert torch.allclose(a[0], b[1], rtol=1e-4, atol=2e-3), float((a[0] - b[1]).abs().max())
+        else:
+            assert torch.equal(a[0], b[1]), step
     with pytest.raises(NotImplementedError):                      # right padding would put pad rows between the prompt and the generated tokens
         model.generate(inputs=ids.flip(1), attention_mask=mask.flip(1), use_customize_greedy=False, do_sample=False, max_new_tokens=2,
                        eos_token_id=128009, pad_token_id=128001)
