@@ -27,7 +27,11 @@ BF16 = torch.bfloat16
 #   fuse_rope       RoPE in the q|k|v GEMM's epilogue / inverse RoPE in the attention backward epilogues (same bits)
 #   fuse_swiglu_bwd SwiGLU backward in the down_proj input-gradient GEMM's epilogue (same bits)
 #   decode_graph    the per-token decode step is captured once as a hipGraph and replayed
-VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True, "fuse_rope": True, "fuse_swiglu_bwd": True, "decode_graph": True, "decode_fused": True}
+VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True, "fuse_rope": True, "fuse_swiglu_bwd": True, "decode_graph": True, "decode_fused": True,
+            # keep the transposed copies of the decoder weights (the B operands of the input-gradient GEMMs) from one backward call to
+            # the next until the optimizer rewrites the parameters: under gradient accumulation the four transposes per layer are made
+            # once per optimizer step instead of once per micro-batch (+2 bytes per decoder parameter while a window is open)
+            "wt_cache": False}
 
 
 def set_variant(name, value):
@@ -236,11 +240,35 @@ def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
     return -(-(t0 + t1) // _CUS) < -(-t0 // _CUS) + -(-t1 // _CUS)
 
 
+_WT_CACHE = {}                                               # (data_ptr, shape) -> (parameter generation, transposed copy)
+
+
+def transposed_weight(w):
+    """w [N, K] -> [K, Np] (transpose_padded).  With VARIANTS["wt_cache"] the copy is kept until the parameters change
+    (`bump_param_generation`, called by every optimizer step / checkpoint load): same bits, one transpose per optimizer step."""
+    if not VARIANTS["wt_cache"]:
+        return transpose_padded(w)
+    key = (w.data_ptr(), tuple(w.shape))
+    gen = param_generation()
+    hit = _WT_CACHE.get(key)
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    if _WT_CACHE and next(iter(_WT_CACHE.values()))[0] != gen:
+        _WT_CACHE.clear()                                     # a new generation: every cached copy is stale
+    wt = transpose_padded(w)
+    _WT_CACHE[key] = (gen, wt)
+    return wt
+
+
+def drop_transposed_weights():
+    _WT_CACHE.clear()
+
+
 def input_grad_gemm(dy2d, w, out=None, residual=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual); the weight is read untransposed whenever the ping-pong kernel applies"""
     if VARIANTS["dw_tn"] and ops.gemm_nn_supported(dy2d, w):
         return ops.gemm_nn(dy2d, w, out=out, residual=residual)
-    return ops.gemm(dy2d, transpose_padded(w), out=out, residual=residual)
+    return ops.gemm(dy2d, transposed_weight(w), out=out, residual=residual)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -334,7 +362,7 @@ class DecoderLayerFn(Function):
                    and all(p.requires_grad for p in gu_params))
         wdT = None
         if fused_t and VARIANTS["fuse_swiglu_bwd"]:
-            wdT = transpose_padded(mlp.down_proj.weight)
+            wdT = transposed_weight(mlp.down_proj.weight)
             if not ops.gemm_swiglu_bwd_supported(dy, wdT, gu, m.I):
                 wdT = None
         if wdT is not None:

@@ -28,6 +28,7 @@ import torch
 from transformers import Trainer
 
 from .checkpoint import consolidate_optimizer_state, load_consolidated_optimizer_state, save_trainer_adapter_checkpoint
+from . import functional as F
 from .zero2 import Zero2AdamW, tag_segments
 from .zero3 import Zero3AdamW
 
@@ -110,7 +111,18 @@ class MetaMorphTrainer(Trainer):
         self.optimizer = cls(groups, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
                              weight_decay=a.weight_decay, max_grad_norm=max_norm or 0.0, **self._zero2_kwargs)
         self.optimizer.enable_overlap()
+        # gradient accumulation: the transposed weight copies of the input-gradient GEMMs live until the optimizer rewrites the parameters
+        # (functional.transposed_weight: keyed on the parameter generation Zero2AdamW bumps).  Not under ZeRO-3: its gathered layers share
+        # rotating slots, i.e. one address holds different layers within a step.
+        F.set_variant("wt_cache", a.gradient_accumulation_steps > 1 and self._zero_stage != 3)
         return self.optimizer
+
+    def train(self, *args, **kwargs):
+        try:
+            return super().train(*args, **kwargs)
+        finally:                                                     # the transposed-weight copies belong to this run's optimizer steps
+            F.set_variant("wt_cache", False)
+            F.drop_transposed_weights()
 
     def _zero2(self):
         opt = self.optimizer

@@ -402,6 +402,52 @@ def test_paired_weight_gradient_launch_matches_separate_launches(monkeypatch):
         assert rel(got[n], ref[n]) < 2e-3, (n, rel(got[n], ref[n]))
 
 
+def test_transposed_weight_cache_under_accumulation(monkeypatch):
+    """functional.transposed_weight with the cache on (the Trainer turns it on when gradient_accumulation_steps > 1): the second
+    micro-batch's backward re-uses the transposed decoder weights of the first (4 transposes per layer less), gradients carry the same
+    bits as without the cache, and a parameter-generation bump (what every optimizer step does) refreshes the copies."""
+    import metamorph_amd.functional as F
+    cfg = tiny_cfg(num_image_tokens=4)
+    sd = init_state_dict(cfg, seed=11, dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 127000, (2, 64), generator=gen).to(DEV)
+    args = dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+
+    def run(cache):
+        monkeypatch.setitem(F.VARIANTS, "wt_cache", cache)
+        F.drop_transposed_weights()
+        calls = []
+        orig = F.ops.transpose
+        monkeypatch.setattr(F.ops, "transpose", lambda x, **kw: (calls.append(tuple(x.shape)), orig(x, **kw))[1])
+        model = hip_model(cfg, sd)
+        model.train()
+        per_pass = []
+        for _ in range(2):                                   # two micro-batches of one accumulation window
+            n0 = len(calls)
+            model(**args).loss.backward()
+            per_pass.append(len(calls) - n0)
+        g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        with torch.no_grad():                                # "optimizer step": parameters change, the generation moves
+            for p in model.model.layers.parameters():
+                p.mul_(0.5)
+        F.bump_param_generation()
+        model.zero_grad(set_to_none=True)
+        model(**args).loss.backward()
+        g2 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        monkeypatch.setattr(F.ops, "transpose", orig)
+        return per_pass, g1, g2
+
+    p_off, a1, a2 = run(False)
+    p_on, b1, b2 = run(True)
+    F.drop_transposed_weights()
+    print(f"\n   transposes per backward call: cache off {p_off}, cache on {p_on}")
+    assert p_off[0] == p_off[1] and p_on[0] <= p_off[0], (p_on, p_off)
+    assert p_on[1] <= p_off[1] - 4 * cfg.num_hidden_layers, (p_on, p_off)     # down, gate|up, o, q|k|v per layer re-used
+    for n in a1:
+        assert torch.equal(a1[n], b1[n]), n
+        assert torch.equal(a2[n], b2[n]), n                  # stale copies would show here
+
+
 def test_stage1_freeze_policy():
     """Only mm_projector (+ embed_tokens) trainable, as in the reference's stage 1 (train.py:1515-1519)."""
     g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
