@@ -379,7 +379,7 @@ def rccl_summary(path, opt, steps, world):
         text = open(path, errors="replace").read()
     except OSError:
         return out
-    m = re.search(r"(?:NCCL|RCCL)[^\n]*?version[ :=]*([^\n]+)", text, flags=re.I)
+    m = re.search(r"RCCL version\s*:?\s*([^\n]+)", text) or re.search(r"NCCL version\s*:?\s*([^\n]+)", text)
     if m:
         out["version"] = m.group(1).strip()[:120]
     ch = re.findall(r"(\d+) coll channels", text) or re.findall(r"[Cc]hannels?[ =:]+(\d+)", text)
@@ -387,7 +387,8 @@ def rccl_summary(path, opt, steps, world):
         out["coll_channels"] = int(ch[-1])
     # whatever the parse finds, the record carries the head of RCCL's own log (INIT lines: version, topology, channels, transports)
     out["log_lines"] = len(text.splitlines())
-    out["log_head"] = [ln.strip()[:160] for ln in text.splitlines() if "NCCL INFO" in ln or "RCCL" in ln][:14]
+    keep = re.compile(r"RCCL version|coll channels|nranks|Channel \d+[/ ]|[Rr]ing|[Tt]ree|via |Algo|algo|proto|XGMI|xgmi|P2P|nchannels|nChannels")
+    out["log_head"] = [ln.strip()[:160] for ln in text.splitlines() if "NCCL INFO" in ln and keep.search(ln)][:20]
     algo = {}
     for line in text.splitlines():                           # TUNING / COLL lines: "ReduceScatter: ... Algo RING proto SIMPLE ... nchannels N"
         m = re.search(r"(AllReduce|ReduceScatter|AllGather)[^\n]*?[Aa]lgo(?:rithm)? (\w+)[^\n]*?proto(?:col)? (\w+)(?:[^\n]*?(?:channels|nchannels|nChannels)[ =:{]*(\d+))?", line)
@@ -460,7 +461,8 @@ def main():
         # RCCL's own account of what it chose (algorithm / protocol / channels per collective): NCCL_DEBUG=INFO into a per-rank file,
         # rank 0's is summarised into the JSON line (the driver's 8-GPU run cannot be observed otherwise)
         rccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mm355_bench_rccl_{os.getpid()}_{rank}.log")
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):   # (the GPU boxes export NCCL_DEBUG=VERSION)
+            os.environ["NCCL_DEBUG"] = "INFO"
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
         os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         # stdout carries exactly ONE line (the JSON record): RCCL prints its NCCL_DEBUG=VERSION banner with printf when the

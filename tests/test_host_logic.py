@@ -722,3 +722,40 @@ def test_preprocess_llama3_matches_reference_on_random_conversations():
     assert masked == 91
 
 
+
+
+def test_bench_rccl_log_summary_and_bus_bandwidth(tmp_path):
+    """bench.py at N > 1 summarises RCCL's own NCCL_DEBUG=INFO log into the JSON line (the driver's 8-GPU run cannot be observed
+    otherwise): version, channel count, algorithm / protocol per collective, transports, the head of the log; bus bandwidth =
+    bytes (world - 1) / world / exposed time.  Pure host logic: exercised here on a synthetic log in RCCL's format."""
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "host:123:123 [0] NCCL INFO Kernel version: 6.18.51-ant.1",
+        "host:123:123 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6",
+        "host:123:140 [0] NCCL INFO comm 0x1 rank 0 nranks 8 cudaDev 0 busId 1000 - Init START",
+        "host:123:140 [0] NCCL INFO Channel 00/32 : 0 1 2 3 4 5 6 7",
+        "host:123:140 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC",
+        "host:123:140 [0] NCCL INFO 32 coll channels, 32 collnet channels, 0 nvls channels, 32 p2p channels, 2 p2p channels per peer",
+        "host:123:150 [0] NCCL INFO ReduceScatter: opCount 5 sendbuff 0x1 recvbuff 0x2 count 27262976 datatype 9 op 0 root 0 comm 0x1 [nranks=8] stream 0x3",
+        "host:123:150 [0] NCCL INFO ReduceScatter: 218103808 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}",
+        "host:123:151 [0] NCCL INFO AllGather: 218103808 Bytes -> Algo RING proto LL128 nchannels 16",
+        "host:123:151 [0] NCCL INFO AllGather: 218103808 Bytes -> Algo RING proto LL128 nchannels 16",
+    ]) + "\n")
+
+    class Opt:
+        def comm_bytes_per_step(self):
+            return {"reduce_scatter_bytes": 16_000_000_000, "all_gather_bytes": 16_000_000_000}
+
+    out = bench.rccl_summary(str(log), Opt(), steps=4, world=8)
+    assert out["version"] == "2.26.6-HEAD:64f48b6" and out["coll_channels"] == 32 and out["log_lines"] == 10 and 6 <= len(out["log_head"]) <= 9 and not any("Kernel version" in ln for ln in out["log_head"])
+    seen = out["collectives_seen"]
+    assert seen.get("AllGather: algo RING proto LL128 channels 16") == 2 and any(k.startswith("ReduceScatter: algo RING proto SIMPLE") for k in seen)
+    assert out["transport_lines"]["p2p_or_xgmi"] >= 1 and out["bytes_per_step"]["all_gather_bytes"] == 16_000_000_000
+    bw = bench.bus_bandwidth(out, {"all_gather": 50.0, "reduce_scatter_exposed": 40.0}, world=8, overlap=False)
+    assert bw == {"all_gather_gb_s": 280.0, "reduce_scatter_gb_s": 350.0}
+    assert bench.bus_bandwidth(out, {"all_gather": 50.0, "reduce_scatter_exposed": 4.0}, world=8, overlap=True) == {"all_gather_gb_s": 280.0}
+    assert bench.bus_bandwidth(out, {"all_gather": 50.0}, world=1, overlap=False) is None
+    assert bench.rccl_summary(str(tmp_path / "missing.log"), Opt(), 1, 8) == {"log": str(tmp_path / "missing.log")}
