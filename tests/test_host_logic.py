@@ -759,3 +759,40 @@ def test_bench_rccl_log_summary_and_bus_bandwidth(tmp_path):
     assert bench.bus_bandwidth(out, {"all_gather": 50.0, "reduce_scatter_exposed": 4.0}, world=8, overlap=True) == {"all_gather_gb_s": 280.0}
     assert bench.bus_bandwidth(out, {"all_gather": 50.0}, world=1, overlap=False) is None
     assert bench.rccl_summary(str(tmp_path / "missing.log"), Opt(), 1, 8) == {"log": str(tmp_path / "missing.log")}
+
+
+@pytest.mark.parametrize("gen,sub", [("gen_attn4", "attn4_gen"), ("gen_attn4_bwd", "attn4_bwd_gen"), ("gen_gemm_st", "gemm_st_gen")])
+def test_committed_instruction_streams_are_what_the_generators_emit(tmp_path, monkeypatch, gen, sub):
+    """The hand-placed streams (csrc/*_gen/*.inc: one asm statement per instruction) are build inputs generated by tools/gen_*.py; the
+    committed files must be exactly what the committed generators emit -- no hand edits, no stale files."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location(gen, os.path.join(REPO, "tools", gen + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / sub)
+    monkeypatch.setattr(sys, "argv", [gen + ".py"])
+    if gen == "gen_gemm_st":
+        mod.emit(out, rd1=8, b1=32, b2=40, dma_every=5, stagger=False)
+    else:
+        monkeypatch.setattr(mod, "OUT", out)
+        mod.main()
+    committed = os.path.join(REPO, "metamorph_amd", "csrc", sub)
+    new, old = sorted(os.listdir(out)), sorted(f for f in os.listdir(committed) if f.endswith(".inc"))
+    assert new == old, (set(new) ^ set(old))
+    for f in new:
+        assert open(os.path.join(out, f)).read() == open(os.path.join(committed, f)).read(), f
+
+
+def test_compiler_stays_out_of_the_streams_registers():
+    """tools/audit_attn4.py on the code objects of csrc/attn4.hip, attn4_bwd.hip and gemm_st.hip (compiled here with the build's flags):
+    outside the asm statements no instruction may name a VGPR at or above the kernel's amdgpu_num_vgpr limit or any AGPR, and there is no
+    scratch traffic and no VGPR spill -- a compiler copy into a register the hand-placed stream owns would be silent corruption."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_attn4", os.path.join(REPO, "tools", "audit_attn4.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in ("attn4", "attn4_bwd", "gemm_st"):
+        bad, stats = mod.audit(mod.compile_s(name))
+        assert stats and all(v["mfma"] >= 64 and v["asm_lines"] > v["mfma"] for v in stats.values()), (name, stats)
+        assert not bad, (name, bad[:5])

@@ -80,4 +80,4 @@ if __name__ == "__main__":
                 print("  line %d: %s" % (ln, t))
     if failed:
         sys.exit(1)
-    print("audit ok: hipcc stays inside v[0:63], no scratch, no VGPR spills")
+    print("audit ok: hipcc stays inside its registers (v[0:63] / v[0:95] / v[0:79] by kernel), no scratch, no VGPR spills")
