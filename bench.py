@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--vit-layers", type=int, default=27)
     ap.add_argument("--zero", type=int, default=2, choices=(2, 3), help="3: decoder-layer parameters sharded (Zero3AdamW, BASELINE configs[4] machinery); NOT the headline config")
     ap.add_argument("--grad-checkpointing", action="store_true", help="per-layer recompute (reference --gradient_checkpointing True); NOT the headline config")
+    ap.add_argument("--set-variant", action="append", default=[], metavar="NAME=0|1",
+                    help="flip a composition switch of metamorph_amd.functional.VARIANTS for a same-box A/B (tools; the default line uses none)")
     ap.add_argument("--ckpt-layers", default="all", help="with --grad-checkpointing: 'all' (the reference's behaviour), an integer n (only the first n "
                     "decoder layers recompute, the others keep their activations), or 'auto' (the fewest layers that fit this GPU's HBM)")
     ap.add_argument("--host-inputs", action="store_true", help="ids / labels / mask / fp32 pixels start every step in pinned HOST memory (PCIe-inclusive "
@@ -450,6 +452,10 @@ def main():
         return self_launch(args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    for kv in args.set_variant:
+        import metamorph_amd.functional as F_
+        name, _, val = kv.partition("=")
+        F_.set_variant(name, int(val or 1))
     # MM355_BENCH_FORCE_DIST=1: drive the RCCL call pattern with a single rank under torchrun (collectives forced at world size 1)
     force_dist = os.environ.get("MM355_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
     if force_dist:
@@ -685,6 +691,7 @@ def main():
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
+                       **({"variants": sorted(args.set_variant)} if args.set_variant else {}),
                        "parallelism": f"dp{world} zero{args.zero}" + ((" +recompute" + ("" if ckpt_layers is None else f"(first {ckpt_layers} layers)")) if args.grad_checkpointing else "") + (
                            " +async-update" if getattr(opt, "async_update", False) else ""), "samples": (f"{args.batch} image-generation per GPU" if args.all_generation else f"{args.batch - 1} image-QA + 1 image-generation per GPU")},
             "loss": round(loss_val, 4), "loss_step0": round(float(loss_first), 5), "batch_pool": n_pool, "model_tflops_per_gpu": round(step_flops * args.steps / dt / 1e12, 1),

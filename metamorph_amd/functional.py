@@ -31,7 +31,10 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             # keep the transposed copies of the decoder weights (the B operands of the input-gradient GEMMs) from one backward call to
             # the next until the optimizer rewrites the parameters: under gradient accumulation the four transposes per layer are made
             # once per optimizer step instead of once per micro-batch (+2 bytes per decoder parameter while a window is open)
-            "wt_cache": False}
+            "wt_cache": False,
+            # one launch for an input-gradient GEMM and the weight-gradient GEMM that reads the same dy: (dn2, dW_gate_up) and (dX_o, dW_o)
+            # -- the mechanism of dw_pair (mm355_gemm_pair_bf16: same kernel body, same bits), saving one ramp and tail per pair
+            "dx_pair": True}
 
 
 def set_variant(name, value):
@@ -264,6 +267,14 @@ def drop_transposed_weights():
     _WT_CACHE.clear()
 
 
+def _pairable(a0, b0, a1, b1):
+    """Two plain NT problems worth one launch: each big enough for the 256 x 256 kernel on its own (>= 200 tiles), the first a whole
+    number of 8 workgroups (the second problem's workgroups then keep their XCD), both eligible for mm355_gemm_pair_bf16."""
+    t0 = -(-a0.shape[0] // 256) * -(-b0.shape[0] // 256)
+    t1 = -(-a1.shape[0] // 256) * -(-b1.shape[0] // 256)
+    return min(t0, t1) >= 200 and t0 % 8 == 0 and ops.gemm_pair_supported(a0, b0, a1, b1)
+
+
 def input_grad_gemm(dy2d, w, out=None, residual=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (+ residual); the weight is read untransposed whenever the ping-pong kernel applies"""
     if VARIANTS["dw_tn"] and ops.gemm_nn_supported(dy2d, w):
@@ -360,9 +371,9 @@ class DecoderLayerFn(Function):
         # full fine-tune on whole 64-row tiles: SwiGLU backward writes act^T and dgu^T itself (no transpose passes over them)
         fused_t = (not VARIANTS["dw_tn"] and dy.shape[0] % 64 == 0 and m.I % 64 == 0 and mlp.down_proj.weight.requires_grad
                    and all(p.requires_grad for p in gu_params))
-        wdT = None
+        wdT = wdT_made = None
         if fused_t and VARIANTS["fuse_swiglu_bwd"]:
-            wdT = transposed_weight(mlp.down_proj.weight)
+            wdT = wdT_made = transposed_weight(mlp.down_proj.weight)
             if not ops.gemm_swiglu_bwd_supported(dy, wdT, gu, m.I):
                 wdT = None
         if wdT is not None:
@@ -371,7 +382,7 @@ class DecoderLayerFn(Function):
             act = None
             del wdT
         else:
-            dact = input_grad_gemm(dy, mlp.down_proj.weight)                   # [M, I]
+            dact = ops.gemm(dy, wdT_made) if wdT_made is not None else input_grad_gemm(dy, mlp.down_proj.weight)   # [M, I]
             if fused_t:
                 dgu, actT, dguT = ops.swiglu_bwd_t(gu, dact, m.I)
                 act = None
@@ -392,27 +403,50 @@ class DecoderLayerFn(Function):
             commit_grad(wd, buf)
         del act, actT
         wgu = fused_weight(gu_params)
-        dn2 = input_grad_gemm(dgu, wgu)                                         # [M, h]
+        dn2 = None
         if any(p.requires_grad for p in gu_params):
             fb, acc, bufs = fused_grad_target(gu_params)
             if VARIANTS["dw_tn"] or not VARIANTS["norm_t"]:
+                dn2 = input_grad_gemm(dgu, wgu)
                 weight_grad_gemm(dgu, ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps), fb, bool(acc), dyT=dguT)
             else:                                                              # norm output, contraction-major, from the saved rstd
                 rp = dguT.shape[1] if dguT is not None else _padded_rows(x2.shape[0], long_k=True)
                 n2T = ops.rmsnorm_apply_t(x2, layer.post_attention_layernorm.weight, rstd2, rp)
-                weight_grad_gemm(dgu, None, fb, bool(acc), dyT=dguT, xT=n2T)
-                del n2T
+                a0, b0 = _dw_operands(dgu, None, dyT=dguT, xT=n2T)
+                wguT = transposed_weight(wgu)
+                if VARIANTS["dx_pair"] and not VARIANTS["dw_tn"] and _pairable(a0, b0, dgu, wguT):
+                    dn2 = torch.empty((dgu.shape[0], wguT.shape[0]), device=dev, dtype=BF16)
+                    ops.gemm_pair(a0, b0, fb, bool(acc), dgu, wguT, dn2, False)   # the weight gradient's long-K tiles first
+                else:
+                    dn2 = ops.gemm(dgu, wguT)
+                    ops.gemm(a0, b0, out=fb, accumulate=bool(acc))
+                del n2T, a0, b0, wguT
             commit_fused_grad(gu_params, fb, acc, bufs)
+        if dn2 is None:
+            dn2 = input_grad_gemm(dgu, wgu)                                     # [M, h]
         del dgu, dguT
         dx2 = _rmsnorm_backward(dn2, x2, layer.post_attention_layernorm.weight, m.eps, dy)     # dy + d rmsnorm
         del dn2
 
         # ---- attention ----
-        do = input_grad_gemm(dx2, att.o_proj.weight)                            # [M, Hq*d]
+        do = None
         if att.o_proj.weight.requires_grad:
             buf, acc = grad_target(att.o_proj.weight)
-            weight_grad_gemm(dx2, o, buf, acc)
+            if VARIANTS["dx_pair"] and not VARIANTS["dw_tn"]:
+                a0, b0 = _dw_operands(dx2, o)
+                woT = transposed_weight(att.o_proj.weight)
+                if _pairable(a0, b0, dx2, woT):
+                    do = torch.empty((dx2.shape[0], woT.shape[0]), device=dev, dtype=BF16)
+                    ops.gemm_pair(a0, b0, buf, acc, dx2, woT, do, False)
+                else:
+                    do = ops.gemm(dx2, woT)
+                    ops.gemm(a0, b0, out=buf, accumulate=acc)
+                del a0, b0, woT
+            else:
+                weight_grad_gemm(dx2, o, buf, acc)
             commit_grad(att.o_proj.weight, buf)
+        if do is None:
+            do = input_grad_gemm(dx2, att.o_proj.weight)                        # [M, Hq*d]
         dqkv = torch.empty_like(qkv)
         fuse_rope = VARIANTS["fuse_rope"] and ops.attn_bwd_rope_supported(m.d)      # inverse RoPE of dq / dk in the attention kernels' epilogues
         ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
