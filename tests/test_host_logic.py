@@ -796,3 +796,34 @@ def test_compiler_stays_out_of_the_streams_registers():
         bad, stats = mod.audit(mod.compile_s(name))
         assert stats and all(v["mfma"] >= 64 and v["asm_lines"] > v["mfma"] for v in stats.values()), (name, stats)
         assert not bad, (name, bad[:5])
+
+
+def test_fused_decode_gemv_row_ownership_is_a_partition():
+    """csrc/decode.hip, gemv_fused_kernel: a wave owns four weight rows chosen so that its epilogue finds its partners in its own
+    accumulators -- MODE 1 (SwiGLU): gate rows c, c + 1 and up rows I + c, I + c + 1; MODE 2 (RoPE + cache append): the rotation partners
+    j, j + 1, j + d/2, j + 1 + d/2 of one q / k head, four neighbours of a v head.  The formulas, restated here, must cover every weight
+    row exactly once for the geometries the models use (a row owned twice or never would be a silent wrong answer only for some heads)."""
+    def units_swiglu(I):
+        return [(c, c + 1, I + c, I + c + 1) for c in range(0, I, 2)]
+
+    def units_rope(Hq, Hkv, d):
+        upd, out = d // 4, []
+        for unit in range((Hq + 2 * Hkv) * d // 4):
+            if unit < (Hq + Hkv) * upd:
+                hd, j = unit // upd, (unit % upd) * 2
+                r0 = hd * d + j
+                out.append((r0, r0 + 1, r0 + d // 2, r0 + d // 2 + 1))
+            else:
+                b0 = (Hq + Hkv) * d + (unit - (Hq + Hkv) * upd) * 4
+                out.append((b0, b0 + 1, b0 + 2, b0 + 3))
+        return out
+
+    for I in (64, 1000, 14336, 28672):
+        rows = sorted(r for u in units_swiglu(I) for r in u)
+        assert rows == list(range(2 * I))
+    for Hq, Hkv, d in ((32, 8, 128), (64, 8, 128), (8, 1, 64), (2, 1, 80), (4, 4, 64)):
+        us = units_rope(Hq, Hkv, d)
+        rows = sorted(r for u in us for r in u)
+        assert rows == list(range((Hq + 2 * Hkv) * d)), (Hq, Hkv, d)
+        for u in us[:(Hq + Hkv) * d // 4]:                    # partners stay inside one head, d/2 apart
+            assert u[0] // d == u[3] // d and u[2] - u[0] == d // 2 and u[0] % d < d // 2
