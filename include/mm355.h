@@ -204,7 +204,8 @@ int mm355_attn_fwd(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v
                    int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, void* stream);
 
 /* mm355_attn_fwd with the kernel generation chosen by the caller -- for tests and tools/ (A/B timing, the serialised debugging stream);
- * the product calls mm355_attn_fwd.  variant: 0 = as mm355_attn_fwd; 2 = the generic-d kernels; 3 = the two-waves-per-SIMD d == 128 kernels; 4 = the one-wave-per-SIMD
+ * the product calls mm355_attn_fwd.  variant: 0 = as mm355_attn_fwd; 2 = the generic-d kernels; 3 = the round-2 two-waves-per-SIMD d == 128 kernels
+ * (-DMM355_LEGACY_VARIANTS builds only); 4 = the one-wave-per-SIMD
  * hand-placed stream (d == 128); 41 = the same stream serialised (every LDS read waited for at once, 32 wait states behind every MFMA:
  * bit-identical to 4 by construction).  MM355_EUNSUPPORTED when the variant does not cover the geometry.  Same reference call site as
  * mm355_attn_fwd (torch SDPA reached at metamorph_llama.py:349-359). */
@@ -212,12 +213,24 @@ int mm355_attn_fwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355
                            mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
                            int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, int variant, void* stream);
 
+/* Diagnostics of the d == 128 stream (tests only; the product calls mm355_attn_fwd): mm355_attn_fwd_variant with variant 4 / 41 that also
+ * reports how often each wave took the DEFERRED-RESCALE branch -- the kernel keeps a stale running row maximum m and rescales O and the
+ * row sums only when some row of the wave's 64 query rows grew by more than 2^6 over it.  rescale_counts: int32 [B][Hq][ceil(L / 256)][4],
+ * zeroed by the caller; entry = number of key tiles (of 64) at which that wave moved its maxima.  The parity tests on adversarial score
+ * distributions (tests/test_attn_hostile_gpu.py) assert these counts against a CPU model of the kernel's decision rule, so that "the
+ * branch ran" is a measured fact and not an assumption.  MM355_EUNSUPPORTED unless d == 128.  Same reference call site as mm355_attn_fwd
+ * (torch SDPA reached at metamorph_llama.py:349-359). */
+int mm355_attn_fwd_debug(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
+                         mm355_bf16* o, int64_t ld_o, float* lse, const int32_t* seqlens,
+                         int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal, int variant,
+                         int32_t* rescale_counts, void* stream);
+
 /* delta[b][h][l] = sum_dd dO*O  (softmax-backward row term). */
 int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta,
                         int64_t B, int64_t L, int64_t Hq, int64_t d, void* stream);
 
 /* Backward: dq / dk / dv are written as bf16 column blocks (leading dimensions ld_dq / ld_dkv), no atomics.
- * workspace: mm355_attn_bwd_ws_floats(...) floats; NULL allowed when that is 0 -- and for d == 128, where it selects the older kernels.
+ * workspace: mm355_attn_bwd_ws_floats(...) floats; NULL allowed when that is 0 (d == 128 always needs it: MM355_EINVAL without).
  * The d == 128 kernels (LLaMA-3) sum a GQA group in registers (the dK/dV workgroup walks all query heads of its KV group) and use the
  * workspace only for 2*B*Hq*L per-row constants; the generic-d kernels under GQA (e.g. TinyLlama, d = 64) run one workgroup per
  * (KV tile, query head) and need 2*B*L*Hq*d floats for the per-head partials that are summed afterwards. */
@@ -235,13 +248,13 @@ int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf
                         const mm355_bf16* d_o, int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens,
                         mm355_bf16* dq, int64_t ld_dq, mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv,
                         int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, float scale, int causal,
-                        const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset, void* stream);
+                        const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset, float* workspace, void* stream);
 
-/* The general form: mm355_attn_bwd (cos_t = sin_t = NULL) or mm355_attn_bwd_rope (tables given), WITH the workspace of
- * mm355_attn_bwd_ws_floats (d == 128 without it runs the older two-waves-per-SIMD kernels) and the kernel generation chosen by the
+/* The general form: mm355_attn_bwd (cos_t = sin_t = NULL) or mm355_attn_bwd_rope (tables given) with the kernel generation chosen by the
  * caller: variant 0 = the product's choice; for tests / tools 2 = the generic-d kernels (under GQA their 2*B*L*Hq*d workspace is the
- * caller's to provide), 3 = the two-waves-per-SIMD d == 128 kernels, 4 = the one-wave-per-SIMD
- * hand-placed streams (d == 128, workspace required), 41 = the same streams serialised (bit-identical to 4 by construction).
+ * caller's to provide), 3 = the round-2 two-waves-per-SIMD d == 128 kernels (only in -DMM355_LEGACY_VARIANTS builds, MM355_EUNSUPPORTED
+ * otherwise), 4 = the one-wave-per-SIMD hand-placed streams (d == 128, workspace required), 41 = the same streams serialised
+ * (bit-identical to 4 by construction).
  * Same reference call site as mm355_attn_bwd (backward of torch SDPA reached at metamorph_llama.py:349-359). */
 int mm355_attn_bwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k,
                            const mm355_bf16* d_o, int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens,
@@ -251,7 +264,7 @@ int mm355_attn_bwd_variant(const mm355_bf16* q, const mm355_bf16* k, const mm355
                            float* workspace, int variant, void* stream);
 
 /* floats of `workspace` mm355_attn_bwd needs for this geometry (ld_max = largest of ld_q / ld_k / ld_o); 0 when none is needed.
- * d == 128: 2 * B * Hq * L (the score chains' C operands -lse * log2 e and -delta); generic d under GQA: 2 * B * L * Hq * d. */
+ * d == 128: 2 * B * Hq * L (the score chains' C operands -lse / scale and -delta); generic d under GQA: 2 * B * L * Hq * d. */
 int64_t mm355_attn_bwd_ws_floats(int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, int64_t ld_max);
 
 /* f32 [rows][cols] -> bf16 column block (generic helper). */

@@ -10,10 +10,17 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmm355.so")
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn3.hip", "attn4.hip", "attn4_bwd.hip", "gemm_st.hip", "decode.hip", "losses.hip"]
+# MM355_LEGACY_VARIANTS=1 (tools only): also compile the kernel generations no product path selects -- the round-2 d == 128 attention
+# (attn3.hip, attention variant 3), the one-wave-per-SIMD GEMM stream (gemm_st.hip, GEMM variants 13 / 14) and GEMM variants 3-6, 8, 10, 12 --
+# for A/B timing (tools/bench_attn4*.py, tools/bench_gemm_*.py) and their tests (MM355_TEST_LEGACY=1).  The product library has none of them.
+LEGACY = os.environ.get("MM355_LEGACY_VARIANTS") == "1"
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn4.hip", "attn4_bwd.hip", "decode.hip", "losses.hip"]
+if LEGACY:
+    SOURCES += ["attn3.hip", "gemm_st.hip"]
 HEADERS = ["mm355_common.h", "gemm_common.h", "attn2.h", "attn3_kernels.h"] + sorted(
-    os.path.join(d, f) for d in ("attn4_gen", "attn4_bwd_gen", "gemm_st_gen") for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(".inc"))   # tools/gen_attn4*.py output
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    os.path.join(d, f) for d in ("attn4_gen", "attn4_bwd_gen") + (("gemm_st_gen",) if LEGACY else ())
+    for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(".inc"))   # tools/gen_attn4*.py output
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DMM355_LEGACY_VARIANTS"] if LEGACY else [])
 # MFMA results stay in arch VGPRs (<= 256 registers, two waves per SIMD): no accumulator <-> VGPR moves around the VALU phases
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # the hand-placed streams own the accumulator file: hipcc must not park its own spills there (tools/audit_attn4.py checks the result)
@@ -57,6 +64,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    for stale in ("attn3.o", "gemm_st.o"):                       # objects of another build flavour must not be linked (or shipped)
+        if stale.replace(".o", ".hip") not in SOURCES and os.path.exists(os.path.join(LIBDIR, stale)):
+            os.remove(os.path.join(LIBDIR, stale))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print("[mm355 build]", " ".join(cmd), flush=True)

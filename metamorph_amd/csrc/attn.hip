@@ -64,24 +64,28 @@ bool fast128(int64_t d, int64_t ld_k) { return d == 128 && ld_k * 2 * 64 < 0x7ff
 }  // namespace
 
 namespace {
-// variant: 0 = the product's choice, 2 = the generic-d kernels of attn2.hip, 3 = the two-waves-per-SIMD kernels of attn3.hip,
-// 4 = the one-wave-per-SIMD stream of attn4.hip, 41 = attn4's serialised debugging stream (bit-identical to 4 by construction; tests / tools only)
+// variant: 0 = the product's choice, 2 = the generic-d kernels of attn2.hip, 3 = the two-waves-per-SIMD kernels of attn3.hip (round 2;
+// compiled only with -DMM355_LEGACY_VARIANTS, MM355_EUNSUPPORTED otherwise), 4 = the one-wave-per-SIMD stream of attn4.hip, 41 = attn4's
+// serialised debugging stream (bit-identical to 4 by construction; tests / tools only)
 int attn_fwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
                   int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
-                  int64_t d, float scale, int causal, int variant, void* stream) {
+                  int64_t d, float scale, int causal, int variant, void* stream, int32_t* dbg = nullptr) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!q || !k || !v || !o || !lse || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7)) return MM355_EINVAL;
     attn2::Args a{q, k, v, nullptr, ld_q, ld_k, ld_o, o, lse, nullptr, nullptr, nullptr, 0, seqlens,
-                  nullptr, nullptr, nullptr, nullptr, 0, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal};
+                  nullptr, nullptr, nullptr, nullptr, 0, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal, nullptr, nullptr, nullptr, dbg};
     const bool can4 = d == 128 && L * ld_k * 2 < 0x7fffffffll;          // 32-bit descriptor offsets inside one sample
     if (variant == 4 || variant == 41) return can4 ? mm355_attn4_fwd_launch(a, variant == 41, (hipStream_t)stream) : MM355_EUNSUPPORTED;
+#ifdef MM355_LEGACY_VARIANTS                                 // tools build (MM355_LEGACY_VARIANTS=1 python -m metamorph_amd.build): round-2 kernels for A/B timing
     if (variant == 3) return fast128(d, ld_k) ? mm355_attn3_fwd_launch(a, (hipStream_t)stream) : MM355_EUNSUPPORTED;
+#else
+    if (variant == 3) return MM355_EUNSUPPORTED;
+#endif
     if (variant == 2) return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
     if (variant != 0) return MM355_EINVAL;
     if (can4 && fast128(d, ld_k)) return mm355_attn4_fwd_launch(a, 0, (hipStream_t)stream);
-    if (fast128(d, ld_k)) return mm355_attn3_fwd_launch(a, (hipStream_t)stream);
-    return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);
+    return mm355_attn2_fwd_launch(a, pick_dp(d), (hipStream_t)stream);   // generic head sizes (SigLIP d = 72, TinyLlama d = 64), samples of >= 2 GiB
 }
 }  // namespace
 
@@ -95,6 +99,13 @@ extern "C" int mm355_attn_fwd_variant(const mm355_bf16* q, const mm355_bf16* k, 
                                       int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
                                       int64_t d, float scale, int causal, int variant, void* stream) {
     return attn_fwd_impl(q, k, v, ld_q, ld_k, o, ld_o, lse, seqlens, B, L, Hq, Hkv, d, scale, causal, variant, stream);
+}
+
+extern "C" int mm355_attn_fwd_debug(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v, int64_t ld_q, int64_t ld_k, mm355_bf16* o,
+                                    int64_t ld_o, float* lse, const int32_t* seqlens, int64_t B, int64_t L, int64_t Hq, int64_t Hkv,
+                                    int64_t d, float scale, int causal, int variant, int32_t* rescale_counts, void* stream) {
+    if (!rescale_counts || (variant != 4 && variant != 41)) return MM355_EINVAL;
+    return attn_fwd_impl(q, k, v, ld_q, ld_k, o, ld_o, lse, seqlens, B, L, Hq, Hkv, d, scale, causal, variant, stream, rescale_counts);
 }
 
 extern "C" int mm355_attn_bwd_prep(const mm355_bf16* o, const mm355_bf16* d_o, int64_t ld_o, float* delta, int64_t B, int64_t L,
@@ -122,14 +133,23 @@ int attn_bwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
     if (!q || !k || !v || !d_o || !lse || !delta || !dq || !dk || !dv || bad_geom(B, L, Hq, Hkv, d)) return MM355_EINVAL;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 7) || (ld_dkv & 7) || (ld_dq & 7)) return MM355_EINVAL;
     const int64_t ld_max = std::max(std::max(ld_q, ld_k), ld_o);
-    const bool fast = fast128(d, ld_max) && variant != 2;    // (variant 2: the generic-d kernels; GQA then needs the 2*B*L*Hq*d workspace)
-    if (rope_cos && !fast) return MM355_EUNSUPPORTED;        // the fused inverse rotation lives in the d == 128 kernels' epilogues
-    // variant: 0 = the product's choice, 2 = attn2.hip (generic d), 3 = attn3.hip (two waves per SIMD), 4 = attn4_bwd.hip (one wave per SIMD, hand-placed streams; needs
-    // the workspace), 41 = its serialised debugging streams
+    // variant: 0 = the product's choice, 2 = attn2.hip (generic d; GQA then needs the 2*B*L*Hq*d workspace), 3 = attn3.hip (two waves per SIMD;
+    // -DMM355_LEGACY_VARIANTS builds only), 4 = attn4_bwd.hip (one wave per SIMD, hand-placed streams; needs the workspace), 41 = its
+    // serialised debugging streams
     if (variant != 0 && variant != 2 && variant != 3 && variant != 4 && variant != 41) return MM355_EINVAL;
-    const bool can4 = fast && workspace && L * ld_max * 2 < 0x7fffffffll;
+    const bool is128 = fast128(d, ld_max) && variant != 2;
+    const bool can4 = is128 && variant != 3 && workspace && L * ld_max * 2 < 0x7fffffffll;
+#ifdef MM355_LEGACY_VARIANTS
+    const bool fast = is128;                                 // attn3's dK/dV + dQ kernels
+#else
+    const bool fast = false;
+    if (variant == 3) return MM355_EUNSUPPORTED;
+    // d == 128 without the stream kernels' workspace / beyond their 31-bit offsets: the generic kernels would need THEIR (larger) GQA workspace,
+    // which mm355_attn_bwd_ws_floats did not size for this geometry
+    if (is128 && !can4 && Hq != Hkv) return workspace ? MM355_EUNSUPPORTED : MM355_EINVAL;
+#endif
+    if (rope_cos && !(can4 || fast)) return MM355_EUNSUPPORTED;   // the fused inverse rotation lives in the d == 128 kernels' epilogues
     if ((variant == 4 || variant == 41) && !can4) return MM355_EUNSUPPORTED;
-    if (variant == 3 && !fast) return MM355_EUNSUPPORTED;
     if (variant == 4 || variant == 41 || (variant == 0 && can4)) {
         attn2::Args a4{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
                        dk, dv, nullptr, nullptr, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal, rope_cos, rope_sin, rope_pos};
@@ -146,7 +166,11 @@ int attn_bwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
     }
     attn2::Args a{q, k, v, d_o, ld_q, ld_k, ld_o, nullptr, nullptr, lse, delta, dq, ld_dq, seqlens,
                   dk, dv, dkp, dvp, ld_dkv, (int)B, (int)L, (int)Hq, (int)Hkv, (int)d, scale, causal, rope_cos, rope_sin, rope_pos};
+#ifdef MM355_LEGACY_VARIANTS
     int rc = fast ? mm355_attn3_dkdv_launch(a, s) : mm355_attn2_dkdv_launch(a, pick_dp(d), s);
+#else
+    int rc = mm355_attn2_dkdv_launch(a, pick_dp(d), s);
+#endif
     if (rc != MM355_OK) return rc;
     if (dkp) {
         const int64_t rows = B * L;
@@ -156,7 +180,10 @@ int attn_bwd_impl(const mm355_bf16* q, const mm355_bf16* k, const mm355_bf16* v,
         rc = mm_launch_status();
         if (rc != MM355_OK) return rc;
     }
-    return fast ? mm355_attn3_dq_launch(a, s) : mm355_attn2_dq_launch(a, pick_dp(d), s);
+#ifdef MM355_LEGACY_VARIANTS
+    if (fast) return mm355_attn3_dq_launch(a, s);
+#endif
+    return mm355_attn2_dq_launch(a, pick_dp(d), s);
 }
 }  // namespace
 
@@ -172,9 +199,9 @@ extern "C" int mm355_attn_bwd_rope(const mm355_bf16* q, const mm355_bf16* k, con
                                    int64_t ld_o, const float* lse, const float* delta, const int32_t* seqlens, mm355_bf16* dq, int64_t ld_dq,
                                    mm355_bf16* dk, mm355_bf16* dv, int64_t ld_dkv, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                                    float scale, int causal, const mm355_bf16* cos_t, const mm355_bf16* sin_t, const int32_t* pos_offset,
-                                   void* stream) {
+                                   float* workspace, void* stream) {
     if (!cos_t || !sin_t) return MM355_EINVAL;
-    return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, nullptr,
+    return attn_bwd_impl(q, k, v, ld_q, ld_k, d_o, ld_o, lse, delta, seqlens, dq, ld_dq, dk, dv, ld_dkv, B, L, Hq, Hkv, d, scale, causal, workspace,
                          cos_t, sin_t, pos_offset, 0, stream);
 }
 

@@ -13,6 +13,9 @@ struct Args {
     // backward only, d == 128 kernels: when set, dq / dk leave the kernels already rotated back through RoPE (the inverse rotation of
     // mm355_rope_qk on the bf16-rounded gradients): cos / sin tables [positions][128] bf16, optional per-sample position offsets
     const uint16_t* rope_cos; const uint16_t* rope_sin; const int32_t* rope_pos;
+    // diagnostics (mm355_attn_fwd_debug; nullptr in the product path): attn4::fwd_kernel writes dbg[((b * Hq + hq) * ceil(L / 256) + query block) * 4 + wave] = how many times
+    // that wave took the deferred-rescale branch (running maximum moved because some row grew by more than 2^THR)
+    int32_t* dbg;
 };
 
 #ifdef __HIPCC__

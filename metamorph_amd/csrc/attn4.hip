@@ -1,11 +1,13 @@
 // Attention forward, d == 128, fourth generation (gfx950): ONE wave per SIMD with the whole 512-entry register file and a hand-placed
 // instruction stream (tools/gen_attn4.py writes csrc/attn4_gen/*.inc; read its header first).
 //   * workgroup = 256 query rows = 4 waves x 64 rows (two 32-row blocks per wave); products on v_mfma_f32_32x32x16_bf16:
-//     S^T[64 keys][64 q] = K Q~^T (32 MFMAs per tile), O^T[128 d][64 q] += V^T P^T (32 MFMAs per tile)
-//   * Q~ = bf16(q * scale * log2 e) is prepared once per block, and the first MFMA of every score chain takes C = -m (the running row
-//     maximum, log2 domain) from a register tuple: the chain delivers s' = s - m and P = exp2(s') is ONE v_exp_f32 per score (no
-//     multiply / subtract on the vector ALU); m only moves when some row grew by more than 2^6 (rare, wave-uniform branch)
-//   * register file, all LITERAL registers owned by the asm stream (map in tools/gen_attn4.py): O a[0:127], Q~ a[128:191], K / V fragment
+//     S^T[64 keys][64 q] = K Q^T (32 MFMAs per tile), O^T[128 d][64 q] += V^T P^T (32 MFMAs per tile)
+//   * the score MFMAs take q and k AS STORED (the bf16 values the reference's SDPA sees) and the first MFMA of every chain takes C = -m
+//     (the running row maximum, in units of the raw dot product) from a register tuple: the chain delivers s' = q . k - m in fp32, and the
+//     softmax scale enters on the fp32 side, P = exp2((scale * log2 e) * s'): one v_pk_mul_f32 per PAIR of scores + one v_exp_f32 per score
+//     (no subtract on the vector ALU); m only moves when some row grew by more than 2^6 (rare, wave-uniform branch).  Rounds 1-4 folded
+//     scale * log2 e into a re-rounded bf16 copy of q: an extra rounding whose score error grows with |s|
+//   * register file, all LITERAL registers owned by the asm stream (map in tools/gen_attn4.py): O a[0:127], Q a[128:191], K / V fragment
 //     rings a[192:255] filled straight from LDS (ds_read_b128 / ds_read_b64_tr_b16 into accumulator registers); v[64:191] two score
 //     tiles, v[192:223] the -m tuples, v[224:255] P; hipcc allocates only v[0:63] (amdgpu_num_vgpr(64): addresses, row sums, row maxima;
 //     tools/audit_attn4.py proves on the emitted code object that no compiler instruction touches anything else)
@@ -36,6 +38,7 @@ constexpr int TILE = 16384;                                  // [64 rows][128] b
 constexpr int VRING = 2 * TILE;                              // K slots 0, 1 | V slots 0, 1
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float THR = 6.0f;                                  // log2 units: the running maximum stays while no row grew by more than 2^6
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 MM_DEV float half_swap_max(float m) {                        // max over the two lanes (l, l ^ 32) that share a query row
     float a = m, b = m;
@@ -113,8 +116,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
             vvo[i] = row * ldb + (uint32_t)((pc ^ (r4 << 2)) << 4);
         }
     }
-    // raw Q rows first (HBM latency is the prologue's critical path): lane holds Q[q = qb*32 + c][d = ks*16 + hi*8 .. + 8] -> v[128:191]
-    const float sl2 = a.scale * LOG2E;
+    // Q rows first (HBM latency is the prologue's critical path): lane holds Q[q = qb*32 + c][d = ks*16 + hi*8 .. + 8] -> v[128:191]
+    const float sl2 = a.scale * LOG2E;                       // raw q . k units -> log2 domain; (sl2, sl2) as the SGPR-pair operand of v_pk_mul_f32
+    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(sl2));
+    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
     {
         const uint16_t* qp0_ = a.q + (row_base + min(qw0 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
         const uint16_t* qp1_ = a.q + (row_base + min(qw0 + 32 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
@@ -132,10 +137,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
 #include ATTN4_INC(zero_o.inc)
-    float LS[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // [qb][r & 3] partial row sums of this lane's keys
+    f32x2_t LS[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // [qb][(r >> 1) & 1] packed partial row sums of this lane's keys
     float MX[2][2], rm_[2], rt_[2];
     uint64_t grow_ = 0;
-    float thr_ = THR;
+    int nresc_ = 0;                                          // deferred-rescale branches this wave took (wave-uniform: lives in an SGPR)
+#define ATTN4_COUNT_RESCALE() (++nresc_)
+    float thr_ = THR / sl2;                                  // the same 2^6, in raw q . k units
     asm volatile("" : "+v"(thr_));
     const float ninf = -INFINITY;
     // LDS read addresses: K rows (b128), logical chunk ks*2 + hi of row c at physical chunk ^ (c & 15); V gathers (tr_b64): lane i of a
@@ -162,8 +169,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
             lim2[qb] = (a.causal ? min(qg, seqlen - 1) : seqlen - 1) - tw * 64 - 4 * hi;
         }
     }
-    // Q~ = bf16(q * scale * log2 e): d-steps 0 and 1 here (the 16 row loads precede the 12 DMA pieces in the memory queue), 2..7 inside the head
-    float t0_, t1_;
+    // Q fragments into the accumulator file: d-steps 0 and 1 here (the 16 row loads precede the 12 DMA pieces in the memory queue), 2..7 inside the head
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #include ATTN4_INC(q_pre01.inc)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
     for (int qb_ = 0; qb_ < 2; ++qb_) {
         const int qg = qw0 + qb_ * 32 + c;
         const bool valid = qg < seqlen && tw >= 0;
-        const float l_run = half_swap_sum((LS[qb_][0] + LS[qb_][1]) + (LS[qb_][2] + LS[qb_][3]));
+        const float l_run = half_swap_sum((LS[qb_][0].x + LS[qb_][0].y) + (LS[qb_][1].x + LS[qb_][1].y));
         const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
         for (int db_ = 0; db_ < 4; ++db_) {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
         }
         float nm0;
         if (qb_ == 0) asm volatile("v_mov_b32 %0, v192" : "=v"(nm0)); else asm volatile("v_mov_b32 %0, v208" : "=v"(nm0));
-        if (hi == 0 && qg < L) lse_base[qg] = valid ? (log2f(l_run) - nm0) * 0.6931471805599453f : 0.f;
+        if (hi == 0 && qg < L) lse_base[qg] = valid ? (log2f(l_run) - nm0 * sl2) * 0.6931471805599453f : 0.f;   // nm0 = -m in raw units
     }
     __syncthreads();
 #pragma unroll
@@ -270,6 +276,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
         const int qg = qw0 + r;
         if (qg < L) *(u32x4*)(o_base + (int64_t)qg * a.ld_o + j * 8) = *(const u32x4*)(so + r * 256 + ((j ^ (r & 15)) << 4));
     }
+    if (a.dbg && lane == 0) a.dbg[(((int64_t)b * a.Hq + hq) * ((L + 255) / 256) + xb) * 4 + wave] = nresc_;   // [B][Hq][blocks][4 waves], zeroed by the caller
 #ifdef MM355_ATTN4_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long tm6 = __builtin_readcyclecounter();

@@ -1,12 +1,15 @@
 // Attention backward, d == 128, fourth generation (gfx950): the dK / dV kernel and the dQ kernel as hand-placed one-wave-per-SIMD
 // instruction streams (tools/gen_attn4_bwd.py writes csrc/attn4_bwd_gen/*.inc; read its header and that of tools/gen_attn4.py first).
 //   * products on v_mfma_f32_32x32x16_bf16; the side a wave owns for its whole life sits in the accumulator file as B operands (dK / dV:
-//     K~ = bf16(K * scale * log2 e) and V of 32 keys; dQ: Q~ and dO of 32 query rows), the other side streams through a four-slot LDS ring
+//     K and V of 32 keys, as stored; dQ: Q and dO of 32 query rows), the other side streams through a four-slot LDS ring
 //     of 64-row tiles (LDS-DMA, rows beyond the sample out of range of the descriptor = zeros); fragments go LDS -> accumulator registers
 //     (ds_read_b128 for the score products, ds_read_b64_tr_b16 pairs for the gradient products, one tile swizzle serves both: 16-B chunk ^
 //     ((row & 3) << 2 | (row >> 2) & 3))
-//   * the score chains start from C = -lse * log2(e) and C = -delta, so P = exp2(x) and dS = P * y are ONE instruction per score each
-//     (dK / dV: the C values are read from the tile's statistics rows straight into the chain's registers; dQ: two constant tuples)
+//   * the score chains start from C = -lse / scale (units of the raw dot product) and C = -delta; the softmax scale enters on the fp32 side,
+//     P = exp2((scale * log2 e) * x): one v_pk_mul_f32 per PAIR of scores, one v_exp_f32 and one v_mul_f32 (dS = P * y) per score
+//     (dK / dV: the C values are read from the tile's statistics rows straight into the chain's registers; dQ: two constant tuples).
+//     q and k enter the MFMAs as stored -- all three attention kernels recompute the SAME fp32 scores (rounds 1-4: a re-rounded bf16 copy of
+//     one operand times scale * log2 e, a different one per kernel)
 //   * dK / dV: workgroup = 128 keys of one KV head (4 waves x 32), walks the 64-row query tiles of all query heads of its GQA group in one
 //     software pipeline (the group sum happens in the accumulators: no partials, no atomics); dQ: workgroup = 128 query rows (4 x 32)
 //   * scale is applied once to the finished accumulators; the inverse RoPE rotation of dq / dk (mm355_attn_bwd_rope) in the epilogues
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(96))) void d
     const uint32_t ldqb = (uint32_t)a.ld_q * 2u, ldob = (uint32_t)a.ld_o * 2u;
     const int64_t stat_n = (int64_t)a.B * a.Hq * L;
 
-    const float sl2 = a.scale * LOG2E;
+    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // (c, c) as the SGPR-pair operand of v_pk_mul_f32
+    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
     LaneAddr la;
     la.init(lane);
     // ring slots 0, 1 are reached from RA / TA / TB (+ immediates < 64 KiB), slots 2, 3 from the copies 64 KiB higher
@@ -360,7 +364,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(80))) void d
     const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * 128;
     const uint32_t nrec = (uint32_t)(seqlen - 1) * ldb + 256u;
 
-    const float sl2 = a.scale * LOG2E;
+    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // (c, c) as the SGPR-pair operand of v_pk_mul_f32
+    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
     LaneAddr la;
     la.init(lane);
     int RA[8], TA[4], TB[4], RAH[8], TAH[4], TBH[4];
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(80))) void d
         const uint16_t* p0_ = a.q + (row_base + qc) * a.ld_q + (int64_t)hq * 128 + hi * 8;
         const uint16_t* p1_ = a.d_o + (row_base + qc) * a.ld_o + (int64_t)hq * 128 + hi * 8;
 #include ATTN4B_INC(q_pers_load.inc)
-        const float nl_ = -a.lse_in[((int64_t)b * a.Hq + hq) * L + qc] * LOG2E;
+        const float nl_ = -a.lse_in[((int64_t)b * a.Hq + hq) * L + qc] * (1.0f / a.scale);
         const float nd_ = -a.delta[((int64_t)b * a.Hq + hq) * L + qc];
 #include ATTN4B_INC(q_tuple_write.inc)
     }
@@ -549,10 +554,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(80))) void d
     }
 }
 
-// nstat[0][b][h][l] = -lse * log2(e), nstat[1][b][h][l] = -delta: the C operands of the dK / dV kernel's score chains
-__global__ __launch_bounds__(256) void nstat_kernel(const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ nstat, int64_t n) {
+// nstat[0][b][h][l] = -lse / scale (raw q . k units), nstat[1][b][h][l] = -delta: the C operands of the dK / dV kernel's score chains
+__global__ __launch_bounds__(256) void nstat_kernel(const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ nstat, int64_t n,
+                                                    float inv_scale) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        nstat[i] = -lse[i] * LOG2E;
+        nstat[i] = -lse[i] * inv_scale;
         nstat[n + i] = -delta[i];
     }
 }
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(256) void nstat_kernel(const float* __restrict__ ls
 int mm355_attn4_bwd_launch(const attn2::Args& a, float* workspace, int variant, hipStream_t s) {
     static std::atomic<uint64_t> ok_kv{0}, ok_kvs{0}, ok_q{0}, ok_qs{0};
     const int64_t n = (int64_t)a.B * a.Hq * a.L;
-    hipLaunchKernelGGL(attn4b::nstat_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, a.lse_in, a.delta, workspace, n);
+    hipLaunchKernelGGL(attn4b::nstat_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, a.lse_in, a.delta, workspace, n, 1.0f / a.scale);
     const int64_t nkv = (int64_t)((a.L + 127) / 128) * a.Hkv * a.B, nq = (int64_t)((a.L + 127) / 128) * a.Hq * a.B;
     if (nkv > 0x7fffffff || nq > 0x7fffffff) return MM355_EINVAL;
     if (variant == 1) {

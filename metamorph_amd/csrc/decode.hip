@@ -677,6 +677,9 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
         w[0] = -INFINITY; w[1] = 0.f;
     }
     (void)active;
+    if (ngr_live == 0 && grp == 0) {                          // an empty cache (kv_len == 0): a zero row, as the split kernel writes it
+        for (int i = tid; i < G * d; i += 1024) o[(int64_t)b * ld_o + (int64_t)(hk * G + i / d) * d + i % d] = 0;
+    }
     if (ngr_live <= 1) return;                                // (uniform over the grid: kv_len is per sample, read by every group of it)
     __threadfence();
     __syncthreads();
@@ -767,10 +770,13 @@ extern "C" int mm355_rope_kv_append(mm355_bf16* qkv, int64_t ld, int64_t B, int6
     return mm_launch_status();
 }
 
+// the arrival counters (one per sample and KV head, Hkv <= Hq) sit at the START of the workspace, at an offset that does not depend on
+// max_kv_len: one workspace serves calls with different cache lengths (the records behind them are scratch, rewritten by every launch)
+static int64_t decode_counter_floats(int64_t B, int64_t Hq) { return (B * Hq + 3) & ~(int64_t)3; }
+
 extern "C" int64_t mm355_attn_decode_ws_floats(int64_t B, int64_t Hq, int64_t d, int64_t max_kv_len) {
     if (B <= 0 || Hq <= 0 || d <= 0 || max_kv_len <= 0) return 0;
-    const int64_t Hkv_max = Hq;                              // one arrival counter per (sample, KV head); Hkv <= Hq
-    return B * Hq * ((max_kv_len + CH - 1) / CH) * (d + 2) + B * Hkv_max;
+    return decode_counter_floats(B, Hq) + B * Hq * ((max_kv_len + CH - 1) / CH) * (d + 2);
 }
 
 static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache, int64_t ld_kv,
@@ -785,7 +791,8 @@ static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16*
     const int nsplit = (int)((max_kv_len + CH - 1) / CH);
     const int ngroup = (nsplit + 3) / 4;                     // 1024-key groups: one workgroup each
     hipStream_t s = (hipStream_t)stream;
-    int* counters = (int*)(workspace + B * Hq * nsplit * (d + 2));   // zero on first use (caller), left zero by every launch
+    int* counters = (int*)workspace;                         // zero on first use (caller), left zero by every launch
+    workspace += decode_counter_floats(B, Hq);               // the per-chunk / per-group records
     int rc;
 #define AD(Gv) (variant == 1 ? launch_split<Gv>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, nsplit, (int)B, (int)Hq, (int)Hkv, (int)d, scale, o, ld_o, counters, s) \
                              : launch_wide<Gv>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, workspace, ngroup, (int)B, (int)Hq, (int)Hkv, (int)d, scale, o, ld_o, counters, s))

@@ -1193,6 +1193,7 @@ bool pp_eligible(const GemmArgs& a, bool ta, bool tb) {
     return ea < 0x7fffffffLL && eb < 0x7fffffffLL;
 }
 
+#ifdef MM355_LEGACY_VARIANTS
 int launch_gemm_pp2(GemmArgs a, hipStream_t s) {
     if (!pp_eligible(a, false, false)) return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
     static std::atomic<uint64_t> lds_ok{0};
@@ -1203,11 +1204,14 @@ int launch_gemm_pp2(GemmArgs a, hipStream_t s) {
     return mm_launch_status();
 }
 
+#endif
+
 int launch_gemm_pp(GemmArgs a, hipStream_t s) {
     if (!pp_eligible(a, false, false)) return launch_gemm<256, 256, 2, 4, true, 1, false>(a, s);
     return launch_gemm_pp_t<false, false>(a, s);
 }
 
+#ifdef MM355_LEGACY_VARIANTS
 int launch_gemm_ring(GemmArgs a, hipStream_t s) {
     if (a.K < 128) return launch_gemm<256, 256, 2, 4, true, 0, false>(a, s);
     constexpr int LDS = 4 * (256 + 256) * 64;               // 128 KiB
@@ -1220,6 +1224,8 @@ int launch_gemm_ring(GemmArgs a, hipStream_t s) {
     hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3((unsigned)total), dim3(512), LDS, s, a);
     return mm_launch_status();
 }
+
+#endif
 
 template <int BM, int BN, int WM, int WN, bool GLDS, int PIPE = 0, bool TNL = false>
 int launch_gemm(GemmArgs a, hipStream_t s) {
@@ -1323,10 +1329,12 @@ extern "C" int mm355_gemm_num_variants(void) { return 14; }
 
 int mm355_gemm_st_launch(const void* args, int serialised, void* stream);   // gemm_st.hip: one wave per SIMD, hand-placed stream
 
+#ifdef MM355_LEGACY_VARIANTS
 namespace {
 // the stream kernel moves whole pairs of K stages and fetches two stages ahead: K % 128 == 0, K >= 256, 31-bit tile-relative offsets
 bool st_eligible(const GemmArgs& a) { return a.K >= 256 && pp_eligible(a, false, false); }
 }  // namespace
+#endif
 
 extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, void* C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, const mm355_bf16* bias, const mm355_bf16* residual,
@@ -1355,16 +1363,18 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
     switch (variant) {
         case 1: return launch_gemm<128, 128, 2, 2, false>(a, s);
         case 2: return launch_gemm<128, 128, 2, 2, true>(a, s);
+        case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
+        case 11: return launch_gemm_pp(a, s);
+#ifdef MM355_LEGACY_VARIANTS                                 // tools build: kernels no product path selects, kept for A/B timing
         case 3: return launch_gemm<256, 128, 4, 2, false>(a, s);
         case 4: return launch_gemm<256, 128, 4, 2, true>(a, s);
         case 5: return launch_gemm<256, 256, 2, 4, false>(a, s);
         case 6: return launch_gemm<256, 256, 2, 4, true>(a, s);
-        case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
         case 8: return launch_gemm<128, 128, 2, 2, true, 1>(a, s);
         case 10: return launch_gemm_ring(a, s);
-        case 11: return launch_gemm_pp(a, s);
         case 12: return launch_gemm_pp2(a, s);
         case 13: case 14: return st_eligible(a) ? mm355_gemm_st_launch(&a, variant == 14, s) : MM355_EUNSUPPORTED;
+#endif
 #ifdef MM355_ABLATIONS                                       // TIMING-ONLY builds (tools/build_ablation.sh ... -DMM355_ABLATIONS): wrong results on purpose
         case 91: return launch_gemm_pp_t<false, false, 1>(a, s);     // no DMA
         case 92: return launch_gemm_pp_t<false, false, 2>(a, s);     // no fragment reads

@@ -243,23 +243,28 @@ def _pair_saves_a_wave(rows0, cols0, rows1, cols1, contraction):
     return -(-(t0 + t1) // _CUS) < -(-t0 // _CUS) + -(-t1 // _CUS)
 
 
-_WT_CACHE = {}                                               # (data_ptr, shape) -> (parameter generation, transposed copy)
+_WT_CACHE = {}                                               # (storage, offset, shape, strides) -> ((generation, source versions...), transposed copy)
 
 
-def transposed_weight(w):
-    """w [N, K] -> [K, Np] (transpose_padded).  With VARIANTS["wt_cache"] the copy is kept until the parameters change
-    (`bump_param_generation`, called by every optimizer step / checkpoint load): same bits, one transpose per optimizer step."""
-    if not VARIANTS["wt_cache"]:
+def transposed_weight(w, sources=None):
+    """w [N, K] -> [K, Np] (transpose_padded).  With VARIANTS["wt_cache"] AND `sources` given the copy is kept until the parameters change:
+    same bits, one transpose per optimizer step.  `sources` = the parameters w is (a fused view of); it is passed only at the decoder
+    layer's own call sites, whose operands are long-lived parameters or views of the optimizer's flat buffer -- never by the generic
+    input_grad_gemm (LinearFn / LinearWBFn also see per-forward temporaries, whose address a later tensor can reuse).  An entry is valid
+    for one parameter generation (`bump_param_generation`: every optimizer step / checkpoint load, which write behind torch's back) AND one
+    set of torch version counters of the sources (any in-place write through torch -- copy_, load_state_dict, mul_ -- invalidates it
+    without anybody having to bump)."""
+    if sources is None or not VARIANTS["wt_cache"]:
         return transpose_padded(w)
-    key = (w.data_ptr(), tuple(w.shape))
-    gen = param_generation()
+    key = (w.untyped_storage().data_ptr(), w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    stamp = (param_generation(),) + tuple(p._version for p in sources)
     hit = _WT_CACHE.get(key)
-    if hit is not None and hit[0] == gen:
+    if hit is not None and hit[0] == stamp:
         return hit[1]
-    if _WT_CACHE and next(iter(_WT_CACHE.values()))[0] != gen:
+    if _WT_CACHE and next(iter(_WT_CACHE.values()))[0][0] != stamp[0]:
         _WT_CACHE.clear()                                     # a new generation: every cached copy is stale
     wt = transpose_padded(w)
-    _WT_CACHE[key] = (gen, wt)
+    _WT_CACHE[key] = (stamp, wt)
     return wt
 
 
@@ -373,7 +378,7 @@ class DecoderLayerFn(Function):
                    and all(p.requires_grad for p in gu_params))
         wdT = wdT_made = None
         if fused_t and VARIANTS["fuse_swiglu_bwd"]:
-            wdT = wdT_made = transposed_weight(mlp.down_proj.weight)
+            wdT = wdT_made = transposed_weight(mlp.down_proj.weight, sources=(mlp.down_proj.weight,))
             if not ops.gemm_swiglu_bwd_supported(dy, wdT, gu, m.I):
                 wdT = None
         if wdT is not None:
@@ -413,7 +418,7 @@ class DecoderLayerFn(Function):
                 rp = dguT.shape[1] if dguT is not None else _padded_rows(x2.shape[0], long_k=True)
                 n2T = ops.rmsnorm_apply_t(x2, layer.post_attention_layernorm.weight, rstd2, rp)
                 a0, b0 = _dw_operands(dgu, None, dyT=dguT, xT=n2T)
-                wguT = transposed_weight(wgu)
+                wguT = transposed_weight(wgu, sources=gu_params)
                 if VARIANTS["dx_pair"] and not VARIANTS["dw_tn"] and _pairable(a0, b0, dgu, wguT):
                     dn2 = torch.empty((dgu.shape[0], wguT.shape[0]), device=dev, dtype=BF16)
                     ops.gemm_pair(a0, b0, fb, bool(acc), dgu, wguT, dn2, False)   # the weight gradient's long-K tiles first
@@ -434,7 +439,7 @@ class DecoderLayerFn(Function):
             buf, acc = grad_target(att.o_proj.weight)
             if VARIANTS["dx_pair"] and not VARIANTS["dw_tn"]:
                 a0, b0 = _dw_operands(dx2, o)
-                woT = transposed_weight(att.o_proj.weight)
+                woT = transposed_weight(att.o_proj.weight, sources=(att.o_proj.weight,))
                 if _pairable(a0, b0, dx2, woT):
                     do = torch.empty((dx2.shape[0], woT.shape[0]), device=dev, dtype=BF16)
                     ops.gemm_pair(a0, b0, buf, acc, dx2, woT, do, False)
@@ -456,7 +461,10 @@ class DecoderLayerFn(Function):
         if not fuse_rope:
             ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True, pos_offset=m.pos_offset)
         wqkv = fused_weight(qkv_params)
-        dn1 = input_grad_gemm(dqkv, wqkv)
+        if VARIANTS["dw_tn"] and ops.gemm_nn_supported(dqkv, wqkv):
+            dn1 = ops.gemm_nn(dqkv, wqkv)
+        else:
+            dn1 = ops.gemm(dqkv, transposed_weight(wqkv, sources=qkv_params))
         if any(p.requires_grad for p in qkv_params):
             fb, acc, bufs = fused_grad_target(qkv_params)
             if VARIANTS["dw_tn"] or not VARIANTS["norm_t"]:
@@ -728,122 +736,169 @@ def linear(x2d, module):
 
 
 class KVCache:
-    """Post-RoPE keys and values of every decoder layer for ONE sequence: [layers, 1, max_len, Hkv*d] bf16 each.  The write
-    position lives on the device as well (pos_dev / len_dev) so that a decode step is replayable as a hipGraph."""
+    """Post-RoPE keys and values of every decoder layer for a BATCH of sequences: [layers, batch, max_len, Hkv*d] bf16 each (one sequence:
+    batch = 1).  Every row of the batch has its own length; the write positions live on the device as well (pos_dev / len_dev, int32
+    [batch]) so that a decode step -- ONE pass over the weights for all rows -- is replayable as a hipGraph."""
 
-    def __init__(self, n_layers, max_len, width, device, Hq=None, d=None):
-        self.k = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
-        self.v = torch.empty((n_layers, 1, max_len, width), device=device, dtype=BF16)
+    def __init__(self, n_layers, max_len, width, device, Hq=None, d=None, batch=1):
+        self.batch = batch
+        self.k = torch.empty((n_layers, batch, max_len, width), device=device, dtype=BF16)
+        self.v = torch.empty((n_layers, batch, max_len, width), device=device, dtype=BF16)
         self.max_len = max_len
-        self.length = 0
-        self.pos_dev = torch.zeros(1, device=device, dtype=torch.int32)       # row the next token is written to
-        self.len_dev = torch.ones(1, device=device, dtype=torch.int32)        # = pos + 1: rows visible to that token
+        self.lengths = [0] * batch                                               # host mirror of pos_dev
+        self.pos_dev = torch.zeros(batch, device=device, dtype=torch.int32)      # row the next token of sequence b is written to
+        self.len_dev = torch.ones(batch, device=device, dtype=torch.int32)       # = pos + 1: rows visible to that token
         self.ws = None
-        if Hq is not None:
-            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(1, Hq, d, max_len)), device=device, dtype=torch.float32)   # arrival counters start at 0
+        if Hq is not None:                                                       # (rows are stepped at most 8 at a time: the GEMV kernels' limit)
+            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(min(batch, 8), Hq, d, max_len)), device=device,
+                                  dtype=torch.float32)                           # arrival counters start at 0
 
-    def set_length(self, n):
-        self.length = n
-        self.pos_dev.fill_(n)
-        self.len_dev.fill_(n + 1)
+    @property
+    def length(self):
+        """rows of the longest sequence (= THE length when batch == 1)"""
+        return max(self.lengths)
+
+    @length.setter
+    def length(self, n):
+        self.lengths = [n] * self.batch
+
+    def set_length(self, n, row=None):
+        if row is None:
+            self.set_lengths([n] * self.batch)
+        else:
+            ls = list(self.lengths)
+            ls[row] = n
+            self.set_lengths(ls)
+
+    def set_lengths(self, lengths):
+        assert len(lengths) == self.batch
+        self.lengths = [int(n) for n in lengths]
+        pos = torch.tensor(self.lengths, dtype=torch.int32)
+        self.pos_dev.copy_(pos)
+        self.len_dev.copy_(pos + 1)
 
 
-def decoder_prefill(x, layers, meta, cache):
+def decoder_prefill(x, layers, meta, cache, row=0):
     """Prompt pass of a cached decode: the training-path layer forward, keeping each layer's post-RoPE k / v rows.
-    x [L, h] -> hidden rows [L, h] (pre final norm)."""
+    x [meta.B * L, h] -> hidden rows (pre final norm).  meta.B == 1: the prompt of sequence `row`; meta.B == cache.batch: all sequences
+    at once (prompts of ONE length -- the beams of a beam search, a batch without padding)."""
     nq, nk = meta.Hq * meta.d, meta.Hkv * meta.d
-    L = x.shape[0]
+    B = meta.B
+    L = x.shape[0] // B
+    assert B == 1 or (B == cache.batch and row == 0)
     for i, layer in enumerate(layers):
         params_ready(layer)
         x, saved = decoder_layer_forward(x, layer, meta)
         qkv = saved[0]
-        cache.k[i, 0, :L].copy_(qkv[:, nq:nq + nk])
-        cache.v[i, 0, :L].copy_(qkv[:, nq + nk:])
+        if B == 1:
+            cache.k[i, row, :L].copy_(qkv[:, nq:nq + nk])
+            cache.v[i, row, :L].copy_(qkv[:, nq + nk:])
+        else:
+            cache.k[i, :, :L].copy_(qkv[:, nq:nq + nk].view(B, L, nk))
+            cache.v[i, :, :L].copy_(qkv[:, nq + nk:].view(B, L, nk))
         del saved
-    cache.set_length(L)
+    if B == 1:
+        cache.set_length(L, row)
+    else:
+        cache.set_length(L)
     return x
 
 
-def decoder_decode_row(x, layers, meta, cache, cos, sin):
-    """One new row against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values; the reference's own
-    greedy loop recomputes the prefix instead, metamorph_llama.py:502-597).  x [1, h] -> [1, h]; appends at cache.length.
-    Every position-dependent input is read from device memory (cache.pos_dev / len_dev): the launch sequence is identical
-    for every token, i.e. capturable once and replayable (DecodeStepGraph)."""
-    if cache.length >= cache.max_len:
-        raise ValueError(f"KV cache full ({cache.max_len} rows)")
+def _decode_rows8(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len):
+    """<= 8 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
+    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 8), attention per row at its own length."""
     nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
         params_ready(layer)
         att, mlp = layer.self_attn, layer.mlp
         wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
         wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
-        if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0 and x.shape[0] <= 8:
+        if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0:
             # five launches per layer: RMSNorm folded into the q|k|v and gate|up GEMVs' operand reads, RoPE + cache append and SwiGLU into
             # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below)
-            qkv = ops.gemv_rope_append(x, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, cache.pos_dev, cache.k[i], cache.v[i],
+            qkv = ops.gemv_rope_append(x, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],
                                        norm_w=layer.input_layernorm.weight, eps=meta.eps)
-            o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, cache.max_len, meta.Hq, meta.Hkv, meta.d, meta.scale,
-                                workspace=cache.ws)
+            o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, max_len, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
             x2 = ops.gemv(o, att.o_proj.weight, residual=x)
             act = ops.gemv_swiglu(x2, wgu, meta.I, norm_w=layer.post_attention_layernorm.weight, eps=meta.eps)
             x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
             continue
         n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
         qkv = ops.gemv(n1, wqkv)
-        ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, cache.pos_dev, cache.k[i], cache.v[i])
-        o = ops.attn_decode(qkv[:, :nq], cache.k[i], cache.v[i], cache.len_dev, cache.max_len, meta.Hq, meta.Hkv, meta.d, meta.scale,
-                            workspace=cache.ws)
+        ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i])
+        o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, max_len, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
         x2 = ops.gemv(o, att.o_proj.weight, residual=x)
         n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
         gu = ops.gemv(n2, wgu)
         act = ops.swiglu_fwd(gu, meta.I)
         x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
-    cache.pos_dev.add_(1)
-    cache.len_dev.add_(1)
-    cache.length += 1
     return x
 
 
+def decoder_decode_row(x, layers, meta, cache, cos, sin):
+    """One new row PER SEQUENCE against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values, the whole batch in one
+    forward per step -- metamorph_llama.py:711-717; the reference's own greedy loop recomputes the prefix instead, :502-597).
+    x [batch, h] -> [batch, h]; row b is appended at cache.lengths[b].  The batch goes through the layers in ONE pass (8 rows at a time):
+    the 15 GB of LLaMA-3-8B weights are read once per step, not once per sequence.  Every position-dependent input is read from device
+    memory (cache.pos_dev / len_dev): the launch sequence is identical for every token, i.e. capturable once and replayable
+    (DecodeStepGraph)."""
+    if cache.length >= cache.max_len:
+        raise ValueError(f"KV cache full ({cache.max_len} rows)")
+    B = x.shape[0]
+    if B != cache.batch:
+        raise ValueError(f"{B} rows for a cache of {cache.batch} sequences")
+    if B <= 8:
+        y = _decode_rows8(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, cache.max_len)
+    else:
+        y = torch.cat([_decode_rows8(x[c:c + 8], layers, meta, cos, sin, cache.k[:, c:c + 8], cache.v[:, c:c + 8], cache.pos_dev[c:c + 8],
+                                     cache.len_dev[c:c + 8], cache.ws, cache.max_len) for c in range(0, B, 8)], 0)
+    cache.pos_dev.add_(1)
+    cache.len_dev.add_(1)
+    cache.lengths = [n + 1 for n in cache.lengths]
+    return y
+
+
 class DecodeStepGraph:
-    """decoder_decode_row captured ONCE as a hipGraph (~13 launches x layers per token collapse into one graph launch; the
-    per-token step is launch-bound otherwise) and replayed per token: copy the new row into `x_in`, replay, read `x_out`.
-    Falls back to eager launches if capture is not possible (functional.set_variant("decode_graph", False) forces that)."""
+    """decoder_decode_row captured ONCE as a hipGraph (5 launches x layers per step collapse into one graph launch; the
+    per-token step is launch-bound otherwise) and replayed per token: copy the new rows (one per sequence) into `x_in`, replay, read
+    `x_out`.  Falls back to eager launches if capture is not possible (functional.set_variant("decode_graph", False) forces that)."""
 
     def __init__(self, layers, meta, cache, cos, sin, h, device):
         self.args = (layers, meta, cache, cos, sin)
         self.cache = cache
-        self.x_in = torch.zeros((1, h), device=device, dtype=BF16)
+        self.x_in = torch.zeros((cache.batch, h), device=device, dtype=BF16)
         self.x_out = None
         self.graph = None
         if not VARIANTS["decode_graph"]:
             return
+        keep = list(cache.lengths)
         try:
-            keep = cache.length
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up outside capture (writes a scratch row, undone below)
                 decoder_decode_row(self.x_in, *self.args)
             torch.cuda.current_stream().wait_stream(side)
-            cache.set_length(keep)
+            cache.set_lengths(keep)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.x_out = decoder_decode_row(self.x_in, *self.args)
-            cache.length = keep                                  # capture records, it does not run: host mirror unchanged
+            cache.lengths = keep                                 # capture records, it does not run: host mirror unchanged
             self.graph = g
         except Exception as e:                                   # pragma: no cover - depends on the runtime
             import warnings
             warnings.warn(f"hipGraph capture of the decode step failed ({e!r}); using eager launches")
             self.graph = None
-            cache.set_length(keep)
+            cache.set_lengths(keep)
 
-    def step(self, row):
+    def step(self, rows):
+        """rows [batch, h] (one new row per sequence) -> their hidden rows [batch, h] (pre final norm; overwritten by the next step)"""
         if self.graph is None:
-            return decoder_decode_row(row.contiguous(), *self.args)
+            return decoder_decode_row(rows.contiguous().view(self.cache.batch, -1), *self.args)
         if self.cache.length >= self.cache.max_len:
             raise ValueError(f"KV cache full ({self.cache.max_len} rows)")
-        self.x_in.copy_(row.view(1, -1))
+        self.x_in.copy_(rows.view(self.cache.batch, -1))
         self.graph.replay()
-        self.cache.length += 1
+        self.cache.lengths = [n + 1 for n in self.cache.lengths]
         return self.x_out
 
 

@@ -91,58 +91,64 @@ class _DecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
 
-class _SeqState:
-    """Decode state of ONE sequence (a batch row / a beam): the KV cache of every layer + the captured per-token step."""
+class _SeqView:
+    """Read-only view of ONE sequence of a HipKVCache (introspection: tests, debugging): its left-padding and its cached length."""
 
-    def __init__(self):
-        self.kv = None                    # functional.KVCache
-        self.stepper = None               # functional.DecodeStepGraph
-        self.meta = None
-        self.pad = 0                      # left-padding rows of this sequence in the batch HF sees (never cached: kv.length counts real rows)
+    def __init__(self, cache, b):
+        self._c, self._b = cache, b
+
+    @property
+    def pad(self):
+        return self._c.pads[self._b]
+
+    @property
+    def length(self):
+        return self._c.kv.lengths[self._b]
 
 
 class HipKVCache(DynamicCache):
     """What `past_key_values` is under HF `generate()` (reference metamorph_llama.py:711-717, `use_customize_greedy=False`): a
-    `transformers` Cache whose payload is one `functional.KVCache` per sequence -- post-RoPE keys / values of every decoder layer in the
-    layout the decode kernels read ([layers, 1, max_len, Hkv*d] bf16, write position on the device) -- plus the captured hipGraph of the
-    per-token step.  HF only asks a cache for its length and, under beam search, to re-order its batch rows (`reorder_cache`); the tensors
-    never leave the device or change layout."""
+    `transformers` Cache whose payload is ONE `functional.KVCache` for the whole batch (batch rows / beams) -- post-RoPE keys / values of
+    every decoder layer in the layout the decode kernels read ([layers, batch, max_len, Hkv*d] bf16, per-row write positions on the device)
+    -- plus the captured hipGraph of the per-token step, which takes all rows through the decoder in ONE pass over the weights (as the
+    reference's `forward` does: the batch goes to one HF forward per step).  HF only asks a cache for its length and, under beam search,
+    to re-order its batch rows (`reorder_cache`); the tensors never leave the device or change layout."""
 
     def __init__(self, capacity=None, **kw):
         super().__init__(**kw)
         self.capacity = capacity          # rows to allocate at the first (prompt) pass; None: prompt + 1024 + 2
-        self.states = []                  # one _SeqState per sequence (batch row or beam), all of the same length
+        self.kv = None                    # functional.KVCache of the whole batch
+        self.pads = []                    # left-padding rows of every sequence in the batch HF sees (never cached: kv.lengths count real rows)
+        self.stepper = None               # functional.DecodeStepGraph
+        self.meta = None
 
     @property
-    def kv(self):
-        return self.states[0].kv if self.states else None
+    def states(self):
+        return [] if self.kv is None else [_SeqView(self, b) for b in range(len(self.pads))]
 
     def get_seq_length(self, layer_idx=0):
         # the length HF counts: padded prompt + generated tokens, the same for every row of a left-padded batch
-        return 0 if not self.states else int(self.states[0].kv.length) + self.states[0].pad
+        return 0 if self.kv is None else int(self.kv.lengths[0]) + self.pads[0]
 
     def get_max_cache_shape(self, layer_idx=0):
-        return -1 if not self.states else int(self.states[0].kv.max_len)
+        return -1 if self.kv is None else int(self.kv.max_len)
 
     def reorder_cache(self, beam_idx):
-        """Beam search: row i continues the hypothesis that lived in row beam_idx[i].  Rows that change owner get a copy of the owner's
-        keys / values (snapshot first: a row may be both a source and a target); buffers and captured graphs stay with their row."""
+        """Beam search: row i continues the hypothesis that lived in row beam_idx[i].  ONE gather over the batch dimension of the live
+        prefix (every layer, keys and values) through a temporary, written back in place: buffers -- and the captured graph that points
+        at them -- stay where they are; a row may be source and target at once."""
         idx = [int(i) for i in beam_idx.reshape(-1).tolist()]
-        if len(idx) != len(self.states):
-            raise ValueError(f"reorder_cache: {len(idx)} indices for {len(self.states)} sequences")
-        moved = [(i, j) for i, j in enumerate(idx) if i != j]
-        if not moved:
+        if len(idx) != len(self.pads):
+            raise ValueError(f"reorder_cache: {len(idx)} indices for {len(self.pads)} sequences")
+        if all(i == j for i, j in enumerate(idx)):
             return
-        snap = {}
-        for j in {j for _, j in moved}:
-            n = int(self.states[j].kv.length)
-            snap[j] = (n, self.states[j].pad, self.states[j].kv.k[:, :, :n].clone(), self.states[j].kv.v[:, :, :n].clone())
-        for i, j in moved:
-            n, pad, k, v = snap[j]
-            self.states[i].kv.k[:, :, :n].copy_(k)
-            self.states[i].kv.v[:, :, :n].copy_(v)
-            self.states[i].kv.set_length(n)
-            self.states[i].pad = pad
+        kv = self.kv
+        n = max(kv.lengths)
+        sel = torch.as_tensor(idx, dtype=torch.long, device=kv.k.device)
+        kv.k[:, :, :n].copy_(kv.k[:, :, :n].index_select(1, sel))
+        kv.v[:, :, :n].copy_(kv.v[:, :, :n].index_select(1, sel))
+        kv.set_lengths([kv.lengths[j] for j in idx])
+        self.pads = [self.pads[j] for j in idx]
 
     def crop(self, max_length):
         """HF's convention: keep the first `max_length` positions of the PADDED sequence (what get_seq_length counts); negative = drop
@@ -150,10 +156,9 @@ class HipKVCache(DynamicCache):
         max_length = int(max_length)
         if max_length < 0:
             max_length = self.get_seq_length() + max_length
-        for st in self.states:
-            keep = max(max_length - st.pad, 0)
-            if keep < st.kv.length:
-                st.kv.set_length(keep)
+        keep = [min(n, max(max_length - pad, 0)) for n, pad in zip(self.kv.lengths, self.pads)]
+        if keep != list(self.kv.lengths):
+            self.kv.set_lengths(keep)
 
 
 class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
@@ -620,26 +625,41 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         return (output, emb) if output_image else output
 
     # ------------------------------------------------------------------ HF generate() on the decode kernels (reference :711-738)
-    def _prefill_rows(self, x2d, state, capacity):
-        """[L0, h] prompt rows of ONE sequence -> hidden rows [L0, h] (pre final norm); allocates and fills `state`."""
-        dev = x2d.device
-        L0, h = x2d.shape
-        _, meta = self._decode_meta(L0)
-        cap = capacity if capacity is not None else L0 + 1024 + 2
+    def _prefill_batch(self, seqs, cache):
+        """Prompt pass of a batch: seqs = one [L_b, h] tensor of prompt rows per sequence (padding already stripped) -> their hidden rows
+        (pre final norm), one [L_b, h] tensor each; allocates and fills `cache.kv` and captures the per-token step.  Prompts of one length
+        (the beams of a beam search, an unpadded batch) go through the decoder as ONE batch; ragged prompts one after the other."""
+        dev = seqs[0].device
+        B, h = len(seqs), seqs[0].shape[1]
+        lens = [int(x.shape[0]) for x in seqs]
+        L0 = max(lens)
+        cap = cache.capacity if cache.capacity is not None else L0 + 1024 + 2
         if cap < L0 + 1:
             raise ValueError(f"HipKVCache capacity {cap} is smaller than the prompt ({L0} rows)")
         cos, sin = self.model.rope_tables(cap, dev)
+        _, meta = self._decode_meta(L0)
         meta.cos, meta.sin = cos, sin
-        state.kv = F.KVCache(len(self.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
-        state.meta = meta
-        rows = F.decoder_prefill(x2d, self.model.layers, meta, state.kv)
-        state.stepper = F.DecodeStepGraph(self.model.layers, meta, state.kv, cos, sin, h, dev)
-        return rows
+        cache.kv = F.KVCache(len(self.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d, batch=B)
+        cache.meta = meta
+        if B > 1 and all(n == L0 for n in lens):
+            _, mb = self._decode_meta(L0)
+            mb.B, mb.cos, mb.sin = B, cos, sin
+            rows = F.decoder_prefill(torch.cat(seqs, 0), self.model.layers, mb, cache.kv)
+            out = list(rows.view(B, L0, h).unbind(0))
+        else:
+            out = []
+            for b, x2d in enumerate(seqs):
+                _, mb = self._decode_meta(lens[b])
+                mb.cos, mb.sin = cos, sin
+                out.append(F.decoder_prefill(x2d.contiguous(), self.model.layers, mb, cache.kv, row=b))
+        cache.stepper = F.DecodeStepGraph(self.model.layers, meta, cache.kv, cos, sin, h, dev)
+        return out
 
-    def _decode_rows(self, x2d, state):
-        """New rows (usually one) of ONE sequence appended one at a time against its cache -> their hidden rows [n, h] (pre final norm)."""
-        outs = [state.stepper.step(x2d[i:i + 1]).clone() for i in range(x2d.shape[0])]
-        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+    def _decode_batch(self, x, cache):
+        """New rows x [B, n, h] (usually n = 1) appended against the batch's cache, every position in ONE pass for all B sequences ->
+        their hidden rows [B, n, h] (pre final norm)."""
+        outs = [cache.stepper.step(x[:, t].contiguous()).clone() for t in range(x.shape[1])]
+        return outs[0].unsqueeze(1) if len(outs) == 1 else torch.stack(outs, 1)
 
     def _rows_logits(self, rows, return_hidden=False):
         """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399); return_hidden: (logits, normed rows)."""
@@ -667,33 +687,31 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
                 raise NotImplementedError("past_key_values must be a metamorph_amd HipKVCache (generate() creates one); a foreign, "
                                           "already filled transformers Cache holds tensors in another layout")
             cache = HipKVCache()                              # an empty HF cache object: swap in ours
-        first = not cache.states
+        first = cache.kv is None
         if first:
-            cache.states = [_SeqState() for _ in range(B)]    # batch rows / beams are independent sequences, each with its own cache
-            # A batch of prompts of different lengths arrives LEFT-padded with its attention mask (the reference: HF generate derives
-            # position_ids = cumsum(mask) - 1 from it, so every row is decoded exactly as it would be alone).  Here the padding rows are never
-            # computed or cached: each sequence keeps its own length, `pad` only restores the common length HF counts.
+            # batch rows / beams are independent sequences of ONE cache.  A batch of prompts of different lengths arrives LEFT-padded with
+            # its attention mask (the reference: HF generate derives position_ids = cumsum(mask) - 1 from it, so every row is decoded
+            # exactly as it would be alone).  Here the padding rows are never computed or cached: each sequence keeps its own length,
+            # `pads` only restores the common length HF counts.
+            pads = [0] * B
             if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
                 m = attention_mask.to(torch.bool).cpu()
                 if tuple(m.shape) != (B, n):
                     raise ValueError(f"attention_mask {tuple(m.shape)} does not match the prompt batch {(B, n)}")
-                for b, st in enumerate(cache.states):
+                for b in range(B):
                     nb = int(m[b].sum())
                     if nb == 0 or not bool(m[b, n - nb:].all()):
                         raise NotImplementedError("cached decoding takes LEFT-padded prompts (valid rows at the end); right padding puts pad rows "
                                                   "between the prompt and the generated tokens in the reference as well")
-                    st.pad = n - nb
-        elif len(cache.states) != B:
-            raise ValueError(f"cache holds {len(cache.states)} sequences, the step brings {B}")
-        rows = []
-        for b, st in enumerate(cache.states):
-            if first and st.pad:
-                r = self._prefill_rows(inputs_embeds[b, st.pad:].reshape(n - st.pad, h).contiguous(), st, cache.capacity)
-                rows.append(torch.cat([r.new_zeros((st.pad, h)), r], 0))     # padding positions: rows nobody reads (HF takes logits[:, -1])
-                continue
-            x2d = inputs_embeds[b].reshape(n, h).contiguous()
-            rows.append(self._prefill_rows(x2d, st, cache.capacity) if first else self._decode_rows(x2d, st))
-        rows = rows[0] if B == 1 else torch.cat(rows, 0)
+                    pads[b] = n - nb
+            cache.pads = pads
+            outs = self._prefill_batch([inputs_embeds[b, pads[b]:].reshape(n - pads[b], h) for b in range(B)], cache)
+            # padding positions: rows nobody reads (HF takes logits[:, -1])
+            rows = torch.cat([r if not pads[b] else torch.cat([r.new_zeros((pads[b], h)), r], 0) for b, r in enumerate(outs)], 0)
+        else:
+            if len(cache.pads) != B:
+                raise ValueError(f"cache holds {len(cache.pads)} sequences, the step brings {B}")
+            rows = self._decode_batch(inputs_embeds, cache).reshape(B * n, h)
         logits, hidden = self._rows_logits(rows.contiguous(), return_hidden=True)
         logits, hidden = logits.view(B, n, -1), hidden.view(B, n, h)
         if return_dict is False:

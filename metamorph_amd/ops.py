@@ -416,6 +416,22 @@ def attn_fwd(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, out=N
     return out, lse
 
 
+def attn_fwd_debug(q2d, k2d, v2d, B, L, Hq, Hkv, d, scale, causal, seqlens=None, variant=4):
+    """attn_fwd through mm355_attn_fwd_debug (d == 128 stream, variant 4 or its serialised twin 41) -> (o, lse, rescale_counts):
+    rescale_counts int32 [B, Hq, ceil(L / 256), 4] = how often each wave took the deferred-rescale branch.  Tests only."""
+    _chk_dev(q2d, k2d, v2d)
+    pq, M, _, ldq = _rows2d(q2d)
+    pk, _, _, ldk = _rows2d(k2d)
+    pv, _, _, ldv = _rows2d(v2d)
+    assert ldv == ldk and M == B * L
+    out = torch.empty((M, Hq * d), device=q2d.device, dtype=BF16)
+    lse = torch.empty((B, Hq, L), device=q2d.device, dtype=torch.float32)
+    counts = torch.zeros((B, Hq, (L + 255) // 256, 4), device=q2d.device, dtype=torch.int32)
+    _lib.check(_L().mm355_attn_fwd_debug(pq, pk, pv, ldq, ldk, out.data_ptr(), out.stride(0), lse.data_ptr(), _p(seqlens),
+                                         B, L, Hq, Hkv, d, scale, int(causal), int(variant), counts.data_ptr(), _stream()), "mm355_attn_fwd_debug")
+    return out, lse, counts
+
+
 def attn_bwd_rope_supported(d):
     """The d == 128 kernels can rotate dq / dk back through RoPE in their epilogues (mm355_attn_bwd_rope)."""
     return d == 128
@@ -435,6 +451,8 @@ def attn_bwd(q2d, k2d, v2d, o, d_o, lse, B, L, Hq, Hkv, d, scale, causal, seqlen
     _lib.check(_L().mm355_attn_bwd_prep(o.data_ptr(), d_o.data_ptr(), o.stride(0), delta.data_ptr(), B, L, Hq, d, _stream()),
                "mm355_attn_bwd_prep")
     n_ws = int(_L().mm355_attn_bwd_ws_floats(B, L, Hq, Hkv, d, max(ldq, ldk, d_o.stride(0))))
+    if variant == 2 and Hq != Hkv:                           # the generic kernels sum a GQA group from fp32 per-query-head partials
+        n_ws = max(n_ws, 2 * B * L * Hq * d)
     ws = torch.empty(n_ws, device=o.device, dtype=torch.float32) if n_ws else None     # d = 128: per-row constants; generic-d GQA: partials
     pdq, _, _, lddq = _rows2d(dq2d)
     pdk, _, _, lddk = _rows2d(dk2d)

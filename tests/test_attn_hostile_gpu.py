@@ -1,0 +1,243 @@
+"""The default d == 128 attention kernels (attn4::fwd_kernel, attn4b::dkdv_kernel / dq_kernel -- what mm355_attn_fwd / mm355_attn_bwd launch for
+LLaMA geometry) on HOSTILE score distributions.  Needs an MI355X:  pytest -m gpu
+
+Every other attention test draws q, k ~ N(0, 0.7^2): scores of +-2, where the forward stream's deferred-rescale branch (its running row
+maximum moves only when some row grew by more than 2^6) never fires and a pre-rounded operand is invisible.  A trained checkpoint (attention
+sinks, retrieval heads: logits of +-20 .. 40) takes that branch constantly.  Here:
+
+  * inputs built so that the branch PROVABLY fires (tests/attn4_model.py: rising tile maxima, one growing row per wave, growth at the
+    threshold +- one representable step, sinks, cliffs of +80 / +110, checkpoint-like wide logits), at L in {513, 2048, 4096}, GQA 4:1 and
+    8:1, ragged lengths;
+  * the kernel's own tally of the branch (mm355_attn_fwd_debug) is compared with the CPU model of its decision rule -- equal, and non-zero;
+  * o / lse against that model (accumulation-order accuracy), against the fp32 oracle (oracle/ref_ops.attention), and against the yardstick
+    "textbook flash attention in the reference stack's bf16 precision" (what torch SDPA computes at metamorph_llama.py:349-359);
+  * the hand-placed streams bit for bit against their serialised twins (variants 4 / 41: the hazard detector) ON THESE INPUTS, forward
+    and backward, and the product entry points (variant 0) bit for bit against variant 4;
+  * dq / dk / dv against fp32 autograd through the oracle, with the same yardstick.
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import attn4_model as M  # noqa: E402
+from oracle import ref_ops as R  # noqa: E402  (the checker)
+
+DEV = "cuda"
+D = 128
+SCALE = D ** -0.5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from metamorph_amd import ops as _ops
+    from metamorph_amd import lib
+    lib.load()
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return _ops
+
+
+def pack_qkv(q, k, v):
+    """[B, L, H, d] x 3 -> the fused row-major [B * L, (Hq + 2 Hkv) d] buffer the kernels read in place"""
+    B, L, Hq, d = q.shape
+    Hkv = k.shape[2]
+    return torch.cat([q.reshape(B * L, Hq * d), k.reshape(B * L, Hkv * d), v.reshape(B * L, Hkv * d)], dim=1).contiguous()
+
+
+def oracle_fwd(q, k, v, seqlens, causal=True):
+    """fp32 oracle: o [B, L, Hq, d] fp32, lse [B, Hq, L], |s| max over visible pairs"""
+    B, L, Hq, d = q.shape
+    Hkv = k.shape[2]
+    valid = None if seqlens is None else (torch.arange(L)[None] < torch.tensor(seqlens)[:, None])
+    ref = R.attention(q.transpose(1, 2).float(), k.transpose(1, 2).float(), v.transpose(1, 2).float(), valid, causal=causal).transpose(1, 2)
+    lse = torch.empty(B, Hq, L)
+    smax = 0.0
+    for b in range(B):                                          # per sample: [Hq, L, L] fp32 at a time
+        s = torch.einsum("lhd,mhd->hlm", q[b].float(), k[b].float().repeat_interleave(Hq // Hkv, 1)) * SCALE
+        vis = torch.ones(L, L, dtype=torch.bool).tril() if causal else torch.ones(L, L, dtype=torch.bool)
+        if valid is not None:
+            vis = vis & valid[b][None, :]
+        s = s.masked_fill(~vis[None], float("-inf"))
+        lse[b] = torch.logsumexp(s, -1)
+        n = L if seqlens is None else seqlens[b]
+        if n:
+            smax = max(smax, float(s[:, :n].masked_fill(~vis[None, :n], 0).abs().max()))
+    return ref, lse, smax
+
+
+def err(x, ref):
+    d = (x.float() - ref.float())
+    return float(d.abs().max()), float(d.pow(2).mean().sqrt())
+
+
+FWD_CASES = [  # kind, B, L, Hq, Hkv, seqlens
+    ("benign", 2, 513, 4, 1, [513, 400]),
+    ("rising", 2, 513, 4, 1, [513, 400]),
+    ("rising", 1, 2048, 8, 1, None),
+    ("rising", 2, 4096, 4, 1, [4096, 3333]),
+    ("one_row", 2, 513, 4, 1, [513, 400]),
+    ("one_row", 1, 2048, 8, 1, None),
+    ("sink", 2, 513, 4, 1, [513, 400]),
+    ("sink", 1, 2048, 8, 1, None),
+    ("cliff", 2, 513, 4, 1, [513, 301]),
+    ("cliff", 1, 2048, 8, 1, None),
+    ("wide", 2, 513, 4, 1, [513, 400]),
+    ("wide", 1, 2048, 8, 1, None),
+    ("wide", 2, 4096, 4, 1, [4096, 3333]),
+    ("threshold", 3, 513, 2, 1, None),
+    ("rising", 3, 320, 2, 2, [1, 64, 65]),                      # lengths of one row / exactly one tile / one row into the second tile
+    ("wide", 2, 300, 4, 4, [0, 300]),                           # an empty sample beside a full one, no GQA
+]
+EXACT_COUNT_KINDS = ("benign", "rising", "one_row", "sink", "cliff", "threshold")   # decisions far from the threshold (or exact in fp32)
+
+
+@pytest.mark.parametrize("case", FWD_CASES, ids=lambda c: f"{c[0]}-B{c[1]}-L{c[2]}-{c[3]}q{c[4]}kv")
+def test_attn4_forward_on_hostile_scores(ops, case):
+    kind, B, L, Hq, Hkv, seqlens = case
+    q, k, v = M.hostile_inputs(kind, B, L, Hq, Hkv, seed=L + Hq)
+    dev = pack_qkv(q, k, v).to(DEV)
+    nq, nk = Hq * D, Hkv * D
+    qd, kd, vd = dev[:, :nq], dev[:, nq:nq + nk], dev[:, nq + nk:]
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
+    o4, lse4, cnt4 = ops.attn_fwd_debug(qd, kd, vd, B, L, Hq, Hkv, D, SCALE, True, sl, variant=4)
+    o41, lse41, cnt41 = ops.attn_fwd_debug(qd, kd, vd, B, L, Hq, Hkv, D, SCALE, True, sl, variant=41)
+    o0, lse0 = ops.attn_fwd(qd, kd, vd, B, L, Hq, Hkv, D, SCALE, True, sl)
+    # the placed stream == its serialised twin == what the product entry point launches, bit for bit
+    assert torch.equal(o4, o41) and torch.equal(lse4, lse41) and torch.equal(cnt4, cnt41), "placed stream differs from its serialised twin"
+    assert torch.equal(o0, o4) and torch.equal(lse0, lse4), "mm355_attn_fwd does not launch the stream under test"
+
+    om, lsem, cntm = M.attn4_forward_model(q, k, v, seqlens, True, SCALE)
+    cnt = cnt4.cpu()
+    nfire, nmodel = int(cnt.sum()), int(cntm.sum())
+    if kind in EXACT_COUNT_KINDS:
+        assert torch.equal(cnt, cntm), f"{kind}: branch tally differs from the decision-rule model\nkernel {cnt.flatten().tolist()}\nmodel  {cntm.flatten().tolist()}"
+    else:                                                       # random scores: a decision within fp32 accumulation noise of the threshold may flip
+        diff = (cnt - cntm).abs()
+        assert int(diff.max()) <= 2 and float((diff > 0).float().mean()) <= 0.05, (diff.flatten().tolist(), )
+    if kind == "benign":
+        assert nfire == 0
+    else:
+        assert nfire > 0, "the deferred-rescale branch never fired: the input is not hostile"
+    if kind == "rising":                                        # every tile after a wave's first raises every row by 8 log2 units: one branch per tile
+        for b in range(B):
+            n = L if seqlens is None else seqlens[b]
+            tw = M.last_tile_of_wave(L, n, True).clamp_min(0)
+            assert torch.equal(cnt[b], tw[None].expand(Hq, -1, -1)), (b, cnt[b].flatten().tolist(), tw.flatten().tolist())
+    if kind == "threshold":                                     # growth <= threshold: no branch; one representable step above: exactly one
+        assert int(cnt[0].sum()) == 0 and int(cnt[1].sum()) == 0
+        tw = M.last_tile_of_wave(L, L, True)
+        assert torch.equal(cnt[2], (tw >= 1).int()[None].expand(Hq, -1, -1))
+
+    ref, lser, smax = oracle_fwd(q, k, v, seqlens)
+    ofl = M.flash_bf16_forward(q, k, v, seqlens, True, SCALE)
+    o = o4.view(B, L, Hq, D).cpu()
+    lse = lse4.cpu()
+    e_model = e_ref = e_flash = (0.0, 0.0)
+    for b in range(B):
+        n = L if seqlens is None else seqlens[b]
+        if n < L:
+            assert float(o[b, n:].float().abs().max()) == 0 and float(lse[b, :, n:].abs().max()) == 0, "padding rows must be zero"
+        if n == 0:
+            continue
+        e_model = max(e_model, err(o[b, :n], om[b, :n]))
+        e_ref = max(e_ref, err(o[b, :n], ref[b, :n]))
+        e_flash = max(e_flash, err(ofl[b, :n], ref[b, :n]))
+        dl_m = float((lse[b, :, :n] - lsem[b, :, :n]).abs().max())
+        dl_r = float(((lse[b, :, :n] - lser[b, :, :n]).abs() / (1.0 + lser[b, :, :n].abs())).max())
+        assert dl_m <= 2e-4 * (1.0 + float(lsem[b, :, :n].abs().max())), ("lse vs model", b, dl_m)
+        assert dl_r <= 1e-4, ("lse vs fp32 oracle (relative to 1 + |lse|)", b, dl_r)
+    omax = float(ref.abs().max())
+    print(f"\n   {kind:9s} B={B} L={L} {Hq}/{Hkv} max|s|={smax:6.1f} branches={nfire} (model {nmodel})  o err vs model max {e_model[0]:.2e} | vs fp32 oracle "
+          f"max {e_ref[0]:.2e} rms {e_ref[1]:.2e} | flash-bf16 yardstick max {e_flash[0]:.2e} rms {e_flash[1]:.2e}  (|o| max {omax:.2f})")
+    assert e_model[0] <= 2.0 ** -6 * max(1.0, omax), ("o vs the model of its own arithmetic: more than 2 bf16 steps", e_model)
+    assert e_ref[0] <= 1.5 * e_flash[0] + 2e-3 * omax, ("o vs fp32 oracle, max", e_ref, e_flash)
+    assert e_ref[1] <= 1.5 * e_flash[1] + 2e-4 * omax, ("o vs fp32 oracle, rms", e_ref, e_flash)
+
+
+BWD_CASES = [
+    ("benign", 2, 513, 4, 1, [513, 400]),
+    ("rising", 2, 513, 4, 1, [513, 400]),
+    ("one_row", 2, 513, 4, 1, [513, 400]),
+    ("sink", 2, 513, 4, 1, [513, 400]),
+    ("cliff", 2, 513, 4, 1, [513, 301]),
+    ("wide", 2, 513, 4, 1, [513, 400]),
+    ("wide", 1, 2048, 8, 1, None),
+    ("rising", 1, 2048, 8, 1, None),
+    ("wide", 2, 300, 4, 4, [0, 300]),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=lambda c: f"{c[0]}-B{c[1]}-L{c[2]}-{c[3]}q{c[4]}kv")
+def test_attn4_backward_on_hostile_scores(ops, case):
+    kind, B, L, Hq, Hkv, seqlens = case
+    q, k, v = M.hostile_inputs(kind, B, L, Hq, Hkv, seed=L + Hq + 1)
+    g = torch.Generator().manual_seed(5)
+    do = (torch.randn(B, L, Hq, D, generator=g) * 0.5).to(torch.bfloat16)
+    if seqlens is not None:                                      # padded query rows carry no gradient
+        valid = torch.arange(L)[None] < torch.tensor(seqlens)[:, None]
+        do = do * valid[:, :, None, None]
+    dev = pack_qkv(q, k, v).to(DEV)
+    nq, nk = Hq * D, Hkv * D
+    qd, kd, vd = dev[:, :nq], dev[:, nq:nq + nk], dev[:, nq + nk:]
+    sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
+    dod = do.reshape(B * L, nq).contiguous().to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, B, L, Hq, Hkv, D, SCALE, True, sl)
+    res = {}
+    for variant in (0, 4, 41):
+        dqkv = torch.full_like(dev, float("nan"))                # every element must be written
+        ops.attn_bwd(qd, kd, vd, o, dod, lse, B, L, Hq, Hkv, D, SCALE, True, sl, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:], variant=variant)
+        assert bool(torch.isfinite(dqkv.float()).all()), f"variant {variant}: a gradient element is not finite / not written"
+        res[variant] = dqkv
+    assert torch.equal(res[4], res[41]), "placed backward streams differ from their serialised twins"
+    assert torch.equal(res[0], res[4]), "mm355_attn_bwd does not launch the streams under test"
+
+    # fp32 truth: autograd through the oracle; yardstick: the textbook bf16 flash backward
+    valid = None if seqlens is None else (torch.arange(L)[None] < torch.tensor(seqlens)[:, None])
+    qf, kf, vf = (t.transpose(1, 2).float().requires_grad_(True) for t in (q, k, v))
+    ref = R.attention(qf, kf, vf, valid, causal=True)
+    (ref * do.transpose(1, 2).float()).sum().backward()
+    _, fq, fk, fv = M.flash_bf16_backward(q, k, v, do, seqlens, True, SCALE)
+    got = res[4].cpu().float()
+    gq, gk, gv = got[:, :nq].view(B, L, Hq, D), got[:, nq:nq + nk].view(B, L, Hkv, D), got[:, nq + nk:].view(B, L, Hkv, D)
+    line = [f"\n   {kind:9s} B={B} L={L} {Hq}/{Hkv}"]
+    for name, x, y, t in (("dq", gq, fq, qf.grad.transpose(1, 2)), ("dk", gk, fk, kf.grad.transpose(1, 2)), ("dv", gv, fv, vf.grad.transpose(1, 2))):
+        if seqlens is not None:                                  # rows beyond a sample's length: exact zeros
+            for b in range(B):
+                assert float(x[b, seqlens[b]:].abs().max()) == 0 if seqlens[b] < L else True
+        nrm = float(t.norm().clamp_min(1e-20))
+        e_dev, e_fl = float((x - t).norm()) / nrm, float((y - t).norm()) / nrm
+        m_dev, m_fl, tmax = float((x - t).abs().max()), float((y - t).abs().max()), float(t.abs().max())
+        line.append(f"{name}: rel {e_dev:.2e} (flash-bf16 {e_fl:.2e}) max {m_dev:.2e} ({m_fl:.2e}, |g| max {tmax:.2e})")
+        # (where the true gradient is a near-total cancellation -- dq / dk under a dominant sink -- both are rounding noise: factors, not equality)
+        assert e_dev <= 2.0 * e_fl + 3e-3, (name, e_dev, e_fl)
+        assert m_dev <= 3.0 * m_fl + 2.0 ** -7 * tmax, (name, m_dev, m_fl, tmax)
+    print("  ".join(line))
+
+
+def test_attn4_error_against_score_magnitude(ops):
+    """The measured price list behind DESIGN.md section 4: error of the forward output against the fp32 oracle as max |s| grows (q, k ~
+    N(0, sigma^2), L = 2048, 4 query heads on one KV head), next to the bf16 flash yardstick and to the arithmetic of rounds 1-4 (scale folded
+    into a re-rounded bf16 copy of q: evaluated by the CPU model, prescale="bf16").  The kernel must stay at the yardstick at every
+    magnitude; the old arithmetic did not (3-5 x at |s| >= 50)."""
+    B, L, Hq, Hkv = 1, 2048, 4, 1
+    print()
+    for sigma in (0.7, 1.5, 2.0, 3.0, 4.0):
+        q, k, v = M._base(B, L, Hq, Hkv, 3, sigma)
+        dev = pack_qkv(q, k, v).to(DEV)
+        nq, nk = Hq * D, Hkv * D
+        o, lse, cnt = ops.attn_fwd_debug(dev[:, :nq], dev[:, nq:nq + nk], dev[:, nq + nk:], B, L, Hq, Hkv, D, SCALE, True, None, variant=4)
+        ref, lser, smax = oracle_fwd(q, k, v, None)
+        ofl = M.flash_bf16_forward(q, k, v, None, True, SCALE)
+        oold, lseold, _ = M.attn4_forward_model(q, k, v, None, True, SCALE, prescale="bf16")
+        e_dev, e_fl, e_old = err(o.view(B, L, Hq, D).cpu(), ref), err(ofl, ref), err(oold, ref)
+        l_dev = float((lse.cpu() - lser).abs().max())
+        l_old = float((lseold - lser).abs().max())
+        print(f"   sigma {sigma:3.1f} max|s| {smax:5.1f} branches {int(cnt.sum()):5d}: o err max / rms  kernel {e_dev[0]:.4f} / {e_dev[1]:.5f}   flash-bf16 {e_fl[0]:.4f} / "
+              f"{e_fl[1]:.5f}   rounds-1-4 arithmetic {e_old[0]:.4f} / {e_old[1]:.5f}   lse err kernel {l_dev:.2e}  rounds-1-4 {l_old:.2e}")
+        assert e_dev[0] <= 1.5 * e_fl[0] + 4e-3 and e_dev[1] <= 1.5 * e_fl[1] + 2e-4, (sigma, e_dev, e_fl)
+        assert l_dev <= 1e-4 * (1.0 + float(lser.abs().max()))

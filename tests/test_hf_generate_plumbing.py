@@ -1,7 +1,8 @@
 """HF `generate()` plumbing of the drop-in class on CPU (reference metamorph_llama.py:711-738, `use_customize_greedy=False`):
-GenerationMixin must drive `forward` -> `_cached_forward` with a `HipKVCache`, one prompt pass then one row per step, and emit the ids
+GenerationMixin must drive `forward` -> `_cached_forward` with a `HipKVCache`, one prompt pass then ONE pass per step for the whole batch
+(round 5: rounds 3-4 ran one pass per batch row / beam), and emit the ids
 the REFERENCE's own HF-generate run emitted on the same weights (tests/golden/hfgen_text.npz, oracle/gen_golden.py hfgen).  The three
-compute hooks of the cached path (`_prefill_rows`, `_decode_rows`, `_rows_logits`; on the GPU: decode kernels + hipGraph replay, see
+compute hooks of the cached path (`_prefill_batch`, `_decode_batch`, `_rows_logits`; on the GPU: decode kernels + hipGraph replay, see
 tests/test_model_gpu.py::test_hf_generate_matches_reference_recorded) are replaced by the CPU oracle here -- this test is about the
 control flow between transformers and the class, which needs no GPU."""
 import os
@@ -34,26 +35,40 @@ def _cpu_model(g):
             h = RM.llama_layer(sd, cfg, i, h, None, cos, sin)
         return h[0]
 
-    def prefill(x2d, state, capacity):
-        calls["prefill"] += 1
-        L0, h = x2d.shape
-        # the stand-in cache keeps the INPUT rows in `kv.k` (same fields HipKVCache.reorder_cache copies between beams)
-        state.kv = SimpleNamespace(k=torch.zeros(1, 1, capacity, h), v=torch.zeros(1, 1, capacity, 1), length=L0, max_len=capacity)
-        state.kv.set_length = lambda n, kv=state.kv: setattr(kv, "length", n)
-        state.kv.k[0, 0, :L0] = x2d.float()
-        return decoder_rows(state.kv.k[0, 0, :L0]).bfloat16()
+    def _kv(B, capacity, h):
+        # the stand-in cache keeps the INPUT rows in `kv.k` (same fields HipKVCache.reorder_cache gathers between beams)
+        kv = SimpleNamespace(k=torch.zeros(1, B, capacity, h), v=torch.zeros(1, B, capacity, 1), lengths=[0] * B, max_len=capacity)
+        kv.set_lengths = lambda ls, kv=kv: setattr(kv, "lengths", [int(n) for n in ls])
+        return kv
 
-    def decode(x2d, state):
-        calls["decode"] += 1
-        assert x2d.shape[0] == 1                                  # one new row per step
-        n = state.kv.length
-        assert n + 1 <= state.kv.max_len
-        state.kv.k[0, 0, n] = x2d[0].float()
-        state.kv.length = n + 1
-        return decoder_rows(state.kv.k[0, 0, :n + 1])[-1:].bfloat16()
+    def prefill(seqs, cache):
+        calls["prefill"] += 1                                     # ONE call for the whole batch
+        B, h = len(seqs), seqs[0].shape[1]
+        L0 = max(x.shape[0] for x in seqs)
+        cache.kv = _kv(B, cache.capacity if cache.capacity is not None else L0 + 64, h)
+        out = []
+        for b, x2d in enumerate(seqs):
+            n = x2d.shape[0]
+            cache.kv.k[0, b, :n] = x2d.float()
+            cache.kv.lengths[b] = n
+            out.append(decoder_rows(cache.kv.k[0, b, :n]).bfloat16())
+        return out
 
-    model._prefill_rows = prefill
-    model._decode_rows = decode
+    def decode(x, cache):
+        calls["decode"] += 1                                      # ONE call per step for all rows
+        B, n, h = x.shape
+        assert n == 1 and B == len(cache.kv.lengths)              # one new row per sequence and step
+        out = []
+        for b in range(B):
+            m = cache.kv.lengths[b]
+            assert m + 1 <= cache.kv.max_len
+            cache.kv.k[0, b, m] = x[b, 0].float()
+            cache.kv.lengths[b] = m + 1
+            out.append(decoder_rows(cache.kv.k[0, b, :m + 1])[-1:].bfloat16())
+        return torch.stack(out, 0)
+
+    model._prefill_batch = prefill
+    model._decode_batch = decode
     def rows_logits(rows, return_hidden=False):                   # final norm + lm_head (the product returns the normed rows on request)
         hid = R.rmsnorm(rows.float(), sd["model.norm.weight"], cfg.rms_norm_eps)
         logits = R.linear(hid, sd["lm_head.weight"]).float()
@@ -99,7 +114,8 @@ def test_hf_generate_beam_search_reproduces_reference_beams():
                          return_dict_in_generate=True, output_scores=True)
     assert out.sequences.tolist() == g["beam_sequences"].tolist(), (out.sequences.tolist(), g["beam_sequences"].tolist())
     assert torch.allclose(out.sequences_scores.float(), torch.from_numpy(g["beam_scores"]), atol=2e-3), out.sequences_scores
-    assert calls["prefill"] == 2                                  # one prompt pass per beam, then one cached row per beam and step
+    assert calls["prefill"] == 1                                  # ONE prompt pass and ONE pass per step for both beams
+    assert calls["decode"] <= int(g["max_new_tokens"])
     assert len(out.past_key_values.states) == 2
 
 
@@ -117,8 +133,8 @@ def test_hf_generate_batch_of_left_padded_prompts_reproduces_reference():
     assert out.sequences[1].tolist() == g["short_alone_sequence"].tolist()
     st = out.past_key_values.states
     n_pad = int((~mask[1]).sum())
-    assert [s.pad for s in st] == [0, n_pad] and st[0].kv.length == st[1].kv.length + n_pad      # pad rows were never cached
-    assert calls["prefill"] == 2
+    assert [s.pad for s in st] == [0, n_pad] and st[0].length == st[1].length + n_pad      # pad rows were never cached
+    assert calls["prefill"] == 1 and calls["decode"] <= 6         # the batch in one pass per step
     # the short prompt alone walks through exactly the same per-step computation
     alone = model.generate(inputs=ids[1:, n_pad:], use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009,
                            pad_token_id=128001, return_dict_in_generate=True, output_scores=True)
@@ -139,22 +155,27 @@ def test_hip_kv_cache_is_a_transformers_cache():
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
     c = HipKVCache(capacity=32)
     assert isinstance(c, Cache) and c.get_seq_length() == 0
-    def seq(n, fill):
-        kv = SimpleNamespace(k=torch.full((2, 1, 32, 4), fill), v=torch.full((2, 1, 32, 4), -fill), length=n, max_len=32)
-        kv.set_length = lambda m, kv=kv: setattr(kv, "length", m)
-        return SimpleNamespace(kv=kv, stepper=None, meta=None, pad=0)
-    c.states = [seq(7, 1.0), seq(7, 2.0), seq(7, 3.0)]
+    def batch(lengths, fills, pads=None):
+        B = len(lengths)
+        kv = SimpleNamespace(k=torch.stack([torch.full((2, 32, 4), f) for f in fills], 1), v=torch.stack([torch.full((2, 32, 4), -f) for f in fills], 1),
+                             lengths=list(lengths), max_len=32)
+        kv.set_lengths = lambda ls, kv=kv: setattr(kv, "lengths", [int(n) for n in ls])
+        c.kv, c.pads = kv, list(pads or [0] * B)
+    batch([7, 7, 7], [1.0, 2.0, 3.0])
     assert c.get_seq_length() == 7 and c.get_max_cache_shape() == 32
-    c.reorder_cache(torch.tensor([1, 1, 0]))                      # row 1 is source AND target, row 0 both as well: snapshot semantics
-    assert [float(st.kv.k[0, 0, 0, 0]) for st in c.states] == [2.0, 2.0, 1.0] and float(c.states[2].kv.v[0, 0, 6, 0]) == -1.0
-    assert float(c.states[0].kv.k[0, 0, 7, 0]) == 1.0            # rows beyond the length are left alone
+    c.reorder_cache(torch.tensor([1, 1, 0]))                      # row 1 is source AND target, row 0 both as well: gather semantics
+    assert [float(c.kv.k[0, b, 0, 0]) for b in range(3)] == [2.0, 2.0, 1.0] and float(c.kv.v[0, 2, 6, 0]) == -1.0
+    assert float(c.kv.k[0, 0, 7, 0]) == 1.0                      # rows beyond the length are left alone
     c.crop(5)
     assert c.get_seq_length() == 5
     # a left-padded row counts its padding: HF's lengths are PADDED lengths; negative = drop the last k positions
-    c.states = [seq(7, 1.0), seq(4, 2.0)]
-    c.states[1].pad = 3
+    batch([7, 4], [1.0, 2.0], pads=[0, 3])
     assert c.get_seq_length() == 7
     c.crop(6)
-    assert [st.kv.length for st in c.states] == [6, 3] and c.get_seq_length() == 6
+    assert c.kv.lengths == [6, 3] and c.get_seq_length() == 6
     c.crop(-2)
-    assert [st.kv.length for st in c.states] == [4, 1] and c.get_seq_length() == 4
+    assert c.kv.lengths == [4, 1] and c.get_seq_length() == 4
+    # beams of a left-padded batch: lengths and paddings travel with their rows
+    batch([7, 4], [1.0, 2.0], pads=[0, 3])
+    c.reorder_cache(torch.tensor([1, 1]))
+    assert c.kv.lengths == [4, 4] and c.pads == [3, 3] and [s.pad for s in c.states] == [3, 3]

@@ -6,6 +6,7 @@ SAME bf16-rounded inputs, so the only differences are the final bf16 rounding (r
 accumulation order.  Integer / index work (gathers, transposes, im2col) is compared bit-exactly.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,9 @@ pytestmark = pytest.mark.gpu
 from oracle import ref_ops as R  # noqa: E402  (the checker)
 
 DEV = "cuda"
+# kernel generations no product path selects (GEMM variants 3-6, 8, 10, 12-14, attention variant 3) exist only in a library built with
+# MM355_LEGACY_VARIANTS=1; their cases are generated only when MM355_TEST_LEGACY=1 asks for them (the default -m gpu run tests what ships)
+LEGACY = os.environ.get("MM355_TEST_LEGACY") == "1"
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +59,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (512, 384, 1152
                (200, 1152, 592), (1024, 1024, 4096)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 7, 11] + ([3, 4, 5, 6, 8, 10] if LEGACY else []))
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_plain(ops, variant, shape):
     M, N, K = shape
@@ -103,37 +107,38 @@ def test_gemm_pingpong_race_screen(ops, shape):
     close(ops.gemm(a.to(DEV), b.to(DEV), variant=11), a.float() @ b.float().t(), 1e-2, 0.02 * math.sqrt(K), f"gemm v11 {shape}")
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 256), (300, 520, 384), (2048, 2304, 256), (8192, 4096, 512), (8448, 2560, 384), (1024, 1028, 1152)])
-def test_gemm_one_wave_per_simd_stream_is_bit_identical(ops, shape):
-    """Variant 13 (csrc/gemm_st.hip: persistent workgroups of four waves, 128 x 128 wave tiles with all 256 accumulators in AGPRs, a
-    hand-placed instruction stream) and variant 14 (the same stream serialised: every LDS read / LDS-DMA piece waited for on the spot)
-    against the eight-wave ping-pong kernel: the same 16x16x32 MFMA per 32 k in ascending order and the same fused store, so every
-    output -- ragged edges, the N % 8 scalar tail, several tiles per workgroup (the persistent hand-over with the next tile's first two
-    K stages in flight during the epilogue), uneven per-XCD tile ranges, each epilogue flag -- is BIT-identical; two data sets (race screen)."""
-    M, N, K = shape
-    for rep in range(2):
-        a, b = rnd(M, K, seed=30 + rep).to(DEV), rnd(N, K, seed=40 + rep).to(DEV)
-        ref = ops.gemm(a, b, variant=11)
-        for v in (13, 14):
-            out = ops.gemm(a, b, variant=v)
-            assert torch.equal(out, ref), f"variant {v} differs from variant 11 at {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
-    a, b = rnd(M, K, seed=1, scale=0.3).to(DEV), rnd(N, K, seed=2, scale=0.3).to(DEV)
-    bias, res, c0 = rnd(N, seed=5).to(DEV), rnd(64, N, seed=6).to(DEV), rnd(M, N, seed=8).to(DEV)
-    for kw in (dict(bias=bias, gelu="erf"), dict(bias=bias, gelu="tanh"), dict(bias=bias, residual=res, res_row_mod=64), dict(accumulate=True),
-               dict(accumulate=True, out_f32=True)):
-        outs = []
-        for v in (11, 13, 14):
-            c = (c0.float() if kw.get("out_f32") else c0).clone()
-            ops.gemm(a, b, out=c, variant=v, **kw)
-            outs.append(c)
-        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), f"epilogue {sorted(kw)} at {shape}"
+if LEGACY:
+    @pytest.mark.parametrize("shape", [(256, 256, 256), (300, 520, 384), (2048, 2304, 256), (8192, 4096, 512), (8448, 2560, 384), (1024, 1028, 1152)])
+    def test_gemm_one_wave_per_simd_stream_is_bit_identical(ops, shape):
+        """Variant 13 (csrc/gemm_st.hip: persistent workgroups of four waves, 128 x 128 wave tiles with all 256 accumulators in AGPRs, a
+        hand-placed instruction stream) and variant 14 (the same stream serialised: every LDS read / LDS-DMA piece waited for on the spot)
+        against the eight-wave ping-pong kernel: the same 16x16x32 MFMA per 32 k in ascending order and the same fused store, so every
+        output -- ragged edges, the N % 8 scalar tail, several tiles per workgroup (the persistent hand-over with the next tile's first two
+        K stages in flight during the epilogue), uneven per-XCD tile ranges, each epilogue flag -- is BIT-identical; two data sets (race screen)."""
+        M, N, K = shape
+        for rep in range(2):
+            a, b = rnd(M, K, seed=30 + rep).to(DEV), rnd(N, K, seed=40 + rep).to(DEV)
+            ref = ops.gemm(a, b, variant=11)
+            for v in (13, 14):
+                out = ops.gemm(a, b, variant=v)
+                assert torch.equal(out, ref), f"variant {v} differs from variant 11 at {shape} round {rep}: max |d| = {float((out.float() - ref.float()).abs().max())}"
+        a, b = rnd(M, K, seed=1, scale=0.3).to(DEV), rnd(N, K, seed=2, scale=0.3).to(DEV)
+        bias, res, c0 = rnd(N, seed=5).to(DEV), rnd(64, N, seed=6).to(DEV), rnd(M, N, seed=8).to(DEV)
+        for kw in (dict(bias=bias, gelu="erf"), dict(bias=bias, gelu="tanh"), dict(bias=bias, residual=res, res_row_mod=64), dict(accumulate=True),
+                   dict(accumulate=True, out_f32=True)):
+            outs = []
+            for v in (11, 13, 14):
+                c = (c0.float() if kw.get("out_f32") else c0).clone()
+                ops.gemm(a, b, out=c, variant=v, **kw)
+                outs.append(c)
+            assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), f"epilogue {sorted(kw)} at {shape}"
 
 
-def test_gemm_stream_variant_rejects_short_k(ops):
-    from metamorph_amd.lib import Mm355Error
-    a, b = rnd(256, 128, seed=1).to(DEV), rnd(256, 128, seed=2).to(DEV)
-    with pytest.raises(Mm355Error):
-        ops.gemm(a, b, variant=13)                              # two K stages: the stream fetches two stages ahead (K >= 256, K % 128 == 0)
+    def test_gemm_stream_variant_rejects_short_k(ops):
+        from metamorph_amd.lib import Mm355Error
+        a, b = rnd(256, 128, seed=1).to(DEV), rnd(256, 128, seed=2).to(DEV)
+        with pytest.raises(Mm355Error):
+            ops.gemm(a, b, variant=13)                              # two K stages: the stream fetches two stages ahead (K >= 256, K % 128 == 0)
 
 
 @pytest.mark.parametrize("shapes", [((512, 768, 256), (300, 520, 384)), ((256, 256, 128), (256, 256, 128)),
@@ -192,7 +197,7 @@ def test_gemm_pair_rejects_ineligible(ops):
         ops.gemm_pair(a, b, o, False, a1, b1, o1, False)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 7, 11] + ([6, 10] if LEGACY else []))
 def test_gemm_epilogues(ops, variant):
     M, N, K = 320, 256, 128
     a, b = rnd(M, K, seed=3, scale=0.3), rnd(N, K, seed=4, scale=0.3)
@@ -879,6 +884,69 @@ def test_attn_decode(ops, case, variant):
         close(out[b], ref, 1e-2, 1e-2, f"attn_decode {case} sample {b}")
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("kind", ["wide", "sink", "cliff"])
+def test_attn_decode_on_hostile_scores(ops, kind, variant):
+    """mm355_attn_decode where a trained checkpoint puts it: logits of +-30 .. 60 (q, k ~ N(0, 3^2)), an attention sink at key 0 (+40 over
+    everything else), and a cliff -- every score at -40 except one key at +40 that sits in the LAST group of a long cache (the groups'
+    partial maxima differ by 115 log2 units when they are merged).  The kernel scales in fp32 (no pre-rounded operand), so it must stay at
+    bf16-output accuracy at any magnitude."""
+    B, Hq, Hkv, d, lens = 2, 32, 8, 128, [2500, 700]
+    Lmax = max(lens) + 3
+    g = torch.Generator().manual_seed(11)
+    sig = 3.0 if kind == "wide" else 0.5
+    q = (torch.randn(B, Hq, d, generator=g) * sig).bfloat16()
+    kc = (torch.randn(B, Lmax, Hkv, d, generator=g) * sig).bfloat16()
+    vc = torch.randn(B, Lmax, Hkv, d, generator=g).bfloat16()
+    unit = d ** -0.5 * 8.0
+    if kind != "wide":
+        q[..., 0] = 8.0
+        kc[..., 0] = 0
+    if kind == "sink":
+        kc[:, 0, :, 0] = 40.0 / unit
+    if kind == "cliff":
+        kc[..., 0] = -40.0 / unit
+        for b in range(B):
+            kc[b, lens[b] - 7, :, 0] = 40.0 / unit
+    out = ops.attn_decode(q.view(B, Hq * d).to(DEV), kc.view(B, Lmax, Hkv * d).to(DEV), vc.view(B, Lmax, Hkv * d).to(DEV),
+                          torch.tensor(lens, dtype=torch.int32, device=DEV), max(lens), Hq, Hkv, d, d ** -0.5, variant=variant)
+    for b in range(B):
+        n = lens[b]
+        kk = kc[b, :n].transpose(0, 1).float().repeat_interleave(Hq // Hkv, dim=0)      # [Hq, n, d]
+        vv = vc[b, :n].transpose(0, 1).float().repeat_interleave(Hq // Hkv, dim=0)
+        s = (q[b].float()[:, None] @ kk.transpose(1, 2)) * d ** -0.5
+        ref = (torch.softmax(s, dim=-1) @ vv).reshape(Hq * d)
+        print(f"   decode {kind} sample {b}: max |s| {float(s.abs().max()):.1f}, max err {float((out[b].float().cpu() - ref).abs().max()):.2e}")
+        close(out[b], ref, 2.0 ** -7, 2.0 ** -7, f"attn_decode {kind} sample {b}")
+
+
+def test_ce_rows_with_logits_of_80(ops):
+    """mm355_ce_rows on logits of +-80 (a confident checkpoint: the target or one wrong class dominates by e^160): loss and the in-place
+    softmax gradient against fp32; no overflow, exact zeros where the probability underflows."""
+    Rr, V, ld = 64, 5003, 5120
+    g = torch.Generator().manual_seed(3)
+    lg = torch.zeros(Rr, ld, dtype=torch.bfloat16)
+    base = torch.randn(Rr, V, generator=g) * 20.0
+    tg = torch.randint(0, V, (Rr,), generator=g, dtype=torch.int32)
+    for r in range(Rr):
+        base[r, int(tg[r]) if r % 2 == 0 else (int(tg[r]) + 1) % V] = 80.0      # even rows: the target dominates; odd rows: a wrong class does
+        base[r, (int(tg[r]) + 2) % V] = -80.0
+    lg[:, :V] = base.bfloat16()
+    lg[:, V:] = float("nan")
+    tg[7] = -100
+    x = lg[:, :V].float().requires_grad_(True)
+    keep = tg >= 0
+    loss = (torch.logsumexp(x, -1) - x.gather(1, tg.clamp_min(0).long()[:, None])[:, 0])[keep].sum()
+    loss.backward()
+    dev = lg.to(DEV).clone()
+    ls = torch.zeros(1, device=DEV)
+    ops.ce_rows_(dev, tg.to(DEV), V, 1.0, ls)
+    assert bool(torch.isfinite(dev[:, :V].float()).all()) and bool(torch.isfinite(ls).all())
+    close(ls[0], loss, 2e-3, 1e-2, "ce loss sum at |logit| = 80")
+    close(dev[:, :V], x.grad, 1e-2, 2e-4, "ce grad at |logit| = 80")
+    assert float(dev[:, V:].float().abs().max()) == 0 and float(dev[7].float().abs().max()) == 0
+
+
 @pytest.mark.parametrize("M", [1, 3, 8])
 @pytest.mark.parametrize("IK", [(64, 512), (14336, 4096), (1000, 1032)])
 def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
@@ -923,7 +991,27 @@ def test_attn_decode_counters_return_to_zero_and_replay(ops, variant, lens):
     first = ops.attn_decode(q, kc, vc, kv, 3072, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant).clone()
     for _ in range(5):
         assert torch.equal(ops.attn_decode(q, kc, vc, kv, 3072, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant), first)
-    assert int(ws[-B * Hq:].view(torch.int32).abs().max()) == 0
+    assert int(ws[:B * Hq].view(torch.int32).abs().max()) == 0
+    # the counters live at a fixed offset: the same workspace serves a call with another max_kv_len (round 4: they sat behind the records,
+    # so a shorter max_kv_len put them inside stale record floats and the merge never ran)
+    short = torch.tensor([1200, 300], dtype=torch.int32, device=DEV)
+    a = ops.attn_decode(q, kc, vc, short, 1280, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant)
+    b = ops.attn_decode(q, kc, vc, short, 1280, Hq, Hkv, d, d ** -0.5, variant=variant)
+    assert torch.equal(a, b)
+    assert torch.equal(ops.attn_decode(q, kc, vc, kv, 3072, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=variant), first)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attn_decode_empty_cache_gives_zero_rows(ops, variant):
+    B, Hq, Hkv, d = 3, 8, 2, 128
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(B, Hq * d, generator=g).bfloat16().to(DEV)
+    kc = torch.randn(B, 64, Hkv * d, generator=g).bfloat16().to(DEV)
+    vc = torch.randn(B, 64, Hkv * d, generator=g).bfloat16().to(DEV)
+    out = torch.full((B, Hq * d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.attn_decode(q, kc, vc, torch.tensor([0, 5, 0], dtype=torch.int32, device=DEV), 64, Hq, Hkv, d, d ** -0.5, out=out, variant=variant)
+    assert bool(torch.isfinite(out.float()).all()) and float(out[0].float().abs().max()) == 0 and float(out[2].float().abs().max()) == 0
+    assert float(out[1].float().abs().max()) > 0
 
 
 # ------------------------------------------------------------------------------------------------ vision

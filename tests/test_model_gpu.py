@@ -405,7 +405,9 @@ def test_paired_weight_gradient_launch_matches_separate_launches(monkeypatch):
 def test_transposed_weight_cache_under_accumulation(monkeypatch):
     """functional.transposed_weight with the cache on (the Trainer turns it on when gradient_accumulation_steps > 1): the second
     micro-batch's backward re-uses the transposed decoder weights of the first (4 transposes per layer less), gradients carry the same
-    bits as without the cache, and a parameter-generation bump (what every optimizer step does) refreshes the copies."""
+    bits as without the cache, and an in-place write to the parameters through torch refreshes the copies WITHOUT anybody bumping the
+    parameter generation (round 4 needed the bump: a stale copy was one forgotten call away; the optimizers, which write behind torch's
+    version counters, still bump)."""
     import metamorph_amd.functional as F
     cfg = tiny_cfg(num_image_tokens=4)
     sd = init_state_dict(cfg, seed=11, dtype=torch.bfloat16)
@@ -427,10 +429,9 @@ def test_transposed_weight_cache_under_accumulation(monkeypatch):
             model(**args).loss.backward()
             per_pass.append(len(calls) - n0)
         g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-        with torch.no_grad():                                # "optimizer step": parameters change, the generation moves
+        with torch.no_grad():                                # a torch-side write (no generation bump): the version counters invalidate the copies
             for p in model.model.layers.parameters():
                 p.mul_(0.5)
-        F.bump_param_generation()
         model.zero_grad(set_to_none=True)
         model(**args).loss.backward()
         g2 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -614,8 +615,8 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
     LEFT-padded, with their attention mask -- on the device through the HIP kernels (round 3 ran this path only with the compute hooks
     replaced by the oracle on the CPU).  Every row must emit what the reference recorded for the batch (hfgen_text.npz; each row
     generates what it generates alone), the padding rows are never cached, the short prompt alone walks through the same per-step
-    arithmetic (bit-identical scores from the first decoded token on: one `_SeqState` per row, same kernels on the same data), right
-    padding is refused."""
+    arithmetic (the batch is decoded in ONE pass per step since round 5 -- GEMV kernels at M = 2 rows instead of M = 1: same products per
+    row; the scores are compared at accumulation-order accuracy and reported when bit-identical), right padding is refused."""
     from oracle.ref_model import decode_fixture_state_dict
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
     g = np.load(os.path.join(GOLDEN, "hfgen_text.npz"))
@@ -630,7 +631,7 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
     assert isinstance(out.past_key_values, HipKVCache)
     st = out.past_key_values.states
     n_pad = int((~mask[1]).sum())
-    assert [s_.pad for s_ in st] == [0, n_pad] and st[0].kv.length == st[1].kv.length + n_pad      # pad rows were never computed or cached
+    assert [s_.pad for s_ in st] == [0, n_pad] and st[0].length == st[1].length + n_pad      # pad rows were never computed or cached
     alone = model.generate(inputs=ids[1:, n_pad:], output_scores=True, **kw)
     assert alone.sequences[0].tolist() == out.sequences[1].tolist()
     for step, (a, b) in enumerate(zip(alone.scores, out.scores)):
@@ -639,10 +640,49 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
             # GEMV (ops dispatch on the row count): same products, different fp32 summation order
             assert torch.allclose(a[0], b[1], rtol=1e-4, atol=2e-3), float((a[0] - b[1]).abs().max())
         else:
-            assert torch.equal(a[0], b[1]), step
+            assert torch.allclose(a[0], b[1], rtol=1e-4, atol=2e-3), (step, float((a[0] - b[1]).abs().max()))
+    print(f"\n   batched vs alone, decoded steps bit-identical: {all(torch.equal(a[0], b[1]) for a, b in list(zip(alone.scores, out.scores))[1:])}")
     with pytest.raises(NotImplementedError):                      # right padding would put pad rows between the prompt and the generated tokens
         model.generate(inputs=ids.flip(1), attention_mask=mask.flip(1), use_customize_greedy=False, do_sample=False, max_new_tokens=2,
                        eos_token_id=128009, pad_token_id=128001)
+
+
+@pytest.mark.parametrize("B", [3, 8, 11])
+def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypatch):
+    """The cached step of a batch (reference: the whole batch goes to ONE forward per step, metamorph_llama.py:711-717) takes all B rows
+    through every decoder layer in one pass -- 5 launches per layer for B <= 8 (the GEMV kernels' M), ceil(B / 8) x that beyond -- not
+    B passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
+    logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal)."""
+    import metamorph_amd.functional as F
+    cfg = tiny_cfg(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=1, num_image_tokens=4)   # d = 128
+    model = hip_model(cfg, init_state_dict(cfg, seed=21, dtype=torch.bfloat16)).eval()
+    g = torch.Generator().manual_seed(B)
+    lens = [12 + 3 * b for b in range(B)]
+    n = max(lens)
+    ids = torch.randint(3, 127000, (B, n), generator=g)
+    mask = torch.zeros(B, n, dtype=torch.bool)
+    for b, L in enumerate(lens):
+        mask[b, n - L:] = True
+    ids[~mask] = 128001
+    launches = []
+    for name in ("gemv_rope_append", "attn_decode", "gemv", "gemv_swiglu"):
+        orig = getattr(F.ops, name)
+        monkeypatch.setattr(F.ops, name, lambda *a, _o=orig, _n=name, **k: (launches.append(_n), _o(*a, **k))[1])
+    monkeypatch.setitem(F.VARIANTS, "decode_graph", False)       # eager launches: countable (the graph replays the same sequence)
+    kw = dict(use_customize_greedy=False, do_sample=False, max_new_tokens=8, eos_token_id=128009, pad_token_id=128001, return_dict_in_generate=True,
+              output_scores=True)
+    out = model.generate(inputs=ids.to(DEV), attention_mask=mask.to(DEV), **kw)
+    per_step = 5 * cfg.num_hidden_layers * ((B + 7) // 8) + ((B + 7) // 8 if B <= 8 else 1)      # + the lm_head GEMV (<= 8 rows) or GEMM
+    steps = len(out.scores) - 1
+    n_dec = len(launches)
+    print(f"\n   B={B}: {n_dec} decode-shape launches over {steps} cached steps (+ prompt pass)")
+    assert n_dec <= (steps + 1) * per_step + 2 * B, (n_dec, steps, per_step)      # one pass per step for the batch, not one per row
+    monkeypatch.undo()
+    for b in range(B):
+        alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
+        assert alone.sequences[0].tolist() == out.sequences[b].tolist(), (b, alone.sequences[0].tolist(), out.sequences[b].tolist())
+        for step, (x, y) in enumerate(zip(alone.scores, out.scores)):
+            assert torch.allclose(x[0], y[b], rtol=1e-4, atol=3e-3), (b, step, float((x[0] - y[b]).abs().max()))
 
 
 def test_bench_emits_the_driver_contract_on_device():
@@ -974,7 +1014,7 @@ def test_configs2_shape_8_frames_seq4096_against_oracle():
 
 
 # ------------------------------------------------------------------ depth beyond two layers for configs[0] and configs[2] (round 4)
-def _depth_check(cfg, ids, labels, mask, images, seed, what):
+def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidden_factor=1.15):
     """HIP model (bf16) vs the LAYER-STREAMED fp32 oracle (oracle/ref_stream.py, pinned to the plain oracle by tests/test_oracle_stream.py)
     on the same bf16-rounded weights, with the SAME streamed oracle run in bf16 -- the reference stack's own arithmetic -- as the yardstick
     for what depth does to bf16: loss at 1e-3 (north_star), final hidden rows no farther from the fp32 truth than 1.15 x the bf16
@@ -982,6 +1022,8 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what):
     max(1.5 x the bf16 oracle's own distance, 3.3e-2)."""
     from oracle.ref_stream import full_depth
     sd16 = init_state_dict(cfg, seed=seed, dtype=torch.bfloat16, fast_big=True)
+    if sd_hook is not None:
+        sd_hook(sd16)
     model = hip_model(cfg, sd16)
     model.train()
     out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), images=images.to(DEV).bfloat16())
@@ -1007,7 +1049,7 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what):
     e_h = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"][valid])
     e_16 = rel(ref16["hidden_states"].float()[valid], ref["hidden_states"][valid])
     print(f"   final hidden rows after {NL} layers vs fp32: hip {e_h:.3e}  oracle-bf16 {e_16:.3e}")
-    assert e_h <= max(1.15 * e_16, 8e-3), (e_h, e_16)
+    assert e_h <= max(hidden_factor * e_16, 8e-3), (e_h, e_16)
     params = dict(model.named_parameters())
     n, worst = 0, (0.0, "", 0.0)
     for k, g in ref["grads"].items():
@@ -1018,6 +1060,51 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what):
         n += 1
     print(f"   {n} gradient tensors (layers 0 and {NL - 1}, heads, projector), worst rel err vs fp32: hip {worst[0]:.3e} (oracle-bf16 {worst[2]:.3e}) {worst[1]}")
     return n
+
+
+def test_sharp_attention_logits_of_30_against_streamed_oracle():
+    """A model whose attention is SHARP: the q / k projections of a 2-layer decoder (4 query heads of 128 on one KV head: the default
+    d = 128 streams) scaled by 8 and 5, i.e. attention logits 40 x those of the N(0, 0.02) initialisation every other model test runs with
+    (near-uniform attention): standard deviation ~ 8, extremes beyond +-30 -- the regime of a trained checkpoint's sinks and retrieval
+    heads, where the forward stream's deferred-rescale branch fires and a pre-rounded operand would show.  Same yardsticks as the depth
+    tests: loss at 1e-3, hidden rows within 1.3 x the bf16 oracle's own distance from fp32, every gradient within max(1.5 x, 3.3e-2)."""
+    cfg = OracleConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=1,
+                       vocab_size=32002, v_layers=2, v_intermediate=144, v_image=56, num_image_tokens=16, tokenizer_model_max_length=1024,
+                       image_start_id=32000)
+    g = torch.Generator().manual_seed(77)
+    T_ = 700
+    ids = torch.randint(3, 31999, (2, T_), generator=g)
+    ids[:, 0] = 1
+    ids[:, 21], ids[:, 22], ids[:, 23] = 32000, -200, 32001
+    ids[1, 400:] = 0
+    labels = torch.full_like(ids, -100)
+    labels[0, 300:] = ids[0, 300:]
+    labels[1, 18:400] = ids[1, 18:400]
+    labels[1, 22] = -200
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    mask[1, 400:] = False
+    images = torch.randn(2, 3, 56, 56, generator=g)
+
+    def sharpen(sd):
+        for k in sd:
+            if k.endswith("self_attn.q_proj.weight"):
+                sd[k] = (sd[k].float() * 8.0).to(sd[k].dtype)
+            elif k.endswith("self_attn.k_proj.weight"):
+                sd[k] = (sd[k].float() * 5.0).to(sd[k].dtype)
+
+    # how sharp: layer-0 logits of the oracle on these weights (printed, and required to reach the regime the test is named after)
+    sd = init_state_dict(cfg, seed=5, dtype=torch.bfloat16, fast_big=True)
+    sharpen(sd)
+    x = sd["model.embed_tokens.weight"].float()[ids[0, 24:]]
+    x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps) * sd["model.layers.0.input_layernorm.weight"].float()
+    qh = (x @ sd["model.layers.0.self_attn.q_proj.weight"].float().t()).view(-1, 4, 128)
+    kh = (x @ sd["model.layers.0.self_attn.k_proj.weight"].float().t()).view(-1, 1, 128)
+    s0 = torch.einsum("lhd,md->hlm", qh, kh[:, 0]) * 128 ** -0.5
+    print(f"\n   layer-0 attention logits (before RoPE): std {float(s0.std()):.1f}, extremes {float(s0.min()):.1f} .. {float(s0.max()):.1f}")
+    assert float(s0.abs().max()) >= 30.0
+    # (sharp softmaxes amplify every bf16 rounding upstream of them: the bf16 oracle itself sits 5 % (hidden) / 5 - 20 % (gradients) from fp32
+    # here -- measured on the CPU -- and two equally good roundings differ by chance, hence 1.3 x instead of the depth tests' 1.15 x)
+    assert _depth_check(cfg, ids, labels, mask, images, seed=5, what="sharp attention (logits x 40)", sd_hook=sharpen, hidden_factor=1.3) >= 20
 
 
 def test_configs0_tinyllama_full_depth_22_layers_against_streamed_oracle():

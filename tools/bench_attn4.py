@@ -13,6 +13,20 @@ from metamorph_amd import ops
 DEV = "cuda"
 
 
+def _base_variant():
+    """the comparison kernels: attn3 (round 2's d == 128 kernels) when the library was built with MM355_LEGACY_VARIANTS=1, else the generic attn2"""
+    from metamorph_amd.lib import Mm355Error
+    x = torch.zeros(64, 3 * 128, device=DEV, dtype=torch.bfloat16)
+    try:
+        ops.attn_fwd(x[:, :128], x[:, 128:256], x[:, 256:], 1, 64, 1, 1, 128, 128 ** -0.5, True, None, variant=3)
+        return 3
+    except Mm355Error:
+        return 2
+
+
+BASE = None
+
+
 def ref_attention(q, k, v, seqlens, causal):
     """q [B, L, Hq, d] etc. (float32 on the device) -> o [B, L, Hq, d], lse [B, Hq, L]"""
     B, L, Hq, d = q.shape
@@ -42,7 +56,7 @@ def run_case(B, L, Hq, Hkv, causal, seqlens, seed=0, full_ref=True):
     qkv = (torch.randn(B * L, (Hq + 2 * Hkv) * d, generator=g) * 0.7).bfloat16().to(DEV)
     q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
     sl = torch.tensor(seqlens, dtype=torch.int32, device=DEV) if seqlens else None
-    o3, l3 = ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, causal, sl, variant=3)
+    o3, l3 = ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, causal, sl, variant=BASE)
     res = {}
     for var in (41, 4):
         o = torch.full((B * L, Hq * d), float("nan"), device=DEV, dtype=torch.bfloat16)
@@ -101,18 +115,20 @@ def timeit(fn, it=10):
     return s.elapsed_time(e) / it
 
 
-def bench(B, L, Hq, Hkv, causal=True, variants=(3, 4, 41)):
+def bench(B, L, Hq, Hkv, causal=True, variants=(0, 4, 41)):
     d = 128
     qkv = (torch.randn(B * L, (Hq + 2 * Hkv) * d, device=DEV) * 0.5).bfloat16()
     q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
     fl = 4.0 * B * Hq * L * L * d / (2 if causal else 1)
     out = torch.empty((B * L, Hq * d), device=DEV, dtype=torch.bfloat16)
-    for var in variants:
+    for var in [BASE if v == 0 else v for v in variants]:
         ms = timeit(lambda: ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, causal, None, out=out, variant=var))
         print(f"[bench B{B} L{L} H{Hq}/{Hkv} causal={int(causal)}] variant {var}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
+    BASE = _base_variant()
+    print(f"comparison kernels: variant {BASE}", flush=True)
     quick = "--quick" in sys.argv
     cases = [  # B, L, Hq, Hkv, causal, seqlens
         (1, 64, 2, 1, True, None),
@@ -145,12 +161,12 @@ if __name__ == "__main__":
     qkv = qkv.bfloat16().to(DEV)
     q2, k2, v2 = qkv[:, :Hq * d], qkv[:, Hq * d:(Hq + Hkv) * d], qkv[:, (Hq + Hkv) * d:]
     ro, rl = ref_attention(q2.float().view(B, L, Hq, d), k2.float().view(B, L, Hkv, d), v2.float().view(B, L, Hkv, d), None, True)
-    for var in (3, 41, 4):
+    for var in (BASE, 41, 4):
         o4, l4 = ops.attn_fwd(q2, k2, v2, B, L, Hq, Hkv, d, d ** -0.5, True, None, variant=var)
         print(f"[spike] variant {var}: |o - fp32|max={float((o4.float() - ro.reshape(B * L, -1)).abs().max()):.3e} lse {float((l4 - rl).abs().max()):.3e}", flush=True)
     if not quick:
         bench(4, 2048, 32, 8)
         bench(16, 2048, 32, 8)
-        bench(16, 2048, 32, 8, variants=(3, 4))
-        bench(8, 4096, 32, 8, variants=(3, 4))
-        bench(16, 2048, 64, 8, causal=False, variants=(3, 4))
+        bench(16, 2048, 32, 8, variants=(0, 4))
+        bench(8, 4096, 32, 8, variants=(0, 4))
+        bench(16, 2048, 64, 8, causal=False, variants=(0, 4))

@@ -12,6 +12,20 @@ from metamorph_amd import ops
 DEV = "cuda"
 
 
+def _base_variant():
+    """the comparison kernels: attn3 (round 2's d == 128 kernels) when the library was built with MM355_LEGACY_VARIANTS=1, else the generic attn2"""
+    from metamorph_amd.lib import Mm355Error
+    x = torch.zeros(64, 3 * 128, device=DEV, dtype=torch.bfloat16)
+    try:
+        ops.attn_fwd(x[:, :128], x[:, 128:256], x[:, 256:], 1, 64, 1, 1, 128, 128 ** -0.5, True, None, variant=3)
+        return 3
+    except Mm355Error:
+        return 2
+
+
+BASE = None
+
+
 def ref_grads(q, k, v, do, seqlens, causal):
     """fp32 autograd on the device; q [B, L, Hq, d] ..."""
     B, L, Hq, d = q.shape
@@ -54,7 +68,7 @@ def run_case(B, L, Hq, Hkv, causal, seqlens, seed=0, rope=False):
         cos, sin = ops.rope_table(L + 32, d, 500000.0, DEV)
         rp = (cos, sin, torch.tensor([3, 0, 29][:B], dtype=torch.int32, device=DEV))
     res = {}
-    for var in (3, 41, 4):
+    for var in (BASE, 41, 4):
         dqkv = torch.full_like(qkv, float("nan"))
         ops.attn_bwd(q2, k2, v2, o, do, lse, B, L, Hq, Hkv, d, d ** -0.5, causal, sl, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:], rope=rp, variant=var)
         torch.cuda.synchronize()
@@ -72,12 +86,12 @@ def run_case(B, L, Hq, Hkv, causal, seqlens, seed=0, rope=False):
         msg = f"[{tag}] variant {var}: finite={fin}"
         good = fin
         for name, sl_ in parts.items():
-            e3 = float((x[:, sl_].float() - res[3][:, sl_].float()).abs().max())
-            scale_ = float(res[3][:, sl_].float().abs().max())
+            e3 = float((x[:, sl_].float() - res[BASE][:, sl_].float()).abs().max())
+            scale_ = float(res[BASE][:, sl_].float().abs().max())
             msg += f" {name}: |x - attn3|max={e3:.2e} (max |x| {scale_:.2e})"
             if refs is not None:
                 er = float((x[:, sl_].float() - refs[:, sl_]).abs().max())
-                e3r = float((res[3][:, sl_].float() - refs[:, sl_]).abs().max())
+                e3r = float((res[BASE][:, sl_].float() - refs[:, sl_]).abs().max())
                 msg += f" vs fp32 {er:.2e} (attn3 {e3r:.2e})"
                 good &= er <= max(2.0 * e3r, 2e-2 * max(scale_, 1.0))
             else:
@@ -85,7 +99,7 @@ def run_case(B, L, Hq, Hkv, causal, seqlens, seed=0, rope=False):
         print(msg + ("  OK" if good else "  **MISMATCH**"), flush=True)
         if not good:
             ok = False
-            base = refs if refs is not None else res[3].float()
+            base = refs if refs is not None else res[BASE].float()
             diff = torch.nan_to_num((x.float() - base).abs(), nan=1e9).view(B, L, ld)
             for name, sl_ in parts.items():
                 dd = diff[:, :, sl_]
@@ -111,7 +125,7 @@ def timeit(fn, it=5):
     return s.elapsed_time(e) / it
 
 
-def bench(B, L, Hq, Hkv, causal=True, variants=(3, 4)):
+def bench(B, L, Hq, Hkv, causal=True, variants=(0, 4)):
     d = 128
     ld = (Hq + 2 * Hkv) * d
     nq, nk = Hq * d, Hkv * d
@@ -121,12 +135,14 @@ def bench(B, L, Hq, Hkv, causal=True, variants=(3, 4)):
     do = torch.randn_like(o)
     dqkv = torch.empty_like(qkv)
     fl = 2.5 * 4.0 * B * Hq * L * L * d / (2 if causal else 1)
-    for var in variants:
+    for var in [BASE if v == 0 else v for v in variants]:
         ms = timeit(lambda: ops.attn_bwd(q2, k2, v2, o, do, lse, B, L, Hq, Hkv, d, d ** -0.5, causal, None, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:], variant=var))
         print(f"[bench bwd B{B} L{L} H{Hq}/{Hkv} causal={int(causal)}] variant {var}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (all of the backward incl. delta)", flush=True)
 
 
 if __name__ == "__main__":
+    BASE = _base_variant()
+    print(f"comparison kernels: variant {BASE}", flush=True)
     quick = "--quick" in sys.argv
     cases = [  # B, L, Hq, Hkv, causal, seqlens
         (1, 64, 2, 1, True, None),

@@ -27,3 +27,27 @@ for use_cache in ((True,) if os.environ.get("CACHED_ONLY") else (True, False)):
         torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
         per = (dt2 - dt) / max(out2.numel() - out.numel(), 1)
         print(f"   decode step alone: {per*1e3:.3f} ms/token = {wbytes/per/1e12:.2f} TB/s of weights; prompt pass + first token ~ {(dt - per*out.numel())*1e3:.1f} ms", flush=True)
+
+# ---- the batched cached step (round 5: all rows of a batch / all beams in ONE pass over the weights): ms per step by batch size
+if not os.environ.get("NO_BATCH"):
+    import metamorph_amd.functional as F
+    with torch.no_grad():
+        for B in (1, 2, 4, 8, 16):
+            _, meta = model._decode_meta(L0)
+            cap = L0 + 2 * new + 4
+            cos, sin = model.model.rope_tables(cap, dev)
+            meta.cos, meta.sin = cos, sin
+            kv = F.KVCache(len(model.model.layers), cap, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d, batch=B)
+            kv.k.normal_(0, 0.5); kv.v.normal_(0, 0.5)
+            kv.set_lengths([L0 - 7 * b for b in range(B)])                   # ragged lengths, as a left-padded batch has them
+            st = F.DecodeStepGraph(model.model.layers, meta, kv, cos, sin, h, dev)
+            rows = (torch.randn(B, h, device=dev) * 0.02).bfloat16()
+            for _ in range(3):
+                st.step(rows)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(new):
+                st.step(rows)
+            torch.cuda.synchronize(); per = (time.perf_counter() - t0) / new
+            print(f"batched step B={B:2d}: {per*1e3:.3f} ms/step = {per/B*1e3:.3f} ms per token and sequence; weights at {wbytes/per/1e12:.2f} TB/s "
+                  f"({'graph' if st.graph is not None else 'eager'})", flush=True)
+            del st, kv

@@ -9,11 +9,11 @@ hipcc will not build that interleave (256 registers + 300 s
 stream is written as one `asm volatile` per instruction in program order ON LITERAL REGISTERS:
 
     a[0:127]    O^T accumulators, block (db, qb) at 16 * (db * 2 + qb)
-    a[128:191]  Q~ fragments (B operands of the score MFMAs), (qb, ks) at 128 + 4 * (qb * 8 + ks)
+    a[128:191]  Q fragments as stored (B operands of the score MFMAs), (qb, ks) at 128 + 4 * (qb * 8 + ks)
     a[192:223]  K fragment ring (8 fragments, (ks % 4) * 2 + kb), filled by ds_read_b128
     a[224:255]  V fragment ring (8 fragments, (kstep % 2) * 4 + db), filled by ds_read_b64_tr_b16 pairs
     v[64:191]   two score tiles S[parity][kb][qb] (16 registers each)
-    v[192:223]  -m (running row maximum, log2 domain) as the C operand of a score chain, one 16-register tuple per qb
+    v[192:223]  -m (running row maximum, in units of the RAW dot product q . k) as the C operand of a score chain, one 16-register tuple per qb
     v[224:255]  P^T fragments (bf16 pairs), (kstep, qb) at 224 + 4 * (kstep * 2 + qb)
     v[0:63]     everything hipcc allocates itself (the kernel carries amdgpu_num_vgpr(64); tools/audit_attn4.py checks the emitted
                 code object for any compiler instruction that touches v64+ or an accumulator register)
@@ -24,8 +24,15 @@ Emitted blocks (included inside attn4::fwd_kernel, which declares the few compil
     head         QK(0), row maxima + first maximum                                   (step -1)
     loop<p>      QK(t + 1) || softmax-finish(t)   then   PV(t) || row maxima(t + 1)     (step t, parity p = t & 1)
     tail<p>      softmax-finish(tw) then PV(tw)                                      (a wave's last tile)
-    zero_o, q_load, q_pre01, epi_read   accumulator initialisation / raw Q rows -> v[128:191] / Q~ of d-steps 0, 1 / read-out
-                 (the Q~ fragments of d-steps 2..7 are scaled and placed under the head's score MFMAs)
+    zero_o, q_load, q_pre01, epi_read   accumulator initialisation / Q rows -> v[128:191] / Q fragments of d-steps 0, 1 -> accumulator file / read-out
+                 (the fragments of d-steps 2..7 are placed under the head's score MFMAs)
+
+Arithmetic (round 5): the score chains run on the operands AS STORED -- s' = q . k - m is the fp32 product of the bf16 values the reference's
+SDPA sees -- and the softmax scale enters on the fp32 side: P = exp2((scale * log2 e) * s'), one `v_pk_mul_f32` per PAIR of scores right in
+front of their two `v_exp_f32` (the constant pair sits in SGPRs).  Rounds 1-4 multiplied q by scale * log2 e and re-rounded it to bf16 before
+the MFMA: one rounding more than the reference has, a score error that grows with |s| (measured: 3x the error of a textbook bf16 flash
+attention at |s| = 50).  The row sums are kept as PACKED pairs (`v_pk_add_f32`), which pays for the new multiplies:
+the number of VALU instructions per MFMA gap is what it was.
 `safe_*` are the same streams with every LDS read waited for at once and every MFMA followed by 32 wait states: the debugging build that
 separates a placement / hazard defect from a logic defect (tools/bench_attn4.py runs both).
 """
@@ -160,8 +167,9 @@ def emit_decide(st, nxt, head):
         st.raw("  {")
     else:                                                    # later tiles: s' is relative to the running maximum; move it only when a row grew by > 2^THR
         st.raw("  if (grow_ != 0) {")
+        st.raw("    ATTN4_COUNT_RESCALE();")                # wave-uniform tally of this branch (scalar ALU): tests assert it fired (Args::dbg)
         st.raw("    rm_[0] = fmaxf(rm_[0], 0.f); rm_[1] = fmaxf(rm_[1], 0.f);")
-        st.raw("    const float al_[2] = {__builtin_amdgcn_exp2f(-rm_[0]), __builtin_amdgcn_exp2f(-rm_[1])};")
+        st.raw("    const float al_[2] = {__builtin_amdgcn_exp2f(-rm_[0] * sl2), __builtin_amdgcn_exp2f(-rm_[1] * sl2)};")   # rm_ is in raw q . k units
         st.asm("s_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15\\n\\ts_nop 15")    # the P V MFMAs drain
         st.raw("    float t0_, t1_;")
         for qb in range(2):
@@ -171,7 +179,7 @@ def emit_decide(st, nxt, head):
                     st.asm("v_accvgpr_read_b32 %%0, a%d\\n\\tv_accvgpr_read_b32 %%1, a%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
                            "v_accvgpr_write_b32 a%d, %%0\\n\\tv_accvgpr_write_b32 a%d, %%1" % (a0, a0 + 1, a0, a0 + 1),
                            '"=&v"(t0_), "=&v"(t1_)', '"v"(al_[%d])' % qb)
-            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d]; LS[%d][2] *= al_[%d]; LS[%d][3] *= al_[%d];" % ((qb, qb) * 4))
+            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d];" % ((qb, qb) * 2))
     for qb in range(2):
         for kb in range(2):
             for r in range(16):
@@ -236,6 +244,11 @@ def gen(mode, par, safe):
             _, kb, qb, r = f
             v = s_blk(par, kb, qb) + r
             st.asm("v_exp_f32 v%d, v%d" % (v, v))
+        elif kind == "scl":                                  # s' (raw q . k units) -> log2 domain, two scores per instruction; the constant pair lives in SGPRs
+            _, kb, qb, r = f
+            v = s_blk(par, kb, qb) + r
+            assert v % 2 == 0
+            st.asm("v_pk_mul_f32 %s, %s, %%0 op_sel_hi:[1,0]" % (vreg(v, 2), vreg(v, 2)), "", '"s"(sl2x2_)')    # both lanes take the pair's LOW half (the form hipcc emits for a uniform scalar)
         elif kind == "cvt":
             pair = f[1]
             kstep, qb, kb, r = elem(2 * pair)
@@ -246,9 +259,11 @@ def gen(mode, par, safe):
             kread_id[(ks, kb)] = kread(ks, kb, kslot_cur)
         elif kind == "vread":
             vstmt(f[1], f[2])
-        elif kind == "add":
+        elif kind == "add":                                  # packed row sums: elements r, r + 1 -> the two lanes of LS[qb][(r >> 1) & 1] (four partial sums per row)
             _, kb, qb, r = f
-            st.asm("v_add_f32 %%0, %%0, v%d" % (s_blk(par, kb, qb) + r), '"+v"(LS[%d][%d])' % (qb, r & 3), "")    # four partial sums: no dependent chain
+            v = s_blk(par, kb, qb) + r
+            assert v % 2 == 0
+            st.asm("v_pk_add_f32 %%0, %%0, %s" % vreg(v, 2), '"+v"(LS[%d][%d])' % (qb, (r >> 1) & 1), "")
         elif kind == "max":
             _, qb, kb, step = f
             s = s_blk(nxt, kb, qb)
@@ -275,13 +290,13 @@ def gen(mode, par, safe):
     a_fill = [[] for _ in range(32)]
     if sm:
         for a in range(32):
+            kstep, qb, kb, r = elem(2 * a)
+            a_fill[a].append(("scl", kb, qb, r))             # the pair's scaling, then its two exponentials
             for e in (2 * a, 2 * a + 1):
                 kstep, qb, kb, r = elem(e)
                 a_fill[a].append(("exp", kb, qb, r))
             if a >= 1:
                 a_fill[a].append(("cvt", a - 1))
-                kstep, qb, kb, r = elem(a - 1)               # row sums of elements 0..30: one per gap, behind their exponentials
-                a_fill[a].append(("add", kb, qb, r))
     if qk:
         for j in range(4):
             for kb in range(2):
@@ -316,15 +331,15 @@ def gen(mode, par, safe):
 
     # ------------------------------------------------------------------ phase B: 32 gaps
     b_fill = [[] for _ in range(32)]
-    if sm:                                                   # row sums: elements 31..63 here (0..30 went beside their exponentials in phase A)
-        e = 31
+    if sm:                                                   # row sums: the 32 pairs, one or two per gap (phase A carries the scalings instead)
+        pr = 0
         for b in range(24):
             for _ in range(1 if (pv and b % 2 == 0) else 2):
-                if e < 64:
-                    kstep, qb, kb, r = elem(e)
+                if pr < 32:
+                    kstep, qb, kb, r = elem(2 * pr)
                     b_fill[b].append(("add", kb, qb, r))
-                    e += 1
-        assert e == 64
+                    pr += 1
+        assert pr == 32
     if pv:
         for k in range(1, 4):
             for db in range(4):
@@ -396,10 +411,9 @@ def q_raw(qb, ks):
 
 
 def emit_prescale(st, qb, ks, i):
-    """word i of fragment (qb, ks): two bf16 -> * scale*log2(e) -> bf16 pair -> accumulator register (t0_, t1_: compiler temporaries)"""
+    """word i of fragment (qb, ks): the two bf16 as stored -> accumulator register (no arithmetic: the softmax scale is applied in fp32, see header)"""
     v, a = q_raw(qb, ks) + i, q_frag(qb, ks) + i
-    st.asm("v_lshlrev_b32 %%0, 16, v%d\\n\\tv_and_b32 %%1, 0xffff0000, v%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
-           "v_cvt_pk_bf16_f32 %%0, %%0, %%1\\n\\tv_accvgpr_write_b32 a%d, %%0" % (v, v, a), '"=&v"(t0_), "=&v"(t1_)', '"v"(sl2)')
+    st.asm("v_accvgpr_write_b32 a%d, v%d" % (a, v))
 
 
 def gen_q_load():
@@ -425,7 +439,8 @@ def main():
     if "--abl" in sys.argv:
         names = sys.argv[sys.argv.index("--abl") + 1]
         ABL.update(names.split(","))
-        OUT = OUT + "_" + names.replace(",", "_")
+        # ablation streams are scratch: build/<dir>/ (git-ignored), never next to the product streams
+        OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "attn4_abl", "attn4_gen_" + names.replace(",", "_"))
     os.makedirs(OUT, exist_ok=True)
     report = []
     for safe in (False, True):

@@ -7,13 +7,14 @@ v[0:63]); read that header first.  Both backward kernels are the same machine:
     a wave keeps ONE side of the products in the accumulator file for its whole life (the "persistent" B operands) and streams tiles of
     the other side through LDS (a four-slot ring filled by LDS-DMA).  Per tile:
       phase A   32 MFMAs:  X(t+1) = Xsrc . P0^T  and  Y(t+1) = Ysrc . P1^T   (A operands: ds_read_b128 fragments of the tile)
-                ||  P = exp2(X(t)),  dS = P * Y(t),  packing to bf16          (X / Y arrive already shifted: C = -lse*log2(e) / -delta)
+                ||  P = exp2(c X(t)),  dS = P * Y(t),  packing to bf16        (X / Y arrive already shifted: C = -lse / scale, -delta;
+                                                                                c = scale * log2 e enters in fp32: one v_pk_mul_f32 per pair of scores)
       phase B   the gradient products of tile t, A operands gathered TRANSPOSED from the same tile (ds_read_b64_tr_b16 pairs)
 
-    kind 'kv' (dK / dV):  persistent K~ = bf16(K * scale*log2 e) and V of the wave's 32 keys; tiles = 64 query rows of (Q, dO, -lse2, -delta);
+    kind 'kv' (dK / dV):  persistent K (as stored) and V of the wave's 32 keys; tiles = 64 query rows of (Q, dO, -lse / scale, -delta);
                           X = S [q][key], Y = dP;  phase B: dV^T += dO^T P (16 MFMAs), dK^T += Q^T dS (16 MFMAs); the C operands of the
                           score chains are pre-loaded from the tile's statistics rows straight into the chain's registers (ds_read_b128)
-    kind 'q'  (dQ):       persistent Q~ and dO of the wave's 32 query rows (+ two 16-register tuples -lse2 / -delta as first C operands);
+    kind 'q'  (dQ):       persistent Q (as stored) and dO of the wave's 32 query rows (+ two 16-register tuples -lse / scale, -delta as first C operands);
                           tiles = 64 keys of (K, V);  X = S^T [key][q], Y = dP^T;  phase B: dQ^T += K^T dS^T (16 MFMAs)
 
 Register map (a = accumulator file):
@@ -23,6 +24,11 @@ Register map (a = accumulator file):
          v[80:207] X / Y of two tiles | v[208:223] dS fragments | v[224:239] -lse2 tuple | v[240:255] -delta tuple   (hipcc: v[0:79])
 
     python tools/gen_attn4_bwd.py          # rewrites metamorph_amd/csrc/attn4_bwd_gen/{kv,q}_*.inc
+
+Arithmetic (round 5, as in the forward stream): the score chains run on q and k AS STORED, X = q . k - lse / scale in fp32, and the softmax
+scale enters on the fp32 side, P = exp2((scale * log2 e) * X).  Rounds 1-4 kept a re-rounded bf16 copy of the persistent operand multiplied
+by scale * log2 e (K~ in the dK / dV kernel, Q~ in the dQ kernel -- so the two kernels and the forward recomputed three slightly different
+P from the same q, k): one rounding more than the reference has, with a score error growing with |s|.
 """
 import os
 import sys
@@ -227,6 +233,8 @@ def gen(K, mode, u4, safe):
 
         for e in range(32):
             ph, g = slot_of[e]
+            if e % 2 == 0:
+                put(ph, g, ("scl", e >> 1))                  # the pair's scaling (raw q . k units -> log2 domain) ahead of its exponentials
             put(ph, g, ("exp", e))
             put(ph, g + 1, ("mul", e))
         for p in range(16):
@@ -250,6 +258,11 @@ def gen(K, mode, u4, safe):
             kstep, i, r = elem(f[1])
             v = K.x(par, i) + r
             st.asm("v_exp_f32 v%d, v%d" % (v, v))
+        elif kind == "scl":
+            kstep, i, r = elem(2 * f[1])
+            v = K.x(par, i) + r
+            assert v % 2 == 0
+            st.asm("v_pk_mul_f32 %s, %s, %%0 op_sel_hi:[1,0]" % (vreg(v, 2), vreg(v, 2)), "", '"s"(sl2x2_)')    # both lanes take the pair's LOW half
         elif kind == "mul":
             kstep, i, r = elem(f[1])
             st.asm("v_mul_f32 v%d, v%d, v%d" % (K.y(par, i) + r, K.y(par, i) + r, K.x(par, i) + r))
@@ -366,23 +379,19 @@ def gen_pers_load(K):
 
 
 def gen_pers_place(K):
-    """operand 0 scaled by scale * log2(e) and re-rounded to bf16, operand 1 as it is -> their accumulator registers"""
+    """both persistent operands as stored -> their accumulator registers (no arithmetic: the softmax scale is applied in fp32, see header)"""
     st = Stream(False)
     for p in range(2):
         for ks in range(8):
             for i in range(4):
                 v = K.XY + 32 * p + 4 * ks + i
                 a = (K.PERS0 if p == 0 else K.PERS1) + 4 * ks + i
-                if p == 0:
-                    st.asm("v_lshlrev_b32 %%0, 16, v%d\\n\\tv_and_b32 %%1, 0xffff0000, v%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
-                           "v_cvt_pk_bf16_f32 %%0, %%0, %%1\\n\\tv_accvgpr_write_b32 a%d, %%0" % (v, v, a), '"=&v"(t0_), "=&v"(t1_)', '"v"(sl2)')
-                else:
-                    st.asm("v_accvgpr_write_b32 a%d, v%d" % (a, v))
+                st.asm("v_accvgpr_write_b32 a%d, v%d" % (a, v))
     return st
 
 
 def gen_tuple_write(K):
-    """q: -lse2 / -delta of the lane's query row -> all 16 registers of the two C tuples"""
+    """q: -lse / scale and -delta of the lane's query row -> all 16 registers of the two C tuples"""
     st = Stream(False)
     for r in range(16):
         st.asm("v_mov_b32 v%d, %%0" % (K.NL + r), "", '"v"(nl_)')
@@ -395,7 +404,8 @@ def main():
     if "--abl" in sys.argv:
         names = sys.argv[sys.argv.index("--abl") + 1]
         ABL.update(names.split(","))
-        OUT = OUT + "_" + names.replace(",", "_")
+        # ablation streams are scratch: build/<dir>/ (git-ignored), never next to the product streams
+        OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "attn4_abl", "attn4_bwd_gen_" + names.replace(",", "_"))
     os.makedirs(OUT, exist_ok=True)
     report = []
     for kname in ("kv", "q"):
