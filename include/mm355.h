@@ -274,7 +274,8 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 /* ------------------------------------------------------------------------------------------------
  * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
  * re-runs the prefix every step).  HBM-bound streaming kernels.
- *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 8 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16); flags BIAS /
+ *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16; one or two rows run on the
+ *         vector ALU, 3 .. 16 rows on v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout); flags BIAS /
  *         GELU_ERF / GELU_TANH / RESIDUAL / OUT_F32 as for the GEMM.
  *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
  *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
@@ -308,7 +309,8 @@ int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cac
                       mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,
                       float* workspace, void* stream);
 /* tests / tools: variant 0 = as mm355_attn_decode (one 1024-thread workgroup per sample, KV head and 1024 cached rows; the lone
- * workgroup of a cache of <= 1024 rows writes the output itself), 1 = one 256-thread workgroup per 256-row chunk + merge by the last. */
+ * workgroup of a cache of <= 1024 rows writes the output itself: no device-scope fence), 1 = one 256-thread workgroup per 256-row chunk +
+ * merge by the last. */
 int mm355_attn_decode_variant(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
                       int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,
                       mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,

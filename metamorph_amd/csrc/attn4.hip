@@ -4,7 +4,7 @@
 //     S^T[64 keys][64 q] = K Q^T (32 MFMAs per tile), O^T[128 d][64 q] += V^T P^T (32 MFMAs per tile)
 //   * the score MFMAs take q and k AS STORED (the bf16 values the reference's SDPA sees) and the first MFMA of every chain takes C = -m
 //     (the running row maximum, in units of the raw dot product) from a register tuple: the chain delivers s' = q . k - m in fp32, and the
-//     softmax scale enters on the fp32 side, P = exp2((scale * log2 e) * s'): one v_pk_mul_f32 per PAIR of scores + one v_exp_f32 per score
+//     softmax scale enters on the fp32 side, P = exp2((scale * log2 e) * s'): one v_mul_f32 + one v_exp_f32 per score
 //     (no subtract on the vector ALU); m only moves when some row grew by more than 2^6 (rare, wave-uniform branch).  Rounds 1-4 folded
 //     scale * log2 e into a re-rounded bf16 copy of q: an extra rounding whose score error grows with |s|
 //   * register file, all LITERAL registers owned by the asm stream (map in tools/gen_attn4.py): O a[0:127], Q a[128:191], K / V fragment
@@ -38,7 +38,6 @@ constexpr int TILE = 16384;                                  // [64 rows][128] b
 constexpr int VRING = 2 * TILE;                              // K slots 0, 1 | V slots 0, 1
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float THR = 6.0f;                                  // log2 units: the running maximum stays while no row grew by more than 2^6
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 MM_DEV float half_swap_max(float m) {                        // max over the two lanes (l, l ^ 32) that share a query row
     float a = m, b = m;
@@ -117,9 +116,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
         }
     }
     // Q rows first (HBM latency is the prologue's critical path): lane holds Q[q = qb*32 + c][d = ks*16 + hi*8 .. + 8] -> v[128:191]
-    const float sl2 = a.scale * LOG2E;                       // raw q . k units -> log2 domain; (sl2, sl2) as the SGPR-pair operand of v_pk_mul_f32
+    const float sl2 = a.scale * LOG2E;                       // raw q . k units -> log2 domain; its bits in an SGPR: the scalar operand of the v_mul_f32s
     const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(sl2));
-    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
     {
         const uint16_t* qp0_ = a.q + (row_base + min(qw0 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
         const uint16_t* qp1_ = a.q + (row_base + min(qw0 + 32 + c, L - 1)) * a.ld_q + (int64_t)hq * 128 + hi * 8;
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ATTN4_DMA_K(i); }
 #include ATTN4_INC(zero_o.inc)
-    f32x2_t LS[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // [qb][(r >> 1) & 1] packed partial row sums of this lane's keys
+    float LS[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // [qb][r & 3] partial row sums of this lane's keys
     float MX[2][2], rm_[2], rt_[2];
     uint64_t grow_ = 0;
     int nresc_ = 0;                                          // deferred-rescale branches this wave took (wave-uniform: lives in an SGPR)
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(64))) void f
     for (int qb_ = 0; qb_ < 2; ++qb_) {
         const int qg = qw0 + qb_ * 32 + c;
         const bool valid = qg < seqlen && tw >= 0;
-        const float l_run = half_swap_sum((LS[qb_][0].x + LS[qb_][0].y) + (LS[qb_][1].x + LS[qb_][1].y));
+        const float l_run = half_swap_sum((LS[qb_][0] + LS[qb_][1]) + (LS[qb_][2] + LS[qb_][3]));
         const float inv = (valid && l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
         for (int db_ = 0; db_ < 4; ++db_) {

@@ -6,7 +6,7 @@
 //     (ds_read_b128 for the score products, ds_read_b64_tr_b16 pairs for the gradient products, one tile swizzle serves both: 16-B chunk ^
 //     ((row & 3) << 2 | (row >> 2) & 3))
 //   * the score chains start from C = -lse / scale (units of the raw dot product) and C = -delta; the softmax scale enters on the fp32 side,
-//     P = exp2((scale * log2 e) * x): one v_pk_mul_f32 per PAIR of scores, one v_exp_f32 and one v_mul_f32 (dS = P * y) per score
+//     P = exp2((scale * log2 e) * x): per score one v_mul_f32, one v_exp_f32 and one v_mul_f32 (dS = P * y)
 //     (dK / dV: the C values are read from the tile's statistics rows straight into the chain's registers; dQ: two constant tuples).
 //     q and k enter the MFMAs as stored -- all three attention kernels recompute the SAME fp32 scores (rounds 1-4: a re-rounded bf16 copy of
 //     one operand times scale * log2 e, a different one per kernel)
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(96))) void d
     const uint32_t ldqb = (uint32_t)a.ld_q * 2u, ldob = (uint32_t)a.ld_o * 2u;
     const int64_t stat_n = (int64_t)a.B * a.Hq * L;
 
-    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // (c, c) as the SGPR-pair operand of v_pk_mul_f32
-    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
+    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // c = scale * log2 e: the SGPR operand of the v_mul_f32s
     LaneAddr la;
     la.init(lane);
     // ring slots 0, 1 are reached from RA / TA / TB (+ immediates < 64 KiB), slots 2, 3 from the copies 64 KiB higher
@@ -364,8 +363,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(80))) void d
     const uint16_t* vbase = a.v + row_base * a.ld_k + (int64_t)hk * 128;
     const uint32_t nrec = (uint32_t)(seqlen - 1) * ldb + 256u;
 
-    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // (c, c) as the SGPR-pair operand of v_pk_mul_f32
-    const uint64_t sl2x2_ = ((uint64_t)sl2b_ << 32) | (uint64_t)sl2b_;
+    const uint32_t sl2b_ = __builtin_amdgcn_readfirstlane(__float_as_uint(a.scale * LOG2E));   // c = scale * log2 e: the SGPR operand of the v_mul_f32s
     LaneAddr la;
     la.init(lane);
     int RA[8], TA[4], TB[4], RAH[8], TAH[4], TBH[4];

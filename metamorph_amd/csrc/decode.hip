@@ -299,6 +299,286 @@ __global__ __launch_bounds__(NT) void gemv_fused_kernel(GemvFusedArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3 .. 16 rows: the same GEMVs on MFMA
+// Round 5 (batched decode: all rows of a batch / all beams go through the layers in ONE pass).  The VALU kernels above spend 8 FMAs +
+// unpacking per weight element and row; beyond two rows they are instruction-bound (measured: 8 rows = 2.6 x the time of one, 1.5 TB/s of
+// weights).  Here the dot products run on v_mfma_f32_16x16x32_bf16 and the kernel stays a weight stream at any M <= 16:
+//   * a wave owns FOUR units (the 4-row units of the kernels above: plain = rows 4u .. 4u+3; SwiGLU = gate rows c, c+1 and up rows I+c,
+//     I+c+1; RoPE = the rotation partners j, j+1, j+d/2, j+1+d/2 of one head) = 16 weight rows as the A operand: lane (fr = lane & 15,
+//     fq = lane >> 4) loads 16 B of row fr at k + 8 fq straight from HBM in the fragment layout (64 contiguous bytes per row and
+//     instruction, eight k-steps per row in flight, the next eight issued before the MFMAs of the current ones);
+//   * the x rows are the B operand (row m = fr, zero beyond M): from L2 as they are, or -- PRENORM -- from LDS, where every workgroup
+//     forms bf16(w * bf16(x * rstd)) once (rmsnorm_fwd_kernel's arithmetic and reduction order);
+//   * D[16 weight rows][16 x rows]: lane (m = fr, unit fq) ends with the FOUR outputs of one unit for one x row -- exactly what the
+//     epilogues of the kernels above take (bias / GELU / residual; SiLU(g) u; RoPE + cache append);
+//   * K is split over KS = 1 / 2 / 4 waves of a workgroup by the number of units (>= ~1000 waves in flight), partial tiles meet in LDS in
+//     a fixed order.  KS depends on (weight rows, K) only, so a fused kernel and the launch sequence it replaces see the same sums.
+struct GemvMfmaArgs {
+    GemvFusedArgs f;                                         // x, W, M, N, K, norm_w / eps, out (MODE 1 / 2) and the MODE fields
+    void* y; int64_t ldy;                                    // MODE 0
+    const uint16_t* bias; const uint16_t* res; int64_t ldr; uint32_t flags;
+    int ks;                                                  // waves per unit group (1, 2, 4)
+    int xs_stride;                                           // PRENORM: LDS row stride of the normalised x rows, bytes
+};
+
+template <int MODE>
+MM_DEV void unit_rows(const GemvFusedArgs& a, int unit, int (&rows)[4]) {
+    if constexpr (MODE == 0) {
+        rows[0] = unit * 4; rows[1] = rows[0] + 1; rows[2] = rows[0] + 2; rows[3] = rows[0] + 3;
+    } else if constexpr (MODE == 1) {
+        const int c = unit * 2;
+        rows[0] = c; rows[1] = c + 1; rows[2] = a.I + c; rows[3] = a.I + c + 1;
+    } else {
+        const int upd = a.d / 4, nrot = (a.Hq + a.Hkv) * upd;
+        if (unit < nrot) {
+            const int hd = unit / upd, j = (unit % upd) * 2;
+            rows[0] = hd * a.d + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + a.d / 2; rows[3] = rows[2] + 1;
+        } else {
+            const int b0 = (a.Hq + a.Hkv) * a.d + (unit - nrot) * 4;
+            rows[0] = b0; rows[1] = b0 + 1; rows[2] = b0 + 2; rows[3] = b0 + 3;
+        }
+    }
+}
+
+template <int MODE, bool PRENORM, int GR>
+__global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
+    const GemvFusedArgs& a = g.f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // PRENORM: [M][xs_stride] normalised x rows (bf16)
+    __shared__ float part[NT / 64][GR][64][4];
+    __shared__ float red[NT / 64];
+    __shared__ float rstd_s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int K = a.K, M = a.M, KS = g.ks;
+    // a wave owns GR groups of 16 weight rows (= 4 GR units) over its K slice: one x fragment feeds GR MFMAs
+    const int grp0 = (blockIdx.x * ((NT / 64) / KS) + wave / KS) * GR, ks = wave % KS;
+    int rows[4];
+    const uint16_t* wp[GR];
+    uint32_t wo[GR];                                         // the same rows as byte offsets into the weight buffer (host: N * ldw * 2 < 4 GiB)
+#pragma unroll
+    for (int gi = 0; gi < GR; ++gi) {                        // A operand: this lane's weight row = row (fr & 3) of unit (grp0 + gi) * 4 + (fr >> 2)
+        unit_rows<MODE>(a, (grp0 + gi) * 4 + (fr >> 2), rows);
+        int myrow = rows[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) myrow = (fr & 3) == r ? rows[r] : myrow;
+        wp[gi] = a.W + (int64_t)min(max(myrow, 0), a.N - 1) * a.ldw + fq * 8;
+        wo[gi] = (uint32_t)min(max(myrow, 0), a.N - 1) * (uint32_t)a.ldw * 2u + (uint32_t)fq * 16u;
+    }
+    const uint16_t* xp = a.x + (int64_t)min(fr, M - 1) * a.ldx + fq * 8;
+    const uint32_t xo = (uint32_t)min(fr, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)fq * 16u;
+    // buffer descriptors: a load whose offset lies beyond num_records returns zeros WITHOUT touching memory -- the branch-free way to
+    // skip the prefetch behind the last block (a branch around a prefetch makes hipcc wait for it at the merge: no pipelining)
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (uint32_t)((uint64_t)(a.N - 1) * a.ldw * 2 + (uint64_t)K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (uint32_t)((uint64_t)(M - 1) * a.ldx * 2 + (uint64_t)K * 2), 0x00020000);
+    const uint32_t OOB = 0xf0000000u;
+    const int nst = (K + 31) >> 5;                            // k-steps of 32
+    const int s0 = (nst * ks) / KS, s1 = (nst * (ks + 1)) / KS;
+    constexpr int U = 8 / GR;                                // k-steps per block: GR x U = 8 weight fragments per buffer, two buffers
+    u32x4 wa[GR][U], wb[GR][U], xa[U], xb[U];
+    const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+    // The main loop runs over this slice's COMPLETE blocks of U k-steps with plain loads -- no predicate, no select behind a load (a
+    // select waits for its load on the spot and serialises the stream); what is left (< U steps, and the one step that is partial in k when
+    // K % 32 != 0) goes through a step-at-a-time tail.  x rows beyond M are read from row M - 1: they only feed D columns nobody stores.
+    // The x fragments are PREFETCHED like the weights, one block ahead and issued BEFORE the weight loads of that block: the vector memory
+    // counter retires in order.  PRENORM reads them from LDS (its own counter).
+    const int e1 = min(s1, (K & 31) ? nst - 1 : nst);        // end of the steps that are complete in k
+    const int nb = max(e1 - s0, 0) / U;
+    auto loadw = [&](u32x4 (&w)[GR][U], int s, uint32_t skip) {   // skip = 0 | OOB (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int gi = 0; gi < GR; ++gi) w[gi][u] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (wo[gi] + (uint32_t)(s + u) * 64u) | skip, 0, 2);
+    };
+    auto loadx = [&](u32x4 (&xv)[U], int s, uint32_t skip) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (PRENORM) xv[u] = *(const u32x4*)(xs + min(fr, M - 1) * g.xs_stride + (min(s + u, nst - 1) * 32 + fq * 8) * 2);
+            else xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (xo + (uint32_t)(s + u) * 64u) | skip, 0, 0);
+        }
+    };
+    loadw(wa, s0, nb > 0 ? 0u : OOB);                        // the weight stream starts before the norm reduction
+    if constexpr (PRENORM) {
+        const int nv = K >> 3;
+        for (int m = 0; m < M; ++m) {                        // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order
+            float ss = 0.f;
+            for (int v = threadIdx.x; v < nv; v += NT) {
+                float xv[8];
+                unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + v * 8), xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[e] * xv[e];
+            }
+            ss = block_sum<NT>(ss, red);
+            if (threadIdx.x == 0) rstd_s[m] = rsqrtf(ss / (float)K + a.eps);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < M * nv; i += NT) {
+            const int m = i / nv, v = i % nv;
+            float xv[8], nw[8];
+            unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + v * 8), xv);
+            unpack8(*(const u32x4*)(a.norm_w + v * 8), nw);
+            const float rs = rstd_s[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = nw[e] * round_bf(xv[e] * rs);
+            *(u32x4*)(xs + (int64_t)m * g.xs_stride + v * 16) = pack8(xv);
+        }
+        __syncthreads();
+    }
+    f32x4 acc[GR][2];
+#pragma unroll
+    for (int gi = 0; gi < GR; ++gi) acc[gi][0] = acc[gi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](const u32x4 (&w)[GR][U], const u32x4 (&xv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)                          // 2 GR independent chains: no MFMA waits for the one before it
+#pragma unroll
+            for (int gi = 0; gi < GR; ++gi)
+                acc[gi][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[gi][u]), __builtin_bit_cast(bf16x8, xv[u]),
+                                                                         acc[gi][u & 1], 0, 0, 0);
+    };
+    loadx(xa, s0, nb > 0 ? 0u : OOB);
+    for (int bk = 0; bk < nb; bk += 2) {                     // (sched_barrier: hipcc otherwise sinks the prefetch loads behind the MFMAs that do not need them)
+        const int s = s0 + bk * U;
+        const uint32_t skb = bk + 1 < nb ? 0u : OOB, ska = bk + 2 < nb ? 0u : OOB;
+        loadx(xb, s + U, skb);
+        loadw(wb, s + U, skb);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wa, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        loadx(xa, s + 2 * U, ska);
+        loadw(wa, s + 2 * U, ska);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(wb, xb);                                          // (a skipped block is all zeros: adds nothing)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int st = s0 + nb * U; st < s1; ++st) {              // the tail: one step at a time, the k tail selected to zero
+        const bool in = st * 32 + fq * 8 < K;
+        const int off = in ? st * 32 : 0;
+        u32x4 xv;
+        if constexpr (PRENORM) xv = *(const u32x4*)(xs + min(fr, M - 1) * g.xs_stride + (off + fq * 8) * 2);
+        else xv = *(const u32x4*)(xp + off);
+        xv = in ? xv : z4;
+#pragma unroll
+        for (int gi = 0; gi < GR; ++gi) {
+            const u32x4 wv = *(const u32x4*)(wp[gi] + off);
+            acc[gi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xv), acc[gi][0], 0, 0, 0);
+        }
+    }
+    f32x4 dd[GR];
+#pragma unroll
+    for (int gi = 0; gi < GR; ++gi) dd[gi] = acc[gi][0] + acc[gi][1];
+    if (KS > 1) {
+#pragma unroll
+        for (int gi = 0; gi < GR; ++gi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave][gi][lane][r] = dd[gi][r];
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int gi = 0; gi < GR; ++gi) {
+            dd[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dd[gi][r] += part[wave + q][gi][lane][r];
+        }
+    }
+    // lane (m = fr, unit fq) of group gi: D rows 4 fq .. 4 fq + 3 = the four outputs of unit (grp0 + gi) * 4 + fq for x row m
+    const int m = fr;
+    if (m >= M) return;
+#pragma unroll
+    for (int gi = 0; gi < GR; ++gi) {
+        const f32x4 d = dd[gi];
+        unit_rows<MODE>(a, (grp0 + gi) * 4 + fq, rows);
+        if constexpr (MODE == 0) {
+            const uint32_t flags = g.flags;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rows[r];
+                if (n >= a.N) continue;
+                float v = d[r];
+                if (flags & MM355_GEMM_BIAS) v += bf2f(g.bias[n]);
+                if (flags & MM355_GEMM_GELU_ERF) v = gelu_erf_f(v);
+                if (flags & MM355_GEMM_GELU_TANH) v = gelu_tanh_f(v);
+                if (flags & MM355_GEMM_RESIDUAL) v += bf2f(g.res[(int64_t)m * g.ldr + n]);
+                if (flags & MM355_GEMM_OUT_F32) ((float*)g.y)[(int64_t)m * g.ldy + n] = v;
+                else ((uint16_t*)g.y)[(int64_t)m * g.ldy + n] = f2bf(v);
+            }
+        } else {
+            if (rows[3] >= a.N || (MODE == 1 && rows[1] >= a.I)) continue;
+            float v4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = round_bf(d[r]);  // what the unfused GEMV stores
+            if constexpr (MODE == 1) {
+                float o[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) o[e] = round_bf(v4[e] / (1.0f + __expf(-v4[e]))) * v4[2 + e];
+                *(uint32_t*)(a.out + (int64_t)m * a.ld_out + rows[0]) = pack2bf(o[0], o[1]);
+            } else {
+                const int nqk = (a.Hq + a.Hkv) * a.d;
+                const int pos = a.positions[m];
+                if (rows[0] < nqk) {
+                    const int hd = rows[0] / a.d, j = rows[0] % a.d;
+                    float y1[2], y2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float c = bf2f(a.cos_t[(int64_t)pos * a.d + j + e]), sn = bf2f(a.sin_t[(int64_t)pos * a.d + j + e]);
+                        y1[e] = round_bf(v4[e] * c) + round_bf(-v4[2 + e] * sn);
+                        y2[e] = round_bf(v4[2 + e] * c) + round_bf(v4[e] * sn);
+                    }
+                    uint16_t* dst = hd < a.Hq ? a.out + (int64_t)m * a.ld_out + rows[0]
+                                              : a.kc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (int64_t)(hd - a.Hq) * a.d + j;
+                    *(uint32_t*)dst = pack2bf(y1[0], y1[1]);
+                    *(uint32_t*)(dst + a.d / 2) = pack2bf(y2[0], y2[1]);
+                } else {
+                    uint16_t* dst = a.vc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (rows[0] - nqk);
+                    *(u32x2*)dst = u32x2{pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
+                }
+            }
+        }
+    }
+}
+
+// groups of 16 rows per wave (GR: the x fragments are re-used GR times) and waves per group block (KS: the K split) by the number of weight
+// rows: as many rows per wave as still leaves >= ~1000 waves in flight.  A function of (weight rows, K) only, so a fused kernel and the
+// launch sequence it replaces see the same sums.
+void gemv_mfma_shape(int64_t units, int& gr, int& ks) {
+    const int64_t groups = (units + 3) / 4;
+    gr = 1;                                                  // measured (profiles/r5_gemv_rows.log): 2 / 4 groups per wave buy nothing on the wide shapes (gate|up 67 us
+                                                             // either way: the x traffic was never the limit) and lose on the narrow ones (fewer waves)
+    const int64_t blocks = (groups + gr - 1) / gr;
+    ks = blocks <= 640 ? 4 : (blocks <= 1280 ? 2 : 1);
+}
+
+template <int MODE, int GR>
+int launch_gemv_mfma_gr(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
+    const int64_t blocks = ((units + 3) / 4 + GR - 1) / GR;
+    const int bpw = (NT / 64) / g.ks;
+    const unsigned grid = (unsigned)((blocks + bpw - 1) / bpw);
+    if (prenorm) {
+        g.xs_stride = (g.f.K + 8) * 2;                       // + 16 B per row: the 16 x rows of a fragment read fall on different banks
+        const int lds = g.f.M * g.xs_stride;
+        if (lds > 140 * 1024) return MM355_EUNSUPPORTED;
+        static std::atomic<uint64_t> ok{0};                  // (one opt-in per device, to the largest size any call may ask for)
+        if (mm_ensure_dynamic_lds((const void*)gemv_mfma_kernel<MODE, true, GR>, 140 * 1024, ok) != MM355_OK) return MM355_ELAUNCH;
+        hipLaunchKernelGGL((gemv_mfma_kernel<MODE, true, GR>), dim3(grid), dim3(NT), lds, s, g);
+    } else {
+        hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, GR>), dim3(grid), dim3(NT), 0, s, g);
+    }
+    return mm_launch_status();
+}
+
+// the MFMA kernel addresses weights and x rows with 32-bit buffer offsets, and marks a skipped prefetch by setting the top four bits
+bool gemv_mfma_addressable(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
+    return (N - 1) * ldw * 2 + K * 2 < 0xf0000000ll && (M - 1) * ldx * 2 + K * 2 < 0xf0000000ll;
+}
+
+template <int MODE>
+int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
+    int gr;
+    gemv_mfma_shape(units, gr, g.ks);
+    if (gr == 4) return launch_gemv_mfma_gr<MODE, 4>(g, units, prenorm, s);
+    if (gr == 2) return launch_gemv_mfma_gr<MODE, 2>(g, units, prenorm, s);
+    return launch_gemv_mfma_gr<MODE, 1>(g, units, prenorm, s);
+}
+
 // ------------------------------------------------------------------------------------------------ RoPE + cache append
 // One new qkv row per sample: rotate q and k at position positions[b] (HF rounding order, as rope_qk_kernel), leave q in
 // place and write the rotated k and the v row into cache row positions[b].  Positions come from DEVICE memory so that the
@@ -733,7 +1013,7 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
                                int64_t K, const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr, uint32_t flags, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
-    if (M > 8) return MM355_EUNSUPPORTED;                    // more rows: mm355_gemm_bf16
+    if (M > 16) return MM355_EUNSUPPORTED;                   // more rows: mm355_gemm_bf16
     if ((K & 7) || (ldx & 7) || (ldw & 7) || !mm_aligned16(x) || !mm_aligned16(W)) return MM355_EINVAL;
     if ((flags & MM355_GEMM_BIAS) && !bias) return MM355_EINVAL;
     if ((flags & MM355_GEMM_RESIDUAL) && !residual) return MM355_EINVAL;
@@ -741,6 +1021,13 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
     if (flags & MM355_GEMM_ACCUMULATE) return MM355_EUNSUPPORTED;
     if (N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (M >= 3) {                                            // 3 .. 16 rows: the MFMA form (one or two rows: the VALU kernels below)
+        if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
+        GemvMfmaArgs g = {};
+        g.f.x = x; g.f.ldx = ldx; g.f.W = W; g.f.ldw = ldw; g.f.M = (int)M; g.f.N = (int)N; g.f.K = (int)K;
+        g.y = y; g.ldy = ldy; g.bias = bias; g.res = residual; g.ldr = ldr; g.flags = flags;
+        return launch_gemv_mfma<0>(g, (N + 3) / 4, false, s);
+    }
     // few rows of a long K (down projection): split K over the waves of a workgroup; measured: K = 14336, N = 4096 28.5 -> 24.3 us,
     // while at K = 4096 the extra LDS hand-over costs more than it buys (13.5 -> 17.7 us)
     const int ksplit = (N <= 8192 && K >= 8192) ? 4 : 1;
@@ -787,6 +1074,7 @@ static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16*
         return MM355_EINVAL;
     if (d <= 0 || d > 128 || (d & 7) || (ld_kv & 7) || (batch_stride_kv & 7) || !mm_aligned16(k_cache) || !mm_aligned16(v_cache)) return MM355_EINVAL;
     if (B > 65535 || Hkv > 65535) return MM355_EINVAL;
+    if (variant < 0 || variant > 1) return MM355_EINVAL;
     const int G = (int)(Hq / Hkv);
     const int nsplit = (int)((max_kv_len + CH - 1) / CH);
     const int ngroup = (nsplit + 3) / 4;                     // 1024-key groups: one workgroup each
@@ -838,13 +1126,19 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
                                       int64_t M, int64_t I, int64_t K, const mm355_bf16* norm_w, float eps, void* stream) {
     (void)hipGetLastError();
     if (!x || !Wgu || !act || M <= 0 || I <= 0 || K <= 0) return MM355_EINVAL;
-    if (M > 8 || (I & 1)) return MM355_EUNSUPPORTED;
+    if (M > 16 || (I & 1)) return MM355_EUNSUPPORTED;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || (ld_act & 1) || !mm_aligned16(x) || !mm_aligned16(Wgu) || (((uintptr_t)act) & 3u)) return MM355_EINVAL;
     if (norm_w && !mm_aligned16(norm_w)) return MM355_EINVAL;
     if (I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;
     GemvFusedArgs a = {};
     a.x = x; a.ldx = ldx; a.W = Wgu; a.ldw = ldw; a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = act; a.ld_out = ld_act; a.I = (int)I;
+    if (M >= 3) {
+        if (!gemv_mfma_addressable(M, 2 * I, K, ldx, ldw)) return MM355_EUNSUPPORTED;
+        GemvMfmaArgs g = {};
+        g.f = a;
+        return launch_gemv_mfma<1>(g, I / 2, norm_w != nullptr, (hipStream_t)stream);
+    }
     return launch_gemv_fused<1>(a, (int)(I / 2), norm_w != nullptr, (hipStream_t)stream);
 }
 
@@ -855,7 +1149,7 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
     (void)hipGetLastError();
     if (!x || !Wqkv || !qkv || !cos_t || !sin_t || !positions || !k_cache || !v_cache || M <= 0 || Hq <= 0 || Hkv <= 0 || d <= 0 || K <= 0)
         return MM355_EINVAL;
-    if (M > 8 || (d & 3)) return MM355_EUNSUPPORTED;         // rotation partners in pairs: d / 2 even
+    if (M > 16 || (d & 3)) return MM355_EUNSUPPORTED;        // rotation partners in pairs: d / 2 even
     if ((K & 7) || (ldx & 7) || (ldw & 7) || (ld_qkv & 1) || (ld_kv & 3) || (batch_stride_kv & 3) || !mm_aligned16(x) || !mm_aligned16(Wqkv) ||
         (((uintptr_t)qkv) & 3u) || (((uintptr_t)k_cache) & 7u) || (((uintptr_t)v_cache) & 7u))
         return MM355_EINVAL;
@@ -866,5 +1160,11 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
     a.x = x; a.ldx = ldx; a.W = Wqkv; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = qkv; a.ld_out = ld_qkv; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.d = (int)d;
     a.cos_t = cos_t; a.sin_t = sin_t; a.positions = positions; a.kc = k_cache; a.vc = v_cache; a.ld_kv = ld_kv; a.bs_kv = batch_stride_kv;
+    if (M >= 3) {
+        if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
+        GemvMfmaArgs g = {};
+        g.f = a;
+        return launch_gemv_mfma<2>(g, N / 4, norm_w != nullptr, (hipStream_t)stream);
+    }
     return launch_gemv_fused<2>(a, (int)(N / 4), norm_w != nullptr, (hipStream_t)stream);
 }

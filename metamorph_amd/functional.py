@@ -32,6 +32,7 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             # the next until the optimizer rewrites the parameters: under gradient accumulation the four transposes per layer are made
             # once per optimizer step instead of once per micro-batch (+2 bytes per decoder parameter while a window is open)
             "wt_cache": False,
+            "decode_fold_rows": 2,                           # decode step: fold the RMSNorms into the GEMVs' operand reads up to this many rows
             # one launch for an input-gradient GEMM and the weight-gradient GEMM that reads the same dy: (dn2, dW_gate_up) and (dX_o, dW_o)
             # -- the mechanism of dw_pair (mm355_gemm_pair_bf16: same kernel body, same bits), saving one ramp and tail per pair
             "dx_pair": True}
@@ -41,7 +42,7 @@ def set_variant(name, value):
     """Flip one composition switch (tools / tests); returns the previous value."""
     if name not in VARIANTS:
         raise KeyError(f"unknown variant {name!r}: {sorted(VARIANTS)}")
-    old, VARIANTS[name] = VARIANTS[name], bool(value)
+    old, VARIANTS[name] = VARIANTS[name], (int(value) if isinstance(VARIANTS[name], int) and not isinstance(VARIANTS[name], bool) else bool(value))
     return old
 
 
@@ -729,7 +730,7 @@ class BilinearL2NormFn(Function):
 
 
 def linear(x2d, module):
-    if x2d.shape[0] <= 8 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad)):
+    if x2d.shape[0] <= 16 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad)):
         # decode shape: a handful of rows, inference only -> stream the weight once (mm355_gemv_bf16)
         return ops.gemv(x2d, module.weight.data, bias=None if module.bias is None else module.bias.data)
     return LinearFn.apply(x2d, module.weight, module.bias, module)
@@ -749,8 +750,8 @@ class KVCache:
         self.pos_dev = torch.zeros(batch, device=device, dtype=torch.int32)      # row the next token of sequence b is written to
         self.len_dev = torch.ones(batch, device=device, dtype=torch.int32)       # = pos + 1: rows visible to that token
         self.ws = None
-        if Hq is not None:                                                       # (rows are stepped at most 8 at a time: the GEMV kernels' limit)
-            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(min(batch, 8), Hq, d, max_len)), device=device,
+        if Hq is not None:                                                       # (rows are stepped at most 16 at a time: the GEMV kernels' limit)
+            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(min(batch, 16), Hq, d, max_len)), device=device,
                                   dtype=torch.float32)                           # arrival counters start at 0
 
     @property
@@ -804,9 +805,10 @@ def decoder_prefill(x, layers, meta, cache, row=0):
     return x
 
 
-def _decode_rows8(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len):
-    """<= 8 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
-    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 8), attention per row at its own length."""
+def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len):
+    """<= 16 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
+    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: one or two rows on the vector ALU, 3 .. 16 on MFMA), attention per
+    row at its own length."""
     nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
         params_ready(layer)
@@ -815,12 +817,17 @@ def _decode_rows8(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len
         wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
         if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0:
             # five launches per layer: RMSNorm folded into the q|k|v and gate|up GEMVs' operand reads, RoPE + cache append and SwiGLU into
-            # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below)
-            qkv = ops.gemv_rope_append(x, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],
-                                       norm_w=layer.input_layernorm.weight, eps=meta.eps)
+            # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below).
+            # Three rows and more (the MFMA GEMVs): the norm runs as its own launch -- folded in, every workgroup would normalise ALL rows
+            # again (measured at 8 / 16 rows: 66 / 100 us for the gate|up launch against 50 with the norm outside) -- seven launches, same bits.
+            fold = x.shape[0] <= VARIANTS["decode_fold_rows"]
+            n1 = x if fold else ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
+            qkv = ops.gemv_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],
+                                       norm_w=layer.input_layernorm.weight if fold else None, eps=meta.eps)
             o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, max_len, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
             x2 = ops.gemv(o, att.o_proj.weight, residual=x)
-            act = ops.gemv_swiglu(x2, wgu, meta.I, norm_w=layer.post_attention_layernorm.weight, eps=meta.eps)
+            n2 = x2 if fold else ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
+            act = ops.gemv_swiglu(n2, wgu, meta.I, norm_w=layer.post_attention_layernorm.weight if fold else None, eps=meta.eps)
             x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
             continue
         n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
@@ -838,7 +845,7 @@ def _decode_rows8(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len
 def decoder_decode_row(x, layers, meta, cache, cos, sin):
     """One new row PER SEQUENCE against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values, the whole batch in one
     forward per step -- metamorph_llama.py:711-717; the reference's own greedy loop recomputes the prefix instead, :502-597).
-    x [batch, h] -> [batch, h]; row b is appended at cache.lengths[b].  The batch goes through the layers in ONE pass (8 rows at a time):
+    x [batch, h] -> [batch, h]; row b is appended at cache.lengths[b].  The batch goes through the layers in ONE pass (16 rows at a time):
     the 15 GB of LLaMA-3-8B weights are read once per step, not once per sequence.  Every position-dependent input is read from device
     memory (cache.pos_dev / len_dev): the launch sequence is identical for every token, i.e. capturable once and replayable
     (DecodeStepGraph)."""
@@ -847,11 +854,11 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
     B = x.shape[0]
     if B != cache.batch:
         raise ValueError(f"{B} rows for a cache of {cache.batch} sequences")
-    if B <= 8:
-        y = _decode_rows8(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, cache.max_len)
+    if B <= 16:
+        y = _decode_rows16(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, cache.max_len)
     else:
-        y = torch.cat([_decode_rows8(x[c:c + 8], layers, meta, cos, sin, cache.k[:, c:c + 8], cache.v[:, c:c + 8], cache.pos_dev[c:c + 8],
-                                     cache.len_dev[c:c + 8], cache.ws, cache.max_len) for c in range(0, B, 8)], 0)
+        y = torch.cat([_decode_rows16(x[c:c + 16], layers, meta, cos, sin, cache.k[:, c:c + 16], cache.v[:, c:c + 16], cache.pos_dev[c:c + 16],
+                                      cache.len_dev[c:c + 16], cache.ws, cache.max_len) for c in range(0, B, 16)], 0)
     cache.pos_dev.add_(1)
     cache.len_dev.add_(1)
     cache.lengths = [n + 1 for n in cache.lengths]

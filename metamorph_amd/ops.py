@@ -165,7 +165,7 @@ def gemm_nn_supported(a, bt):
 
 
 def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
-    """out[M,N] = x[M,K] . w[N,K]^T for M <= 8 rows (decode shape): streams the weight once at HBM rate."""
+    """out[M,N] = x[M,K] . w[N,K]^T for M <= 16 rows (decode shape): streams the weight once at HBM rate (1 - 2 rows: vector ALU; 3 - 16: MFMA)."""
     _chk_dev(x, w, out, bias, residual)
     px, M, K, ldx = _rows2d(x)
     pw, N, Kw, ldw = _rows2d(w)
@@ -189,7 +189,7 @@ def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
 
 
 def gemv_swiglu(x, wgu, I, norm_w=None, eps=0.0, out=None):
-    """act[M, I] = SiLU(g) * u, [g | u] = n . wgu^T, n = RMSNorm(x; norm_w, eps) (norm_w None: n = x); M <= 8 (decode shape)."""
+    """act[M, I] = SiLU(g) * u, [g | u] = n . wgu^T, n = RMSNorm(x; norm_w, eps) (norm_w None: n = x); M <= 16 (decode shape)."""
     _chk_dev(x, wgu, norm_w, out)
     px, M, K, ldx = _rows2d(x)
     pw, N, Kw, ldw = _rows2d(wgu)
@@ -201,7 +201,7 @@ def gemv_swiglu(x, wgu, I, norm_w=None, eps=0.0, out=None):
 
 
 def gemv_rope_append(x, wqkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache, norm_w=None, eps=0.0, out=None):
-    """The fused q|k|v projection of M <= 8 new rows (optionally of RMSNorm(x)), RoPE at positions[m] (int32, device), rotated k and v
+    """The fused q|k|v projection of M <= 16 new rows (optionally of RMSNorm(x)), RoPE at positions[m] (int32, device), rotated k and v
     straight into cache row positions[m]; returns the row buffer [M, (Hq+2Hkv)*d] whose q columns are valid."""
     _chk_dev(x, wqkv, norm_w, cos, sin, positions, k_cache, v_cache, out)
     px, M, K, ldx = _rows2d(x)

@@ -839,8 +839,8 @@ def test_swiglu_bwd_transposed_outputs(ops):
 
 # ------------------------------------------------------------------------------------------------ decode shape (row N1)
 
-@pytest.mark.parametrize("M", [1, 2, 3, 8])
-@pytest.mark.parametrize("NK", [(64, 512), (130, 1032), (6144, 4096), (1000, 14336)])
+@pytest.mark.parametrize("M", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("NK", [(64, 512), (130, 1032), (6144, 4096), (1000, 14336), (4096, 64)])
 def test_gemv(ops, M, NK):
     N, K = NK
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
@@ -857,12 +857,12 @@ def test_gemv(ops, M, NK):
 def test_gemv_rejects_many_rows(ops):
     from metamorph_amd.lib import Mm355Error
     with pytest.raises(Mm355Error):
-        ops.gemv(rnd(9, 64, seed=1).to(DEV), rnd(16, 64, seed=2).to(DEV))
+        ops.gemv(rnd(17, 64, seed=1).to(DEV), rnd(16, 64, seed=2).to(DEV))
 
 
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", [(1, 8, 2, 128, [700]), (3, 4, 4, 64, [1, 256, 300]), (2, 32, 4, 128, [513, 77]), (1, 16, 16, 72, [40]),
-                                  (2, 8, 2, 128, [2500, 1030]), (2, 16, 2, 128, [1024, 1025]), (1, 4, 2, 64, [4000])])
+                                  (2, 8, 2, 128, [2500, 1030]), (2, 16, 2, 128, [1024, 1025]), (1, 4, 2, 64, [4000]), (3, 32, 8, 128, [128, 129, 127])])
 def test_attn_decode(ops, case, variant):
     """Last-row attention against a KV cache == the oracle's attention on the same prefix, last query row.  Variant 0 (product): one
     1024-thread workgroup per 1024 cached rows -- caches of <= 1024 rows finish in it, longer ones through one record per group merged
@@ -947,7 +947,7 @@ def test_ce_rows_with_logits_of_80(ops):
     assert float(dev[:, V:].float().abs().max()) == 0 and float(dev[7].float().abs().max()) == 0
 
 
-@pytest.mark.parametrize("M", [1, 3, 8])
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
 @pytest.mark.parametrize("IK", [(64, 512), (14336, 4096), (1000, 1032)])
 def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
     """mm355_gemv_swiglu_bf16 (RMSNorm in the operand read, SiLU(g) * u in the epilogue) == rmsnorm_fwd -> gemv -> swiglu_fwd, bit for bit;
@@ -959,7 +959,7 @@ def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
     assert torch.equal(ops.gemv_swiglu(x, w, I), ops.swiglu_fwd(ops.gemv(x, w), I))
 
 
-@pytest.mark.parametrize("geo", [(1, 8, 2, 128, 512), (3, 4, 4, 64, 1032), (2, 32, 8, 128, 4096), (8, 2, 1, 80, 256)])
+@pytest.mark.parametrize("geo", [(1, 8, 2, 128, 512), (3, 4, 4, 64, 1032), (2, 32, 8, 128, 4096), (8, 2, 1, 80, 256), (8, 32, 8, 128, 4096), (16, 8, 2, 128, 1024)])
 def test_gemv_rope_append_fused_equals_the_launch_sequence(ops, geo):
     """mm355_gemv_rope_append_bf16 == rmsnorm_fwd -> gemv -> rope_kv_append: the q columns of the row buffer and the cache rows written
     (and ONLY those cache rows) carry the same bits; positions differ per sample and come from device memory."""
@@ -978,7 +978,7 @@ def test_gemv_rope_append_fused_equals_the_launch_sequence(ops, geo):
         assert torch.equal(k1, k0) and torch.equal(v1, v0), "cache rows"
 
 
-@pytest.mark.parametrize("variant,lens", [(0, [2700, 300]), (0, [700, 300]), (1, [700, 300])])
+@pytest.mark.parametrize("variant,lens", [(0, [2700, 300]), (0, [700, 300]), (0, [100, 3000]), (1, [700, 300])])
 def test_attn_decode_counters_return_to_zero_and_replay(ops, variant, lens):
     """The chunk that arrives last merges and re-arms its counter: the same workspace serves launch after launch (hipGraph replay)."""
     B, Hq, Hkv, d = 2, 32, 8, 128

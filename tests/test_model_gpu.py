@@ -647,10 +647,11 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
                        eos_token_id=128009, pad_token_id=128001)
 
 
-@pytest.mark.parametrize("B", [3, 8, 11])
+@pytest.mark.parametrize("B", [3, 8, 11, 19])
 def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypatch):
     """The cached step of a batch (reference: the whole batch goes to ONE forward per step, metamorph_llama.py:711-717) takes all B rows
-    through every decoder layer in one pass -- 5 launches per layer for B <= 8 (the GEMV kernels' M), ceil(B / 8) x that beyond -- not
+    through every decoder layer in one pass -- 5 launches per layer (7 from three rows on: the norms run on their own) for B <= 16 (the GEMV
+    kernels' M), ceil(B / 16) x that beyond -- not
     B passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
     logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal)."""
     import metamorph_amd.functional as F
@@ -672,7 +673,7 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     kw = dict(use_customize_greedy=False, do_sample=False, max_new_tokens=8, eos_token_id=128009, pad_token_id=128001, return_dict_in_generate=True,
               output_scores=True)
     out = model.generate(inputs=ids.to(DEV), attention_mask=mask.to(DEV), **kw)
-    per_step = 5 * cfg.num_hidden_layers * ((B + 7) // 8) + ((B + 7) // 8 if B <= 8 else 1)      # + the lm_head GEMV (<= 8 rows) or GEMM
+    per_step = 5 * cfg.num_hidden_layers * ((B + 15) // 16) + 1                                   # counted launches: the GEMVs + attention (+ lm_head)
     steps = len(out.scores) - 1
     n_dec = len(launches)
     print(f"\n   B={B}: {n_dec} decode-shape launches over {steps} cached steps (+ prompt pass)")
@@ -682,7 +683,9 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
         alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
         assert alone.sequences[0].tolist() == out.sequences[b].tolist(), (b, alone.sequences[0].tolist(), out.sequences[b].tolist())
         for step, (x, y) in enumerate(zip(alone.scores, out.scores)):
-            assert torch.allclose(x[0], y[b], rtol=1e-4, atol=3e-3), (b, step, float((x[0] - y[b]).abs().max()))
+            # (alone: one row = the vector-ALU GEMVs; in the batch: 3 .. 16 rows = the MFMA GEMVs -- the same products in another fp32
+            # summation order, re-rounded to bf16 after every projection: differences of a bf16 step of the hidden state, i.e. ~1e-2 on a logit)
+            assert torch.allclose(x[0], y[b], rtol=2e-2, atol=2e-2), (b, step, float((x[0] - y[b]).abs().max()))
 
 
 def test_bench_emits_the_driver_contract_on_device():

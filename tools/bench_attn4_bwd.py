@@ -167,7 +167,7 @@ if __name__ == "__main__":
         except Exception as e:
             print(f"[{c}] EXCEPTION {type(e).__name__}: {e}", flush=True)
             allok = False
-    for c in ((2, 333, 8, 2, True, [333, 256]), (1, 512, 4, 2, True, None)):
+    for c in ((2, 333, 8, 2, True, [333, 256]), (1, 512, 4, 2, True, None)) if BASE == 3 else ():     # (the generic kernels have no fused inverse RoPE)
         try:
             allok &= run_case(*c, rope=True)
         except Exception as e:

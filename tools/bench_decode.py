@@ -12,7 +12,7 @@ model = build_model(dict(LLAMA3_8B, num_hidden_layers=layers), dict(num_hidden_l
 h = 4096
 L0, new = int(os.environ.get("PROMPT", 512)), int(os.environ.get("NEW", 64))
 emb = (torch.randn(1, L0, h, device=dev) * 0.02).bfloat16()
-for use_cache in ((True,) if os.environ.get("CACHED_ONLY") else (True, False)):
+for use_cache in (() if os.environ.get("NO_GREEDY") else (True,) if os.environ.get("CACHED_ONLY") else (True, False)):
     n = new if use_cache else min(new, 8)
     model.greedy_decode(None, None, emb, max_new_tokens=2, use_cache=use_cache, eos_token_id=())
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -31,8 +31,11 @@ for use_cache in ((True,) if os.environ.get("CACHED_ONLY") else (True, False)):
 # ---- the batched cached step (round 5: all rows of a batch / all beams in ONE pass over the weights): ms per step by batch size
 if not os.environ.get("NO_BATCH"):
     import metamorph_amd.functional as F
+    if os.environ.get("FOLD_ROWS"):
+        F.set_variant("decode_fold_rows", int(os.environ["FOLD_ROWS"]))
+    wbytes = sum(p.numel() for n_, p in model.named_parameters() if "vision_tower" not in n_ and "embed_tokens" not in n_) * 2
     with torch.no_grad():
-        for B in (1, 2, 4, 8, 16):
+        for B in [int(b) for b in os.environ.get("BATCHES", "1,2,3,4,8,16,32").split(",")]:
             _, meta = model._decode_meta(L0)
             cap = L0 + 2 * new + 4
             cos, sin = model.model.rope_tables(cap, dev)

@@ -28,11 +28,12 @@ Emitted blocks (included inside attn4::fwd_kernel, which declares the few compil
                  (the fragments of d-steps 2..7 are placed under the head's score MFMAs)
 
 Arithmetic (round 5): the score chains run on the operands AS STORED -- s' = q . k - m is the fp32 product of the bf16 values the reference's
-SDPA sees -- and the softmax scale enters on the fp32 side: P = exp2((scale * log2 e) * s'), one `v_pk_mul_f32` per PAIR of scores right in
-front of their two `v_exp_f32` (the constant pair sits in SGPRs).  Rounds 1-4 multiplied q by scale * log2 e and re-rounded it to bf16 before
+SDPA sees -- and the softmax scale enters on the fp32 side: P = exp2((scale * log2 e) * s'), one `v_mul_f32` per score one MFMA gap ahead
+of its `v_exp_f32` (the constant sits in an SGPR).  Rounds 1-4 multiplied q by scale * log2 e and re-rounded it to bf16 before
 the MFMA: one rounding more than the reference has, a score error that grows with |s| (measured: 3x the error of a textbook bf16 flash
-attention at |s| = 50).  The row sums are kept as PACKED pairs (`v_pk_add_f32`), which pays for the new multiplies:
-the number of VALU instructions per MFMA gap is what it was.
+attention at |s| = 50).  Costs 64 multiplies per tile.  They are PLAIN `v_mul_f32`, not `v_pk_mul_f32`: between MFMAs a
+packed-fp32 instruction costs ~22 cycles here against ~3.5 for a plain one (measured with the timing ablations `--abl noscl / noadd /
+sclscalar`: 32 v_pk_mul_f32 = +700 cycles per tile, 64 v_mul_f32 = +220); the same holds for `v_pk_add_f32`, so the row sums stay scalar.
 `safe_*` are the same streams with every LDS read waited for at once and every MFMA followed by 32 wait states: the debugging build that
 separates a placement / hazard defect from a logic defect (tools/bench_attn4.py runs both).
 """
@@ -179,7 +180,7 @@ def emit_decide(st, nxt, head):
                     st.asm("v_accvgpr_read_b32 %%0, a%d\\n\\tv_accvgpr_read_b32 %%1, a%d\\n\\tv_mul_f32 %%0, %%0, %%2\\n\\tv_mul_f32 %%1, %%1, %%2\\n\\t"
                            "v_accvgpr_write_b32 a%d, %%0\\n\\tv_accvgpr_write_b32 a%d, %%1" % (a0, a0 + 1, a0, a0 + 1),
                            '"=&v"(t0_), "=&v"(t1_)', '"v"(al_[%d])' % qb)
-            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d];" % ((qb, qb) * 2))
+            st.raw("    LS[%d][0] *= al_[%d]; LS[%d][1] *= al_[%d]; LS[%d][2] *= al_[%d]; LS[%d][3] *= al_[%d];" % ((qb, qb) * 4))
     for qb in range(2):
         for kb in range(2):
             for r in range(16):
@@ -244,11 +245,10 @@ def gen(mode, par, safe):
             _, kb, qb, r = f
             v = s_blk(par, kb, qb) + r
             st.asm("v_exp_f32 v%d, v%d" % (v, v))
-        elif kind == "scl":                                  # s' (raw q . k units) -> log2 domain, two scores per instruction; the constant pair lives in SGPRs
-            _, kb, qb, r = f
+        elif kind == "scl":                                  # s' (raw q . k units) -> log2 domain; the constant lives in an SGPR.  Two plain multiplies:
+            _, kb, qb, r = f                                 # a v_pk_mul_f32 costs ~22 cycles between MFMAs (measured, profiles/r5_attn4_packed_fp32.log), these two ~7
             v = s_blk(par, kb, qb) + r
-            assert v % 2 == 0
-            st.asm("v_pk_mul_f32 %s, %s, %%0 op_sel_hi:[1,0]" % (vreg(v, 2), vreg(v, 2)), "", '"s"(sl2x2_)')    # both lanes take the pair's LOW half (the form hipcc emits for a uniform scalar)
+            st.asm("v_mul_f32 v%d, %%0, v%d\\n\\tv_mul_f32 v%d, %%0, v%d" % (v, v, v + 1, v + 1), "", '"s"(sl2b_)')
         elif kind == "cvt":
             pair = f[1]
             kstep, qb, kb, r = elem(2 * pair)
@@ -259,11 +259,9 @@ def gen(mode, par, safe):
             kread_id[(ks, kb)] = kread(ks, kb, kslot_cur)
         elif kind == "vread":
             vstmt(f[1], f[2])
-        elif kind == "add":                                  # packed row sums: elements r, r + 1 -> the two lanes of LS[qb][(r >> 1) & 1] (four partial sums per row)
+        elif kind == "add":
             _, kb, qb, r = f
-            v = s_blk(par, kb, qb) + r
-            assert v % 2 == 0
-            st.asm("v_pk_add_f32 %%0, %%0, %s" % vreg(v, 2), '"+v"(LS[%d][%d])' % (qb, (r >> 1) & 1), "")
+            st.asm("v_add_f32 %%0, %%0, v%d" % (s_blk(par, kb, qb) + r), '"+v"(LS[%d][%d])' % (qb, r & 3), "")    # four partial sums: no dependent chain
         elif kind == "max":
             _, qb, kb, step = f
             s = s_blk(nxt, kb, qb)
@@ -288,13 +286,19 @@ def gen(mode, par, safe):
 
     # ------------------------------------------------------------------ phase A: 32 gaps
     a_fill = [[] for _ in range(32)]
+    a_pre = []                                               # fillers ahead of phase A's first MFMA
     if sm:
+        # pair a's scaling sits ONE GAP AHEAD of its two exponentials (one wave per SIMD: nobody covers the latency of a dependent
+        # VALU -> transcendental pair issued back to back; measured: +23 % on the whole kernel with the scaling right in front of them)
+        kstep, qb, kb, r = elem(0)
+        a_pre.append(("scl", kb, qb, r))
         for a in range(32):
-            kstep, qb, kb, r = elem(2 * a)
-            a_fill[a].append(("scl", kb, qb, r))             # the pair's scaling, then its two exponentials
             for e in (2 * a, 2 * a + 1):
                 kstep, qb, kb, r = elem(e)
                 a_fill[a].append(("exp", kb, qb, r))
+            if a + 1 < 32:
+                kstep, qb, kb, r = elem(2 * a + 2)
+                a_fill[a].append(("scl", kb, qb, r))
             if a >= 1:
                 a_fill[a].append(("cvt", a - 1))
     if qk:
@@ -312,6 +316,8 @@ def gen(mode, par, safe):
         for i in range(4):
             a_fill[1 + i].append(("dma", "K", i))
 
+    for f in a_pre:
+        do_filler(f)
     counts = []
     for a in range(32):
         n0 = len(st.lines)
@@ -331,15 +337,15 @@ def gen(mode, par, safe):
 
     # ------------------------------------------------------------------ phase B: 32 gaps
     b_fill = [[] for _ in range(32)]
-    if sm:                                                   # row sums: the 32 pairs, one or two per gap (phase A carries the scalings instead)
-        pr = 0
+    if sm:                                                   # row sums: all 64 elements here, two or three per gap (phase A carries the scalings instead)
+        e = 0
         for b in range(24):
-            for _ in range(1 if (pv and b % 2 == 0) else 2):
-                if pr < 32:
-                    kstep, qb, kb, r = elem(2 * pr)
+            for _ in range(2 if (pv and b % 3 == 0) else 3):
+                if e < 64:
+                    kstep, qb, kb, r = elem(e)
                     b_fill[b].append(("add", kb, qb, r))
-                    pr += 1
-        assert pr == 32
+                    e += 1
+        assert e == 64
     if pv:
         for k in range(1, 4):
             for db in range(4):
