@@ -87,7 +87,11 @@ def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
     images = torch.randn(B * frames, 3, 384, 384, generator=g)
     if device is None:                                       # --host-inputs: what a DataLoader with pin_memory hands the Trainer
         return tuple(t.pin_memory() for t in (ids, labels, mask, images))
-    return ids.to(device), labels.to(device), mask.to(device), images.to(device).to(torch.bfloat16)
+    # resident in HBM before the timed region; the integer tensors keep their host originals as mirrors -- what the collator of a real run
+    # holds anyway (reference batch contract train.py:1258-1284) -- so that the splice plan is built without a device -> host copy
+    from metamorph_amd import hostmirror
+    return (hostmirror.to_device(ids, device), hostmirror.to_device(labels, device), hostmirror.to_device(mask, device),
+            images.to(device).to(torch.bfloat16))
 
 
 def build_bench_model(dev, layers=32, vit_layers=27, image_tokens=256, seed=1234):
@@ -547,12 +551,13 @@ def main():
         timer.install()
         hbm_timer.install()
     step_no = [0]
+    from metamorph_amd import hostmirror
 
     def step():
         ids, labels, mask, images = pool[step_no[0] % n_pool]
         step_no[0] += 1
         if args.host_inputs:                                 # host -> HBM inside the step (HF Trainer._prepare_inputs), pixels cast on the device
-            ids, labels, mask = (t.to(dev, non_blocking=True) for t in (ids, labels, mask))
+            ids, labels, mask = (hostmirror.to_device(t, dev, non_blocking=True) for t in (ids, labels, mask))
             images = images.to(dev, non_blocking=True).to(torch.bfloat16)
         opt.zero_grad()
         out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images)

@@ -1129,7 +1129,8 @@ class SpliceFn(Function):
 class EmbeddingFn(Function):
     """Plain `embed_tokens(ids)` WITH a gradient: the text-only training path (forward(images=None): the reference's splice returns early,
     metamorph_arch.py:184-191, and HF's LlamaModel embeds the ids itself).  Backward = the splice's deterministic segmented row sum
-    (`mm355_embed_grad`: rows sorted by token id on the host, one D2H copy of the ids -- this is not the hot path)."""
+    (`mm355_embed_grad`: rows sorted by token id on the host, from the ids' host mirror if their mover registered one -- hostmirror.py --,
+    else one D2H copy; this is not the hot path)."""
 
     @staticmethod
     def forward(ctx, embed_weight, embed_module, ids):
@@ -1143,7 +1144,8 @@ class EmbeddingFn(Function):
     def backward(ctx, dout):
         w = ctx.embed_module.weight
         if w.requires_grad:
-            flat = ctx.ids.reshape(-1).detach().cpu().numpy().astype(np.int64)
+            from .hostmirror import host_array
+            flat = host_array(ctx.ids).reshape(-1).astype(np.int64)
             order = np.argsort(flat, kind="stable")
             sorted_tok = flat[order]
             starts = np.flatnonzero(np.concatenate(([True], sorted_tok[1:] != sorted_tok[:-1])))

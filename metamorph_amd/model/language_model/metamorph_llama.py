@@ -30,6 +30,7 @@ from ... import functional as F
 from ... import ops
 from ...constants import DEFAULT_IMAGE_END_ID, DEFAULT_IMAGE_START_ID, IGNORE_INDEX
 from ...splice_plan import SplicePlan
+from ...hostmirror import host_array
 from ..metamorph_arch import MetaMorphMetaForCausalLM, MetaMorphMetaModel, upload_plan
 from ..modules import HipEmbedding, HipGELU, HipLinear, HipRMSNorm
 
@@ -296,13 +297,13 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
             return cached[1]
         # inputs_embeds supplied by the caller: derive the index arrays from the given tensors (one host copy)
         B, L, _ = inputs_embeds.shape
-        msk = np.ones((B, L), dtype=bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
+        msk = np.ones((B, L), dtype=bool) if attention_mask is None else host_array(attention_mask).astype(bool)
         left = getattr(self.config, "tokenizer_padding_side", "right") == "left"
         seqlens = msk.sum(1).astype(np.int32)
         if not all((msk[b, L - seqlens[b]:] if left else msk[b, : seqlens[b]]).all() for b in range(B)):
             raise NotImplementedError("attention_mask must be a contiguous padding mask on the configured tokenizer_padding_side")
-        lab = None if labels is None else labels.detach().cpu().numpy()
-        pos = np.zeros((B, L), dtype=np.int64) if image_positions is None else image_positions.detach().cpu().numpy()
+        lab = host_array(labels)
+        pos = np.zeros((B, L), dtype=np.int64) if image_positions is None else host_array(image_positions)
         nxt = np.zeros((B, L), dtype=bool)
         nxt[:, :-1] = pos[:, 1:] == 1
         st = ce_rows = None

@@ -15,6 +15,7 @@ import torch
 from .. import functional as F
 from .. import ops
 from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_IMAGE_START_ID
+from ..hostmirror import host_array
 from ..splice_plan import SplicePlan, build_splice_plan
 from .modules import HipLinear
 from .multimodal_encoder.builder import build_vision_tower
@@ -71,7 +72,38 @@ class PlanOnDevice(dict):
     """int32 index arrays of a SplicePlan uploaded once (one pinned staging copy) + the host plan itself."""
 
 
-def upload_plan(plan: SplicePlan, device) -> PlanOnDevice:
+class _PinnedStage:
+    """Two rotating pinned staging buffers (grow-only) for the per-step plan upload: no host allocation per step, and a buffer is reused
+    only after the copy that last read it has finished (an event per buffer; by then two steps have passed)."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.events = [None, None]
+        self.i = 0
+
+    def take(self, nbytes):
+        self.i ^= 1
+        ev = self.events[self.i]
+        if ev is not None:
+            ev.synchronize()
+        b = self.bufs[self.i]
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+            self.bufs[self.i] = b
+        return b
+
+    def sent(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.i] = ev
+
+
+_STAGE = _PinnedStage()
+
+
+def upload_plan(plan: SplicePlan, device, extra=None) -> PlanOnDevice:
+    """Every array the step needs from the host plan in ONE pinned, asynchronous host -> device copy: the int32 index arrays, and (extra)
+    the [B, L] tensors handed back to the caller (labels, attention mask, image positions, position ids) in their own dtypes."""
     names = ["src", "feat_row", "pred_rows", "seqlens", "emb_tok", "emb_seg", "emb_pos"]
     arrays = {n: getattr(plan, n).astype(np.int32, copy=False) for n in names}
     M = plan.B * plan.L
@@ -81,18 +113,31 @@ def upload_plan(plan: SplicePlan, device) -> PlanOnDevice:
         inv = np.full(M, -1, dtype=np.int32)
         inv[plan.ce_rows] = np.arange(plan.ce_rows.shape[0], dtype=np.int32)
         arrays["ce_inv"] = inv
-    sizes = {k: int(v.shape[0]) for k, v in arrays.items()}
+    for k, v in (extra or {}).items():
+        if v is not None:
+            arrays["x_" + k] = np.ascontiguousarray(v)
     offs, total = {}, 0
-    for k, n in sizes.items():
-        offs[k] = total
-        total += (n + 3) // 4 * 4                           # keep every array 16-byte aligned
-    host = np.zeros(max(total, 4), dtype=np.int32)
     for k, v in arrays.items():
-        host[offs[k]: offs[k] + sizes[k]] = v
-    t = torch.from_numpy(host)
-    if torch.device(device).type == "cuda":
-        t = t.pin_memory().to(device, non_blocking=True)
-    out = PlanOnDevice({k: t[offs[k]: offs[k] + sizes[k]] for k in arrays})
+        offs[k] = total
+        total += (v.nbytes + 15) // 16 * 16                  # keep every array 16-byte aligned
+    cuda = torch.device(device).type == "cuda"
+    if cuda:
+        stage = _STAGE.take(total)
+        host = stage.numpy()
+    else:
+        host = np.zeros(max(total, 16), dtype=np.uint8)
+    for k, v in arrays.items():
+        host[offs[k]: offs[k] + v.nbytes] = v.reshape(-1).view(np.uint8)
+    if cuda:
+        t = stage[:max(total, 16)].to(device, non_blocking=True)
+        _STAGE.sent()
+    else:
+        t = torch.from_numpy(host)
+    out = PlanOnDevice()
+    for k, v in arrays.items():
+        td = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.bool_): torch.bool,
+              np.dtype(np.uint8): torch.uint8}[v.dtype]
+        out[k] = t[offs[k]: offs[k] + v.nbytes].view(td).view(v.shape)
     out["host"] = plan
     return out
 
@@ -151,15 +196,18 @@ class MetaMorphMetaForCausalLM(ABC):
         cfg = self.config
         N, T, h = image_features.shape
         dev = image_features.device
-        # ONE host copy of the integer inputs (the reference syncs once per sample instead)
-        ids_h = input_ids.detach().cpu().numpy()
-        lab_h = labels.detach().cpu().numpy() if labels is not None else None
-        msk_h = attention_mask.detach().cpu().numpy() if attention_mask is not None else None
+        # The integer inputs on the host: CPU tensors as they are, device tensors through the mirror their mover registered
+        # (metamorph_amd.hostmirror: MetaMorphTrainer / bench.py do) -- no device -> host copy, no synchronisation; unknown device tensors
+        # fall back to ONE host copy (the reference syncs once per sample instead)
+        ids_h, lab_h, msk_h = host_array(input_ids), host_array(labels), host_array(attention_mask)
         plan = build_splice_plan(ids_h, lab_h, msk_h, N, T, getattr(cfg, "tokenizer_model_max_length", None),
                                  getattr(cfg, "tokenizer_padding_side", "right"),
                                  getattr(cfg, "image_start_id", DEFAULT_IMAGE_START_ID),
                                  vocab_size=self.get_model().embed_tokens.weight.shape[0])
-        pd = upload_plan(plan, dev)
+        keep_np = plan.target_keep.astype(np.int32) if 0 < plan.target_keep.shape[0] != N else None
+        mask_np = None if attention_mask is None else plan.attention_mask.astype(np.bool_ if attention_mask.dtype == torch.bool else np.int64)
+        pd = upload_plan(plan, dev, extra=dict(labels=plan.labels, mask=mask_np, image_positions=plan.image_positions,
+                                               position_ids=None if position_ids is None else plan.position_ids, keep=keep_np))
         emb = self.get_model().embed_tokens
         proj2d = image_features.reshape(N * T, h)
         if torch.is_grad_enabled() and (emb.weight.requires_grad or proj2d.requires_grad):
@@ -168,21 +216,20 @@ class MetaMorphMetaForCausalLM(ABC):
             x = ops.splice_gather(emb.weight.data, proj2d.detach(), pd["src"], h)
         inputs_embeds = x.view(plan.B, plan.L, h)
 
-        new_labels = torch.from_numpy(plan.labels).to(dev) if plan.labels is not None else None
+        new_labels = pd.get("x_labels")                      # (all four came over in the plan's one upload)
         if attention_mask is None:
             new_mask = None
         else:
-            new_mask = torch.from_numpy(plan.attention_mask).to(device=dev, dtype=attention_mask.dtype)
-        new_pos = None if position_ids is None else torch.from_numpy(plan.position_ids).to(dev)
-        image_positions = torch.from_numpy(plan.image_positions).to(dev)
+            new_mask = pd["x_mask"] if pd["x_mask"].dtype == attention_mask.dtype else pd["x_mask"].to(attention_mask.dtype)
+        new_pos = pd.get("x_position_ids")
+        image_positions = pd["x_image_positions"]
         if plan.target_keep.shape[0] != N:                  # keep only answer-image features (metamorph_arch.py:415-423)
             Na = int(plan.target_keep.shape[0])
             if Na == 0:
                 target_features = target_features[:0]
             else:
-                keep = torch.from_numpy(plan.target_keep.astype(np.int32)).to(dev)
                 C = target_features.shape[-1]
-                target_features = ops.rows_gather(target_features.reshape(N, T * C).contiguous(), keep).view(Na, T, C)
+                target_features = ops.rows_gather(target_features.reshape(N, T * C).contiguous(), pd["x_keep"]).view(Na, T, C)
         # remember the plan for llm_forward (same tensor object => same plan)
         self._mm_plan = (inputs_embeds, pd)
         return None, new_pos, new_mask, past_key_values, inputs_embeds, new_labels, image_positions, target_features

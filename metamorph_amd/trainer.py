@@ -29,6 +29,7 @@ from transformers import Trainer
 
 from .checkpoint import consolidate_optimizer_state, load_consolidated_optimizer_state, save_trainer_adapter_checkpoint
 from . import functional as F
+from . import hostmirror
 from .zero2 import Zero2AdamW, tag_segments
 from .zero3 import Zero3AdamW
 
@@ -129,6 +130,19 @@ class MetaMorphTrainer(Trainer):
         while opt is not None and not isinstance(opt, (Zero2AdamW, Zero3AdamW)):
             opt = getattr(opt, "optimizer", None)                    # accelerate's AcceleratedOptimizer wrapper
         return opt
+
+    def _prepare_inputs(self, inputs):
+        """HF moves the collator's batch to the device here; the integer tensors the splice plan is built from (reference batch contract,
+        train.py:1258-1284) keep their host originals registered as mirrors (metamorph_amd.hostmirror), so the model's forward neither copies
+        them back nor synchronises with the device."""
+        out = super()._prepare_inputs(inputs)
+        if isinstance(inputs, dict) and isinstance(out, dict):
+            for k in ("input_ids", "labels", "attention_mask"):
+                src, dst = inputs.get(k), out.get(k)
+                if isinstance(src, torch.Tensor) and isinstance(dst, torch.Tensor) and src.device.type == "cpu" and dst.device.type != "cpu" \
+                        and src.dtype == dst.dtype and src.shape == dst.shape:
+                    hostmirror.attach(dst, src)
+        return out
 
     def training_step(self, model, inputs, num_items_in_batch=None):
         z = self._zero2()

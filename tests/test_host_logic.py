@@ -864,3 +864,49 @@ def test_gemm_st_lds_address_algebra():
             want = {row * 512 + (((2 * g + e) ^ (row & 7)) << 4) for e in range(2)}
             have = {row * 512 + (((c) ^ (row & 7)) << 4) for c in range(32) if c // 2 == g}
             assert want == have
+
+
+def test_host_mirrors_serve_the_splice_plan_without_a_device_copy():
+    """metamorph_amd.hostmirror: the integer batch tensors keep their host originals when they are moved to the device, so that the splice
+    plan (host integer work) needs no device -> host copy and no synchronisation.  A mirror dies with its tensor, is invalidated by an
+    in-place write, and CPU tensors are their own mirror."""
+    import gc
+    from metamorph_amd import hostmirror as HM
+    ids = torch.arange(12).view(3, 4)
+    before = dict(HM.STATS)
+    assert HM.host_array(ids) is not None and HM.STATS["cpu"] == before["cpu"] + 1          # a CPU tensor: its own storage, no copy
+    assert np.shares_memory(HM.host_array(ids), ids.numpy())
+    fake_dev = ids.clone()                                        # stands in for the device copy (same API: object identity + version)
+    HM.attach(fake_dev, ids)
+    ent = HM._MIRRORS[id(fake_dev)]
+    assert ent[0]() is fake_dev and np.array_equal(ent[2], ids.numpy())
+    v0 = fake_dev._version
+    fake_dev.add_(1)                                              # an in-place write: the mirror no longer describes the tensor
+    assert fake_dev._version != v0 and HM._MIRRORS[id(fake_dev)][1] == v0
+    with pytest.raises(ValueError):
+        HM.attach(fake_dev, ids[:2])
+    n = len(HM._MIRRORS)
+    del fake_dev
+    gc.collect()
+    assert len(HM._MIRRORS) == n - 1                              # weak: no tensor is kept alive by its mirror
+    assert HM.host_array(None) is None
+
+
+def test_upload_plan_packs_every_array_with_its_dtype():
+    """upload_plan: the index arrays and the [B, L] tensors handed back to the caller travel in ONE buffer (16-byte aligned pieces, own
+    dtypes); on the CPU path the views must reproduce the host arrays exactly."""
+    from metamorph_amd.model.metamorph_arch import upload_plan
+    from metamorph_amd.splice_plan import build_splice_plan
+    ids = np.array([[1, 5, 128256, -200, 128257, 7, 9, 0], [1, 4, 6, 8, 3, 0, 0, 0]])
+    lab = np.where(ids > 5, ids, -100)
+    msk = np.array([[1] * 7 + [0], [1] * 5 + [0] * 3], dtype=bool)
+    plan = build_splice_plan(ids, lab, msk, 2, 3, 64, "right", 128256, vocab_size=128258)
+    pd = upload_plan(plan, "cpu", extra=dict(labels=plan.labels, mask=plan.attention_mask, image_positions=plan.image_positions,
+                                             position_ids=None, keep=np.array([0], dtype=np.int32)))
+    assert pd["x_labels"].dtype == torch.int64 and torch.equal(pd["x_labels"], torch.from_numpy(plan.labels))
+    assert pd["x_mask"].dtype == torch.bool and torch.equal(pd["x_mask"], torch.from_numpy(plan.attention_mask))
+    assert torch.equal(pd["x_image_positions"], torch.from_numpy(plan.image_positions)) and "x_position_ids" not in pd
+    assert pd["x_keep"].dtype == torch.int32 and pd["x_keep"].tolist() == [0]
+    for k in ("src", "feat_row", "pred_rows", "seqlens", "emb_tok", "emb_seg", "emb_pos", "ce_rows"):
+        assert pd[k].dtype == torch.int32 and np.array_equal(pd[k].numpy(), np.asarray(getattr(plan, k), dtype=np.int32)), k
+        assert pd[k].data_ptr() % 16 == 0 or pd[k].numel() == 0, k

@@ -688,6 +688,28 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
             assert torch.allclose(x[0], y[b], rtol=2e-2, atol=2e-2), (b, step, float((x[0] - y[b]).abs().max()))
 
 
+def test_forward_with_host_mirrors_does_not_touch_the_device_for_its_plan():
+    """The splice plan is host integer work; with the batch's host originals registered as mirrors (metamorph_amd.hostmirror: what
+    MetaMorphTrainer._prepare_inputs and bench.py do when they move a batch to the device) `forward` builds it without copying ids / labels /
+    mask back -- no device -> host synchronisation per step (round 4: one `.cpu()` per tensor and step) -- and returns the same bits."""
+    from metamorph_amd import hostmirror as HM
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4)
+    model = hip_model(cfg, init_state_dict(cfg, seed=11, dtype=torch.bfloat16))
+    model.train()
+    ids, msk, lab, img = T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]).to(DEV).bfloat16()
+    plain = model(input_ids=ids.to(DEV), attention_mask=msk.to(DEV), labels=lab.to(DEV), images=img)
+    s0 = dict(HM.STATS)
+    mirrored = model(input_ids=HM.to_device(ids, DEV), attention_mask=HM.to_device(msk, DEV), labels=HM.to_device(lab, DEV), images=img)
+    assert HM.STATS["sync"] == s0["sync"] and HM.STATS["mirror"] >= s0["mirror"] + 3, (s0, HM.STATS)
+    cpu_in = model(input_ids=ids, attention_mask=msk, labels=lab, images=img)                 # CPU tensors are their own mirror
+    assert HM.STATS["sync"] == s0["sync"]
+    for out in (mirrored, cpu_in):
+        assert torch.equal(out.loss, plain.loss) and torch.equal(out.hidden_states, plain.hidden_states)
+    mirrored.loss.backward()
+    assert HM.STATS["sync"] == s0["sync"]
+
+
 def test_bench_emits_the_driver_contract_on_device():
     """`python bench.py --layers 2 --vit-layers 2 --steps 2 --warmup 1 --batch 2` really runs (a 2-layer debug geometry, NOT the headline
     config) and its ONE stdout line carries the driver's contract: the required keys, value = tokens of the timed steps / their wall time,
