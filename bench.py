@@ -258,6 +258,46 @@ def _cpu_threads():
     return max(1, min(avail, 32))          # 32 threads beat 64 / 128 / 256 on the GPU box host (profiles/r3_host_threads.log)
 
 
+# ------------------------------------------------------------------------------------------------ pre-registered N-GPU expectation
+# This build has never run on more than one GPU (every lease is a 1-GPU box).  So that the driver's 1 / 2 / 4 / 8-GPU run is a TEST and not
+# a first look, the expectation is written down here and in DESIGN.md section 6 BEFORE that run, from one-GPU measurements + stated link
+# assumptions, and every multi-rank bench line carries it (`predicted`) beside what it measured.
+ONE_RANK_REFERENCE_MS = {(16, 2048, 1): 1240.0}      # (per-GPU batch, seq, frames) -> one-rank ms/step (profiles/r5_bench_default_*.json: 1 233 - 1 248)
+XGMI_LINK_GBS = 153.0            # per link and direction, MI355X_MICROARCH.md (7 links per GPU, point-to-point)
+XGMI_EFFICIENCY = 0.8            # of the link rate that RCCL's kernels sustain (assumed)
+GEMM_SLOWDOWN_UNDER_COLLECTIVE = 0.10    # measured on one GPU with a CU-holding side kernel: 7-13 % (profiles/r2_gemm_cu_thief.log)
+
+
+def predict_step(world, step1_ms, adamw_ms, seg_bytes, tail_bytes, gemm_share=0.83, layer_bwd_ms=None, n_layers=32):
+    """Per-rank step time of the weak-scaling job at `world` ranks from the one-rank step (`step1_ms`, of which `adamw_ms` is the sharded
+    update): gradients of one decoder layer (`seg_bytes`, bf16) are reduce-scattered while the backward of the next layer runs, the
+    `tail_bytes` of everything outside the decoder (embeddings, lm_head, heads) at step(), all parameters all-gathered after the update.
+    Two collective algorithms bound the prediction: "ring" (every byte crosses ONE link per hop: (N-1)/N * S per link) and "direct" (shard j
+    goes straight to rank j over its own link: S / N per link)."""
+    if world <= 1:
+        return {"world": 1, "ms_per_step": round(step1_ms, 1)}
+    link = XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9
+    total = seg_bytes * n_layers + tail_bytes
+    out = {"world": world, "assumptions": {"xgmi_link_GBps": XGMI_LINK_GBS, "link_efficiency": XGMI_EFFICIENCY,
+                                           "gemm_slowdown_while_collective_resident": GEMM_SLOWDOWN_UNDER_COLLECTIVE,
+                                           "one_rank_step_ms": round(step1_ms, 1), "one_rank_adamw_ms": round(adamw_ms, 1),
+                                           "grad_bytes_per_layer_segment": int(seg_bytes), "grad_bytes_outside_decoder": int(tail_bytes)}}
+    layer_bwd_ms = layer_bwd_ms if layer_bwd_ms is not None else (step1_ms - adamw_ms) * (2.0 / 3.0) / n_layers
+    for algo, per_link in (("ring", (world - 1) / world), ("direct", 1.0 / world)):
+        rs_seg = seg_bytes * per_link / link * 1e3                       # ms one layer's reduce-scatter keeps the links (and some CUs) busy
+        rs_tail = tail_bytes * per_link / link * 1e3                     # exposed: issued at step(), nothing left to hide it
+        ag_all = total * per_link / link * 1e3                           # exposed with the synchronous update (async_update hides most of it)
+        hidden = min(rs_seg, layer_bwd_ms)                               # a segment's reduce-scatter hides under the next layer's backward
+        exposed_rs = rs_tail + n_layers * (rs_seg - hidden) + rs_seg     # + the last layer's segment (nothing behind it)
+        slow = GEMM_SLOWDOWN_UNDER_COLLECTIVE * gemm_share * (n_layers * hidden)
+        compute = step1_ms - adamw_ms * (1.0 - 1.0 / world)
+        ms = compute + exposed_rs + ag_all + slow
+        out[algo] = {"ms_per_step": round(ms, 1), "scaling_vs_one_rank": round(world * step1_ms / ms, 2),
+                     "exposed_reduce_scatter_ms": round(exposed_rs, 1), "all_gather_ms": round(ag_all, 1), "gemm_slowdown_ms": round(slow, 1),
+                     "compute_ms": round(compute, 1)}
+    return out
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/ref_model.py, kind 'port') on a bounded sample of the same workload: ONE sample built like the bench's
     (one 256-token image + text, labels as in make_batch) at the workload's own length (2048 spliced tokens), LLaMA-3-8B / SO400M layer
@@ -318,7 +358,10 @@ def cpu_baseline(args):
                        f"{NV}/27 tower layers + full lm_head; measured per stage: decoder layer forward " + " / ".join(f"{t:.2f}s" for t in t_layers)
                        + f", decoder backward ({NL} layers) {t_dec_b:.2f}s, heads fwd {t_head_f:.2f}s bwd {t_head_b:.2f}s, embedding + projector bwd {t_emb_b:.2f}s, tower ({NV} layers) {t_vit:.2f}s; "
                        f"per-layer cost {per_layer:.2f}s (mean of {NL} separately timed layers) x 32 + heads + tower x 27/{NV} = {full:.1f}s per {L} tokens"),
+            # two explicit fields (not prose): what the host clock measured for the layers actually run, and what `value` is quoted on
             "measured_seconds": round(sum(t_layers) + t_dec_b + t_head + t_vit, 2),
+            "extrapolated_seconds_full_depth": round(full, 2),
+            "layers_run": {"decoder": NL, "decoder_full": 32, "tower": NV, "tower_full": 27},
             "decoder_layer_forward_seconds": [round(t, 3) for t in t_layers]}
 
 
@@ -705,6 +748,18 @@ def main():
         }
         if roofline:
             rec["roofline"] = roofline
+        # the pre-registered multi-GPU expectation: at one rank for 2 / 4 / 8 ranks from THIS run's step time, at N > 1
+        # for this N from the committed one-rank reference -- beside the measured `ms_per_step`
+        seg_b, tail_b = 218_112_000 * 2.0, (n_params - 32 * 218_112_000) * 2.0 if args.layers == 32 else 0.0
+        if args.layers == 32 and not args.train_vision and args.zero == 2:
+            adamw_ms = 39.4 * (n_params / 8.07e9)
+            if world == 1:
+                rec["predicted_scaling"] = [predict_step(n, dt / args.steps * 1e3, adamw_ms, seg_b, tail_b) for n in (2, 4, 8)]
+            else:
+                ref_ms = ONE_RANK_REFERENCE_MS.get((args.batch, args.seq, args.frames))
+                if ref_ms:
+                    rec["predicted"] = predict_step(world, ref_ms, adamw_ms, seg_b, tail_b)
+                    rec["predicted_ms_per_step"] = {k: rec["predicted"][k]["ms_per_step"] for k in ("ring", "direct")}
         rec["rccl_ranks"] = dist.get_world_size() if (world > 1 or force_dist) else 1
         if dist_run:
             rec["params_equal_across_ranks"] = params_equal

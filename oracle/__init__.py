@@ -5,7 +5,7 @@ one hot path of facebookresearch/metamorph that `metamorph_amd` accelerates:
 SigLIP tower -> token-reduce + L2 norm -> mm_projector -> <image>/text splice ->
 LLaMA decoder -> {lm_head + CE, vision_head + cosine}.
 
-Rules (enforced by tests/test_oracle_isolation.py):
+Rules (enforced by tests/test_host_logic.py::test_product_never_imports_oracle_or_reference):
   * only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
     import anything from this package;
   * nothing under `metamorph_amd/` imports it -- the product fails loudly when

@@ -910,3 +910,23 @@ def test_upload_plan_packs_every_array_with_its_dtype():
     for k in ("src", "feat_row", "pred_rows", "seqlens", "emb_tok", "emb_seg", "emb_pos", "ce_rows"):
         assert pd[k].dtype == torch.int32 and np.array_equal(pd[k].numpy(), np.asarray(getattr(plan, k), dtype=np.int32)), k
         assert pd[k].data_ptr() % 16 == 0 or pd[k].numel() == 0, k
+
+
+def test_pre_registered_multi_gpu_prediction_model():
+    """bench.predict_step: the expectation for the N-GPU runs this build never sees, written down before the driver's
+    scaling run: one rank returns the measured step; more ranks subtract the sharded part of AdamW, add what the links cannot hide; the
+    direct (one hop per shard) algorithm is never slower than the ring; everything is finite and the 8-GPU figures are the ones DESIGN quotes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seg, tail = 218_112_000 * 2.0, (8.07e9 - 32 * 218_112_000) * 2.0
+    assert b.predict_step(1, 1240.0, 39.4, seg, tail) == {"world": 1, "ms_per_step": 1240.0}
+    last = None
+    for n in (2, 4, 8):
+        r = b.predict_step(n, 1240.0, 39.4, seg, tail)
+        assert r["direct"]["ms_per_step"] <= r["ring"]["ms_per_step"]
+        assert r["ring"]["compute_ms"] == round(1240.0 - 39.4 * (1 - 1 / n), 1)
+        assert r["ring"]["all_gather_ms"] > r["direct"]["all_gather_ms"] or n == 2
+        last = r
+    assert 7.0 <= last["ring"]["scaling_vs_one_rank"] <= 7.7 and 7.8 <= last["direct"]["scaling_vs_one_rank"] <= 8.2, last
