@@ -309,8 +309,11 @@ int mm355_attn_decode(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cac
                       mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,
                       float* workspace, void* stream);
 /* tests / tools: variant 0 = as mm355_attn_decode (one 1024-thread workgroup per sample, KV head and 1024 cached rows; the lone
- * workgroup of a cache of <= 1024 rows writes the output itself: no device-scope fence), 1 = one 256-thread workgroup per 256-row chunk +
- * merge by the last. */
+ * workgroup of a cache of <= 1024 rows writes the output itself: no device-scope fence -- and, when max_kv_len <= 1024, the GQA group is
+ * spread over one workgroup per query head (pairs of heads from 64 workgroups on): same arithmetic, bit-identical output, half the
+ * launch time), 1 = one 256-thread workgroup per 256-row chunk + merge by the last, 2 = variant 0 with the whole GQA group in one
+ * workgroup whatever the bound.  max_kv_len is a LAUNCH parameter: a caller that knows its lengths on the host passes 1024 while every
+ * kv_lens[b] <= 1024 and the capacity afterwards (metamorph_amd.functional.decode_kv_bound). */
 int mm355_attn_decode_variant(const mm355_bf16* q, int64_t ld_q, const mm355_bf16* k_cache, const mm355_bf16* v_cache,
                       int64_t ld_kv, int64_t batch_stride_kv, const int32_t* kv_lens, int64_t max_kv_len,
                       mm355_bf16* o, int64_t ld_o, int64_t B, int64_t Hq, int64_t Hkv, int64_t d, float scale,

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
                                                                 const uint16_t* __restrict__ vc, int64_t ld_kv, int64_t bs_kv,
                                                                 const int32_t* __restrict__ kv_lens, float* __restrict__ ws, int ngroup,
                                                                 int Hq, int Hkv, int d, float scale, uint16_t* __restrict__ o, int64_t ld_o,
-                                                                int* __restrict__ counters) {
+                                                                int* __restrict__ counters, int kvdiv) {
     constexpr int SB = 4;
     constexpr int NB = G >= 8 ? 2 : (G >= 4 ? 4 : 8);                       // K / V rows per lane in flight (128 registers per thread at 16 waves per CU)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int kk = k0 + wave * 64 + (h * NB + i) * 4 + kq;
-                    kraw[i] = (kk < kv_len && dc * 8 < d) ? *(const u32x4*)(kc + (int64_t)b * bs_kv + (int64_t)kk * ld_kv + (int64_t)hk * d + dc * 8)
+                    kraw[i] = (kk < kv_len && dc * 8 < d) ? *(const u32x4*)(kc + (int64_t)b * bs_kv + (int64_t)kk * ld_kv + (int64_t)(hk / kvdiv) * d + dc * 8)
                                                           : u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int kk = kg + (h * NB + i) * 16;
-                    vraw[i] = (kk < kend && dc * 8 < d) ? *(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)hk * d + dc * 8)
+                    vraw[i] = (kk < kend && dc * 8 < d) ? *(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)(hk / kvdiv) * d + dc * 8)
                                                         : u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
@@ -988,14 +988,15 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
     }
 }
 
+// G = query heads per workgroup; Hgrp = Hq / G workgroups per sample and key group, each reading cache head (its index) / kvdiv
 template <int G>
 int launch_wide(const uint16_t* q, int64_t ld_q, const uint16_t* kc, const uint16_t* vc, int64_t ld_kv, int64_t bs_kv, const int32_t* kv_lens,
-                float* ws, int ngroup, int B, int Hq, int Hkv, int d, float scale, uint16_t* o, int64_t ld_o, int* counters, hipStream_t s) {
+                float* ws, int ngroup, int B, int Hq, int Hgrp, int d, float scale, uint16_t* o, int64_t ld_o, int* counters, hipStream_t s, int kvdiv = 1) {
     constexpr int LDS = (G * 128 + 4 * G * CH + 2 * 4 * G * 4 + 16 * G * 128) * 4;
     static std::atomic<uint64_t> lds_ok{0};
     if (LDS > 65536 && mm_ensure_dynamic_lds((const void*)attn_decode_wide_kernel<G>, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
-    hipLaunchKernelGGL(attn_decode_wide_kernel<G>, dim3((unsigned)ngroup, (unsigned)Hkv, (unsigned)B), dim3(1024), LDS, s, q, ld_q, kc, vc, ld_kv,
-                       bs_kv, kv_lens, ws, ngroup, Hq, Hkv, d, scale, o, ld_o, counters);
+    hipLaunchKernelGGL(attn_decode_wide_kernel<G>, dim3((unsigned)ngroup, (unsigned)Hgrp, (unsigned)B), dim3(1024), LDS, s, q, ld_q, kc, vc, ld_kv,
+                       bs_kv, kv_lens, ws, ngroup, Hq, Hgrp, d, scale, o, ld_o, counters, kvdiv);
     return mm_launch_status();
 }
 
@@ -1074,7 +1075,22 @@ static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16*
         return MM355_EINVAL;
     if (d <= 0 || d > 128 || (d & 7) || (ld_kv & 7) || (batch_stride_kv & 7) || !mm_aligned16(k_cache) || !mm_aligned16(v_cache)) return MM355_EINVAL;
     if (B > 65535 || Hkv > 65535) return MM355_EINVAL;
-    if (variant < 0 || variant > 1) return MM355_EINVAL;
+    if (variant < 0 || variant > 2) return MM355_EINVAL;      // 2 = variant 0 with the whole GQA group in one workgroup whatever the bound
+    const int64_t G0_ = Hq / Hkv;
+    if (variant == 0 && max_kv_len <= 4 * CH && (G0_ == 2 || G0_ == 4 || G0_ == 8)) {
+        // a cache bound of <= 1024 rows is ONE key group: its lone workgroup per head group finishes without records or fences, so the
+        // GQA group can be spread over more workgroups -- one query head each (two from 64 workgroups on): 32 workgroups instead of 8 for
+        // one LLaMA-3-8B sample, 21 -> 10.5 us per launch (profiles/r5_attn_decode_heads_per_workgroup.log); the K / V rows are read by
+        // every workgroup of the group (L2 hits).  Same arithmetic per head: bit-identical outputs.  Longer bounds keep the whole group in
+        // one workgroup (fewer fences when the groups merge: the split forms are 2 - 4 x SLOWER there).
+        const int G0 = (int)(Hq / Hkv);
+        const int gw = (B * Hq <= 64 || G0 == 2) ? 1 : 2;
+        int* counters_ = (int*)workspace;
+        float* recs_ = workspace + decode_counter_floats(B, Hq);
+        hipStream_t s_ = (hipStream_t)stream;
+        if (gw == 1) return launch_wide<1>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, recs_, 1, (int)B, (int)Hq, (int)Hq, (int)d, scale, o, ld_o, counters_, s_, G0);
+        return launch_wide<2>(q, ld_q, k_cache, v_cache, ld_kv, batch_stride_kv, kv_lens, recs_, 1, (int)B, (int)Hq, (int)(Hq / 2), (int)d, scale, o, ld_o, counters_, s_, G0 / 2);
+    }
     const int G = (int)(Hq / Hkv);
     const int nsplit = (int)((max_kv_len + CH - 1) / CH);
     const int ngroup = (nsplit + 3) / 4;                     // 1024-key groups: one workgroup each

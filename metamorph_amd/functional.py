@@ -805,7 +805,7 @@ def decoder_prefill(x, layers, meta, cache, row=0):
     return x
 
 
-def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_len):
+def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bound):
     """<= 16 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
     every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: one or two rows on the vector ALU, 3 .. 16 on MFMA), attention per
     row at its own length."""
@@ -824,7 +824,7 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_le
             n1 = x if fold else ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
             qkv = ops.gemv_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],
                                        norm_w=layer.input_layernorm.weight if fold else None, eps=meta.eps)
-            o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, max_len, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
+            o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, kv_bound, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
             x2 = ops.gemv(o, att.o_proj.weight, residual=x)
             n2 = x2 if fold else ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
             act = ops.gemv_swiglu(n2, wgu, meta.I, norm_w=layer.post_attention_layernorm.weight if fold else None, eps=meta.eps)
@@ -833,7 +833,7 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_le
         n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
         qkv = ops.gemv(n1, wqkv)
         ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i])
-        o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, max_len, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
+        o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, kv_bound, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
         x2 = ops.gemv(o, att.o_proj.weight, residual=x)
         n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
         gu = ops.gemv(n2, wgu)
@@ -842,7 +842,17 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, max_le
     return x
 
 
-def decoder_decode_row(x, layers, meta, cache, cos, sin):
+SHORT_KV = 1024                                              # mm355_attn_decode: a bound of <= 1024 rows is one key group (no merge, more workgroups)
+
+
+def decode_kv_bound(cache):
+    """The static upper bound on the cached lengths handed to mm355_attn_decode for the NEXT step: 1024 while every sequence (incl. the row
+    being appended) still fits one key group -- the kernel then runs its single-group form --, the cache's capacity afterwards.  The host
+    knows the lengths (cache.lengths); the bound is a launch parameter, so a captured step exists once per bound (DecodeStepGraph)."""
+    return SHORT_KV if (cache.length + 1 <= SHORT_KV and cache.max_len >= SHORT_KV) else cache.max_len
+
+
+def decoder_decode_row(x, layers, meta, cache, cos, sin, kv_bound=None):
     """One new row PER SEQUENCE against the cache (reference semantics: HF LlamaDecoderLayer with past_key_values, the whole batch in one
     forward per step -- metamorph_llama.py:711-717; the reference's own greedy loop recomputes the prefix instead, :502-597).
     x [batch, h] -> [batch, h]; row b is appended at cache.lengths[b].  The batch goes through the layers in ONE pass (16 rows at a time):
@@ -854,11 +864,12 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
     B = x.shape[0]
     if B != cache.batch:
         raise ValueError(f"{B} rows for a cache of {cache.batch} sequences")
+    bound = decode_kv_bound(cache) if kv_bound is None else kv_bound
     if B <= 16:
-        y = _decode_rows16(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, cache.max_len)
+        y = _decode_rows16(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, bound)
     else:
         y = torch.cat([_decode_rows16(x[c:c + 16], layers, meta, cos, sin, cache.k[:, c:c + 16], cache.v[:, c:c + 16], cache.pos_dev[c:c + 16],
-                                      cache.len_dev[c:c + 16], cache.ws, cache.max_len) for c in range(0, B, 16)], 0)
+                                      cache.len_dev[c:c + 16], cache.ws, bound) for c in range(0, B, 16)], 0)
     cache.pos_dev.add_(1)
     cache.len_dev.add_(1)
     cache.lengths = [n + 1 for n in cache.lengths]
@@ -866,47 +877,62 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin):
 
 
 class DecodeStepGraph:
-    """decoder_decode_row captured ONCE as a hipGraph (5 launches x layers per step collapse into one graph launch; the
-    per-token step is launch-bound otherwise) and replayed per token: copy the new rows (one per sequence) into `x_in`, replay, read
-    `x_out`.  Falls back to eager launches if capture is not possible (functional.set_variant("decode_graph", False) forces that)."""
+    """decoder_decode_row captured as a hipGraph (5 - 7 launches x layers per step collapse into one graph launch; the per-token step is
+    launch-bound otherwise) and replayed per token: copy the new rows (one per sequence) into `x_in`, replay, read `x_out`.  One capture
+    per attention bound (decode_kv_bound: the short, single-key-group form while every sequence holds <= 1024 rows, the general one
+    afterwards), made when first needed.  Falls back to eager launches if capture is not possible (functional.set_variant("decode_graph",
+    False) forces that)."""
 
     def __init__(self, layers, meta, cache, cos, sin, h, device):
         self.args = (layers, meta, cache, cos, sin)
         self.cache = cache
         self.x_in = torch.zeros((cache.batch, h), device=device, dtype=BF16)
-        self.x_out = None
-        self.graph = None
-        if not VARIANTS["decode_graph"]:
-            return
+        self.graphs = {}                                     # kv bound -> (graph, x_out)
+        self.capture_ok = VARIANTS["decode_graph"]
+        if self.capture_ok:
+            self._capture(decode_kv_bound(cache))
+
+    @property
+    def graph(self):                                         # (tools / tests: "is the step a graph?")
+        return next(iter(self.graphs.values()))[0] if self.graphs else None
+
+    def _capture(self, bound):
+        cache = self.cache
         keep = list(cache.lengths)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up outside capture (writes a scratch row, undone below)
-                decoder_decode_row(self.x_in, *self.args)
+                decoder_decode_row(self.x_in, *self.args, kv_bound=bound)
             torch.cuda.current_stream().wait_stream(side)
             cache.set_lengths(keep)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.x_out = decoder_decode_row(self.x_in, *self.args)
+                x_out = decoder_decode_row(self.x_in, *self.args, kv_bound=bound)
             cache.lengths = keep                                 # capture records, it does not run: host mirror unchanged
-            self.graph = g
+            self.graphs[bound] = (g, x_out)
         except Exception as e:                                   # pragma: no cover - depends on the runtime
             import warnings
             warnings.warn(f"hipGraph capture of the decode step failed ({e!r}); using eager launches")
-            self.graph = None
+            self.capture_ok = False
+            self.graphs = {}
             cache.set_lengths(keep)
 
     def step(self, rows):
         """rows [batch, h] (one new row per sequence) -> their hidden rows [batch, h] (pre final norm; overwritten by the next step)"""
-        if self.graph is None:
+        if self.capture_ok:
+            bound = decode_kv_bound(self.cache)
+            if bound not in self.graphs:
+                self._capture(bound)
+        if not self.capture_ok:
             return decoder_decode_row(rows.contiguous().view(self.cache.batch, -1), *self.args)
         if self.cache.length >= self.cache.max_len:
             raise ValueError(f"KV cache full ({self.cache.max_len} rows)")
+        g, x_out = self.graphs[bound]
         self.x_in.copy_(rows.view(self.cache.batch, -1))
-        self.graph.replay()
+        g.replay()
         self.cache.lengths = [n + 1 for n in self.cache.lengths]
-        return self.x_out
+        return x_out
 
 
 class GeluFn(Function):

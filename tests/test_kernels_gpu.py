@@ -884,6 +884,29 @@ def test_attn_decode(ops, case, variant):
         close(out[b], ref, 1e-2, 1e-2, f"attn_decode {case} sample {b}")
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 8, 128), (8, 32, 8, 128), (3, 16, 8, 128), (2, 32, 4, 64), (16, 32, 8, 128)])
+def test_attn_decode_heads_spread_over_workgroups_is_bit_identical(ops, shape):
+    """With a bound of <= 1024 cached rows the product launch gives every query head (or pair of heads) of a GQA group its own workgroup;
+    variant 2 keeps the group in one workgroup (the form used for longer bounds).  Each head's arithmetic is the same: equal bit for bit,
+    for full, short, one-row and empty caches, with a bound of exactly 1024 and below."""
+    B, Hq, Hkv, d = shape
+    g = torch.Generator().manual_seed(31)
+    q = (torch.randn(B, Hq * d, generator=g) * 1.5).bfloat16().to(DEV)
+    kc = (torch.randn(B, 1024, Hkv * d, generator=g) * 1.5).bfloat16().to(DEV)
+    vc = torch.randn(B, 1024, Hkv * d, generator=g).bfloat16().to(DEV)
+    lens = [1024, 1, 577, 0, 256, 1023, 64, 300, 5, 900, 2, 1000, 129, 640, 33, 17][:B]
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    for bound in (1024, max(max(lens), 1)):
+        a = ops.attn_decode(q, kc, vc, kv, bound, Hq, Hkv, d, d ** -0.5, variant=0)
+        b = ops.attn_decode(q, kc, vc, kv, bound, Hq, Hkv, d, d ** -0.5, variant=2)
+        assert torch.equal(a, b), (shape, bound)
+    # and the same rows under the capacity bound of a longer cache (whole group per workgroup, second key group idle)
+    kc2 = torch.cat([kc, kc[:, :512]], 1).contiguous()
+    vc2 = torch.cat([vc, vc[:, :512]], 1).contiguous()
+    c = ops.attn_decode(q, kc2, vc2, kv, 1536, Hq, Hkv, d, d ** -0.5, variant=0)
+    assert torch.equal(ops.attn_decode(q, kc, vc, kv, 1024, Hq, Hkv, d, d ** -0.5), c)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("kind", ["wide", "sink", "cliff"])
 def test_attn_decode_on_hostile_scores(ops, kind, variant):

@@ -653,7 +653,8 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     through every decoder layer in one pass -- 5 launches per layer (7 from three rows on: the norms run on their own) for B <= 16 (the GEMV
     kernels' M), ceil(B / 16) x that beyond -- not
     B passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
-    logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal)."""
+    logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal wherever the top two
+    logits are further apart than that accuracy)."""
     import metamorph_amd.functional as F
     cfg = tiny_cfg(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=1, num_image_tokens=4)   # d = 128
     model = hip_model(cfg, init_state_dict(cfg, seed=21, dtype=torch.bfloat16)).eval()
@@ -681,11 +682,52 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     monkeypatch.undo()
     for b in range(B):
         alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
-        assert alone.sequences[0].tolist() == out.sequences[b].tolist(), (b, alone.sequences[0].tolist(), out.sequences[b].tolist())
         for step, (x, y) in enumerate(zip(alone.scores, out.scores)):
             # (alone: one row = the vector-ALU GEMVs; in the batch: 3 .. 16 rows = the MFMA GEMVs -- the same products in another fp32
             # summation order, re-rounded to bf16 after every projection: differences of a bf16 step of the hidden state, i.e. ~1e-2 on a logit)
             assert torch.allclose(x[0], y[b], rtol=2e-2, atol=2e-2), (b, step, float((x[0] - y[b]).abs().max()))
+            if int(x[0].argmax()) != int(y[b].argmax()):
+                # a random-init model has near-ties: the two runs may pick different ids only where the top two logits are closer than
+                # that accuracy, and from there on they decode different sequences (nothing further to compare)
+                top = torch.topk(y[b].float(), 2).values
+                assert float(top[0] - top[1]) < 2e-2, (b, step, float(top[0] - top[1]))
+                break
+        else:
+            assert alone.sequences[0].tolist() == out.sequences[b].tolist(), (b, alone.sequences[0].tolist(), out.sequences[b].tolist())
+
+
+def test_decode_step_graph_switches_its_attention_bound_when_a_sequence_passes_1024_rows():
+    """mm355_attn_decode's bound on the cached lengths is a launch parameter (1024 while every sequence fits one key group: the
+    one-workgroup-per-head form; the capacity afterwards).  DecodeStepGraph keeps one captured step per bound and picks by the lengths the
+    host knows: a batch whose longest sequence grows from 1018 to 1030 rows replays the short graph, then the long one, and every step's
+    rows equal the eager step under the capacity bound bit for bit."""
+    import metamorph_amd.functional as F
+    cfg = tiny_cfg(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=1, num_image_tokens=4)   # d = 128
+    model = hip_model(cfg, init_state_dict(cfg, seed=5, dtype=torch.bfloat16)).eval()
+    cap, B, h = 1100, 3, 512
+    _, meta = model._decode_meta(16)
+    cos, sin = model.model.rope_tables(cap, DEV)
+    meta.cos, meta.sin = cos, sin
+    g = torch.Generator().manual_seed(3)
+    k0 = (torch.randn(cfg.num_hidden_layers, B, cap, meta.Hkv * meta.d, generator=g) * 0.5).bfloat16().to(DEV)
+    v0 = (torch.randn(cfg.num_hidden_layers, B, cap, meta.Hkv * meta.d, generator=g) * 0.5).bfloat16().to(DEV)
+    rows = [(torch.randn(B, h, generator=g) * 0.5).bfloat16().to(DEV) for _ in range(12)]
+    outs = []
+    with torch.no_grad():
+        for graph in (True, False):
+            kv = F.KVCache(cfg.num_hidden_layers, cap, meta.Hkv * meta.d, DEV, Hq=meta.Hq, d=meta.d, batch=B)
+            kv.k.copy_(k0); kv.v.copy_(v0)
+            kv.set_lengths([1018, 1000, 7])
+            if graph:
+                st = F.DecodeStepGraph(model.model.layers, meta, kv, cos, sin, h, DEV)
+                assert st.capture_ok
+                outs.append([st.step(r).clone() for r in rows])
+                assert sorted(st.graphs) == [F.SHORT_KV, cap], sorted(st.graphs)
+            else:
+                outs.append([F.decoder_decode_row(r, model.model.layers, meta, kv, cos, sin, kv_bound=cap).clone() for r in rows])
+            assert kv.lengths == [1030, 1012, 19]
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
 
 
 def test_forward_with_host_mirrors_does_not_touch_the_device_for_its_plan():

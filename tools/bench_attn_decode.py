@@ -34,7 +34,8 @@ for B in (1, 8):
         ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(B, Hq, d, cap)), device=DEV, dtype=torch.float32)
         out = torch.empty(B, Hq * d, device=DEV, dtype=torch.bfloat16)
         row = []
+        ref = ops.attn_decode(q, kc, vc, lens, cap, Hq, Hkv, d, d ** -0.5, workspace=ws, variant=0).float()
         for var in [int(v) for v in os.environ.get("VARS", "0,1").split(",")]:
             us = t(lambda: ops.attn_decode(q, kc, vc, lens, cap, Hq, Hkv, d, d ** -0.5, out=out, workspace=ws, variant=var))
-            row.append(f"v{var} {us:6.1f}")
+            row.append(f"v{var} {us:6.1f} (|d| {float((out.float() - ref).abs().max()):.1e})")
         print(f"B={B} kv={kv:5d}: " + "  ".join(row) + " us", flush=True)
