@@ -275,13 +275,15 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
  * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
  * re-runs the prefix every step).  HBM-bound streaming kernels.
  *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16; one or two rows run on the
- *         vector ALU, 3 .. 16 rows on v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout); flags BIAS /
- *         GELU_ERF / GELU_TANH / RESIDUAL / OUT_F32 as for the GEMM.
+ *         vector ALU with the x rows parked in LDS, so that only weight loads sit in the in-order vector-memory queue; 3 .. 16 rows on
+ *         v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout); flags BIAS / GELU_ERF / GELU_TANH /
+ *         RESIDUAL / OUT_F32 as for the GEMM.  The weight is addressed with 32-bit byte offsets: N * ldw * 2 < 3.75 GiB for 3 .. 16
+ *         rows and for the fused forms below (else MM355_EUNSUPPORTED); the fused forms of one or two rows also need K <= 16384.
  *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
  *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
  *         upper bound of them (sizes the launch and the workspace of mm355_attn_decode_ws_floats floats); GQA groups 1/2/4/8.
- *         ONE launch (round 4): the 256-key chunk that finishes last merges the partials of its heads; the arrival counters are the
- *         last B*Hq words of the workspace -- zero them once before the first call (hipMemset), every call leaves them zero.
+ *         ONE launch: the key group that finishes last merges the partials of its heads; the arrival counters are the FIRST B*Hq
+ *         words of the workspace (whatever max_kv_len) -- zero them once before the first call (hipMemset), every call leaves them zero.
  *   gemv_swiglu: act[M][I] = SiLU(g) * u with [g | u] = n . Wgu[2I][K]^T formed in the GEMV's epilogue (g, u rounded to bf16 first:
  *         the bits of mm355_gemv_bf16 + mm355_swiglu_fwd); norm_w != NULL: n = RMSNorm(x; norm_w, eps) formed per workgroup on the
  *         fly (the bits of mm355_rmsnorm_fwd), else n = x.  HF LlamaMLP / LlamaRMSNorm at decode shape (metamorph_llama.py:502-597).

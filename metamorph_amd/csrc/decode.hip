@@ -1,8 +1,8 @@
 // Decode-shape kernels (gfx950): the same decoder as the training path, but for a handful of new rows per step against a
 // KV cache (greedy_decode / generate, reference metamorph_llama.py:502-597, 665-717, which re-runs the whole
 // prefix every step with use_cache=False).  Everything here is HBM-bound streaming, not MFMA work:
-//   * gemv_kernel      y[M,N] = x[M,K] W[N,K]^T for M <= 8: every weight row is read exactly once, 16 B per lane, four rows per
-//                      wave in flight, fp32 accumulation, wave reduction, the usual bias / GELU / residual epilogue
+//   * gemv_*_kernel    y[M,N] = x[M,K] W[N,K]^T for M <= 16: every weight row is read exactly once, 16 B per lane, four rows per
+//                      wave in flight, fp32 accumulation, the usual bias / GELU / residual epilogue (or SwiGLU / RoPE + cache append)
 //   * attn_decode_*    one query row per (sample, head) against [kv_len] cached keys: KV is split into 256-key chunks over
 //                      workgroups (all query heads of a GQA group share one read of their K / V chunk), partial (max, sum, o)
 //                      per chunk, merged by a second tiny kernel (flash-decoding)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
 // ------------------------------------------------------------------------------------------------ fused decode GEMVs
 // The decode step of one layer is nine tiny launches around four weight streams; three of them fold into the GEMVs that consume /
 // produce their rows (round 4):
-//   PRENORM  the RMSNorm in front of the qkv and gate|up projections: every workgroup reduces the M <= 8 input rows itself (8 KiB each,
+//   PRENORM  the RMSNorm in front of the qkv and gate|up projections: every workgroup reduces the input rows itself (8 KiB each,
 //            L2-resident) while its first weight loads are in flight, and forms bf16(w * bf16(x * rstd)) -- rmsnorm_fwd_kernel's
 //            arithmetic and reduction order, bit for bit -- as the x operand;
 //   MODE 1   SiLU(gate) * up in the epilogue: a wave owns gate rows c, c + 1 AND up rows I + c, I + 1 + c of the fused weight, rounds
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(NT) void gemv_kernel(const uint16_t* __restrict__ x
 //   MODE 2   RoPE + KV-cache append in the epilogue: a wave owns the rotation partners j, j + 1, j + d/2, j + 1 + d/2 of one head (v rows:
 //            four neighbours), rotates the bf16-rounded q / k values at the DEVICE-side position as rope_kv_append_kernel does and
 //            writes q to the row buffer, k / v to the cache row.
+// One or two rows: gemv_deep_kernel; 3 .. 16: gemv_mfma_kernel (both below; the modes are template parameters of either).
 struct GemvFusedArgs {
     const uint16_t* x; int64_t ldx;
     const uint16_t* W; int64_t ldw;
@@ -143,161 +144,6 @@ struct GemvFusedArgs {
     const uint16_t* cos_t; const uint16_t* sin_t; const int32_t* positions;
     uint16_t* kc; uint16_t* vc; int64_t ld_kv, bs_kv;
 };
-
-template <int MR, int MODE, bool PRENORM>
-__global__ __launch_bounds__(NT) void gemv_fused_kernel(GemvFusedArgs a) {
-    constexpr int R = 4;
-    __shared__ float red[NT / 64];
-    __shared__ float rstd_s[MR];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = blockIdx.x * (NT / 64) + wave;          // four weight rows
-    const int K = a.K, M = a.M;
-    int rows[R];
-    bool live = true;
-    if constexpr (MODE == 1) {
-        const int c = unit * 2;
-        live = c < a.I;
-        rows[0] = c; rows[1] = c + 1; rows[2] = a.I + c; rows[3] = a.I + c + 1;
-    } else {
-        const int upd = a.d / 4, nrot = (a.Hq + a.Hkv) * upd;
-        if (unit < nrot) {
-            const int hd = unit / upd, j = (unit % upd) * 2;
-            rows[0] = hd * a.d + j; rows[1] = rows[0] + 1; rows[2] = rows[0] + a.d / 2; rows[3] = rows[2] + 1;
-        } else {
-            const int b0 = (a.Hq + a.Hkv) * a.d + (unit - nrot) * 4;
-            rows[0] = b0; rows[1] = b0 + 1; rows[2] = b0 + 2; rows[3] = b0 + 3;
-        }
-        live = rows[3] < a.N;
-    }
-    const uint16_t* wr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wr[r] = a.W + (int64_t)min(rows[r], a.N - 1) * a.ldw;
-    // first two chunks of the weight stream go out before the norm reduction (its latency hides under them)
-    const int nch = (K + 511) / 512;
-    u32x4 w0[R], w1[R];
-    {
-        const int k = lane * 8;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            w0[r] = (live && k < K) ? *(const u32x4*)(wr[r] + k) : u32x4{0u, 0u, 0u, 0u};
-            w1[r] = (live && k + 512 < K) ? *(const u32x4*)(wr[r] + k + 512) : u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    if constexpr (PRENORM) {
-        // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order, block_sum<256>
-        const int nv = K >> 3;
-        for (int m = 0; m < M; ++m) {
-            float ss = 0.f;
-            for (int v = threadIdx.x; v < nv; v += NT) {
-                float xv[8];
-                unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + v * 8), xv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += xv[e] * xv[e];
-            }
-            ss = block_sum<NT>(ss, red);
-            if (threadIdx.x == 0) rstd_s[m] = rsqrtf(ss / (float)K + a.eps);
-        }
-        __syncthreads();
-    }
-    float acc[MR][R];
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-    auto fma_chunk = [&](const u32x4 (&wv)[R], int k) {
-        float xf[MR][8];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            if (m < M) {
-                unpack8(*(const u32x4*)(a.x + (int64_t)m * a.ldx + k), xf[m]);
-                if constexpr (PRENORM) {
-                    float nw[8];
-                    unpack8(*(const u32x4*)(a.norm_w + k), nw);
-                    const float rs = rstd_s[m];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xf[m][e] = round_bf(nw[e] * round_bf(xf[m][e] * rs));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xf[m][e] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float wf[8];
-            unpack8(wv[r], wf);
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
-        }
-    };
-    if (live) {                                              // chunk order and fma order = gemv_kernel<MR, 1>: the same bits
-        int c = 0;
-        for (; c + 1 < nch; c += 2) {
-            const int k = c * 512 + lane * 8;
-            const bool in1 = k + 512 < K;
-            u32x4 n0[R], n1[R];
-            const int kn = k + 1024;
-            const bool more = c + 2 < nch;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {                    // the next trip's loads before this trip's arithmetic
-                n0[r] = (more && kn < K) ? *(const u32x4*)(wr[r] + kn) : u32x4{0u, 0u, 0u, 0u};
-                n1[r] = (more && kn + 512 < K) ? *(const u32x4*)(wr[r] + kn + 512) : u32x4{0u, 0u, 0u, 0u};
-            }
-            if (k < K) fma_chunk(w0, k);
-            if (in1) fma_chunk(w1, k + 512);
-#pragma unroll
-            for (int r = 0; r < R; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
-        }
-        if (c < nch) {
-            const int k = c * 512 + lane * 8;
-            if (k < K) fma_chunk(w0, k);
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
-    if (!live || lane >= M) return;
-    // lane m finishes the unit's outputs of row m
-    float v4[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float t = 0.f;
-#pragma unroll
-        for (int mm = 0; mm < MR; ++mm)
-            if (mm == lane) t = acc[mm][r];
-        v4[r] = round_bf(t);                                 // what the unfused GEMV stores
-    }
-    const int m = lane;
-    if constexpr (MODE == 1) {
-        float o[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) o[e] = round_bf(v4[e] / (1.0f + __expf(-v4[e]))) * v4[2 + e];
-        *(uint32_t*)(a.out + (int64_t)m * a.ld_out + rows[0]) = pack2bf(o[0], o[1]);
-    } else {
-        const int nqk = (a.Hq + a.Hkv) * a.d;
-        const int pos = a.positions[m];
-        if (rows[0] < nqk) {
-            const int hd = rows[0] / a.d, j = rows[0] % a.d;
-            float y1[2], y2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float c = bf2f(a.cos_t[(int64_t)pos * a.d + j + e]), sn = bf2f(a.sin_t[(int64_t)pos * a.d + j + e]);
-                y1[e] = round_bf(v4[e] * c) + round_bf(-v4[2 + e] * sn);
-                y2[e] = round_bf(v4[2 + e] * c) + round_bf(v4[e] * sn);
-            }
-            uint16_t* dst = hd < a.Hq ? a.out + (int64_t)m * a.ld_out + rows[0]
-                                      : a.kc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (int64_t)(hd - a.Hq) * a.d + j;
-            *(uint32_t*)dst = pack2bf(y1[0], y1[1]);
-            *(uint32_t*)(dst + a.d / 2) = pack2bf(y2[0], y2[1]);
-        } else {
-            uint16_t* dst = a.vc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (rows[0] - nqk);
-            *(u32x2*)dst = u32x2{pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ 3 .. 16 rows: the same GEMVs on MFMA
 // Round 5 (batched decode: all rows of a batch / all beams go through the layers in ONE pass).  The VALU kernels above spend 8 FMAs +
@@ -577,6 +423,232 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
     if (gr == 4) return launch_gemv_mfma_gr<MODE, 4>(g, units, prenorm, s);
     if (gr == 2) return launch_gemv_mfma_gr<MODE, 2>(g, units, prenorm, s);
     return launch_gemv_mfma_gr<MODE, 1>(g, units, prenorm, s);
+}
+
+// ------------------------------------------------------------------------------------------------ one or two rows: x in LDS, weights alone in the queue
+// Round 4's kernels (gemv_kernel at the top, and a fused twin of it) read the x chunk of every trip from L2 INSIDE the loop, i.e. behind
+// the weight loads they had just prefetched: the vector-memory counter retires in order, so each x chunk waited for the whole prefetch
+// block and the pipeline never ran ahead -- 2.9 / 3.1 TB/s on the N = 4096 / 6144 projections (o: 11.8 us, q|k|v: 16.3 us), 5.2 on
+// gate|up (45.5 us), 3.44 ms per token.  Here nothing but weight loads enters the queue once the stream runs:
+//   * the x rows (and the norm weight) go FIRST, then the first NB trips of weights (a trip = 1024 k x 4 rows = 8 loads of 16 B per lane);
+//     while those fly the workgroup reduces the rows (PRENORM: rmsnorm_fwd_kernel's order), forms bf16(w * bf16(x * rstd)) and parks the
+//     rows in LDS (zero beyond K), whose reads have their own counter;
+//   * the stream continues through a register ring: trip t is consumed, trip t + NB issued into its registers; behind the end the offset
+//     carries the out-of-range mark (buffer loads return zeros without touching memory: no branch around a prefetch);
+//   * chunk order, fma order and epilogues are those of gemv_kernel<MR, 1> (plain) and of the launch sequences the fused modes replace
+//     (GEMV -> SwiGLU; GEMV -> RoPE + cache append): the same bits (a lane beyond K adds fma(x, 0, acc): nothing).
+// Measured (profiles/r5_decode_*): o 8.3 us, q|k|v 12.3, gate|up 37.1 (6.3 TB/s), down 21.5 (was 22.5 with K split over four waves),
+// lm_head 155 (was 170): 2.89 ms per token = 5.2 TB/s of weights.  Ring depth 1 .. 4 is within noise of it (the in-order x loads were
+// the stall, not the depth).
+template <int MR, int MODE, bool PRENORM, int XV>
+__global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
+    const GemvFusedArgs& a = g.f;
+    constexpr int R = 4;
+    constexpr int NB = 2;                                    // trips in the register ring (measured 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // [MR][kpad] bf16 x rows as the dot products take them
+    __shared__ float red[NT / 64];
+    __shared__ float rstd_s[MR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * (NT / 64) + wave;          // four weight rows
+    const int K = a.K, M = a.M;
+    const int ntrip = (K + 1023) >> 10, kpad = ntrip << 10, nv = K >> 3;
+    int rows[R];
+    unit_rows<MODE>(a, unit, rows);
+    bool live;
+    if constexpr (MODE == 0) live = rows[0] < a.N;
+    else if constexpr (MODE == 1) live = rows[1] < a.I;
+    else live = rows[3] < a.N;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (uint32_t)((uint64_t)(a.N - 1) * a.ldw * 2 + (uint64_t)K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (uint32_t)((uint64_t)(M - 1) * a.ldx * 2 + (uint64_t)K * 2), 0x00020000);
+    const uint32_t OOB = 0xf0000000u;
+    uint32_t wo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wo[r] = (uint32_t)min(rows[r], a.N - 1) * (uint32_t)a.ldw * 2u;
+    // ---- (1) this thread's vectors v = t + 256 i of the x rows (and of the norm weight)
+    u32x4 xr[MR][XV], nr[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = threadIdx.x + NT * i;
+        const uint32_t sk = v < nv ? 0u : OOB;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            xr[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ((uint32_t)min(m, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)v * 16u) | sk, 0, 0);
+        if constexpr (PRENORM) {
+            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, (uint32_t)K * 2u, 0x00020000);
+            nr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsN, ((uint32_t)v * 16u) | sk, 0, 0);
+        }
+    }
+    // ---- (2) the first NB trips of the weight stream
+    u32x4 wb[NB][2][R];
+    auto issue = [&](u32x4 (&w)[2][R], int t) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int k = (t * 2 + ch) * 512 + lane * 8;
+            const uint32_t sk = (live && k < K) ? 0u : OOB;
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[ch][r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (wo[r] + (uint32_t)k * 2u) | sk, 0, 2);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NB; ++j) issue(wb[j], j);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (3) the rows -> LDS in the form the dot products take
+    if constexpr (PRENORM) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {                       // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                float xv[8];
+                unpack8(xr[m][i], xv);                       // (beyond K: zeros)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xv[e] * xv[e];
+            }
+            ss = block_sum<NT>(ss, red);
+            if (threadIdx.x == 0) rstd_s[m] = rsqrtf(ss / (float)K + a.eps);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = threadIdx.x + NT * i;
+        if (v * 8 < kpad) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                u32x4 out = xr[m][i];
+                if constexpr (PRENORM) {
+                    float xv[8], nw[8];
+                    unpack8(xr[m][i], xv);
+                    unpack8(nr[i], nw);
+                    const float rs = rstd_s[m];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = nw[e] * round_bf(xv[e] * rs);
+                    out = pack8(xv);
+                }
+                *(u32x4*)(xs + ((int64_t)m * kpad + v * 8) * 2) = out;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- (4) the stream
+    float acc[MR][R];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+    auto consume = [&](const u32x4 (&w)[2][R], int t) {
+        const int tc = min(t, ntrip - 1);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int k = (tc * 2 + ch) * 512 + lane * 8;
+            float xf[MR][8];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) unpack8(*(const u32x4*)(xs + ((int64_t)m * kpad + k) * 2), xf[m]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float wf[8];
+                unpack8(w[ch][r], wf);
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
+            }
+        }
+    };
+    for (int t0 = 0; t0 < ntrip; t0 += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            consume(wb[j], t0 + j);                          // (a trip behind the end is all zeros)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(wb[j], t0 + j + NB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
+    if (!live) return;
+    if constexpr (MODE == 0) {                               // gemv_kernel's epilogue: lane (m * R + r) finishes output (m, rows[r])
+        if (lane < MR * R) {
+            const int m = lane / R, r = lane % R, n = rows[0] + r;
+            if (m < M && n < a.N) {
+                float v = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < MR; ++mm)
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr)
+                        if (mm == m && rr == r) v = acc[mm][rr];
+                const uint32_t flags = g.flags;
+                if (flags & MM355_GEMM_BIAS) v += bf2f(g.bias[n]);
+                if (flags & MM355_GEMM_GELU_ERF) v = gelu_erf_f(v);
+                if (flags & MM355_GEMM_GELU_TANH) v = gelu_tanh_f(v);
+                if (flags & MM355_GEMM_RESIDUAL) v += bf2f(g.res[(int64_t)m * g.ldr + n]);
+                if (flags & MM355_GEMM_OUT_F32) ((float*)g.y)[(int64_t)m * g.ldy + n] = v;
+                else ((uint16_t*)g.y)[(int64_t)m * g.ldy + n] = f2bf(v);
+            }
+        }
+        return;
+    } else {
+        if (lane >= M) return;                               // the fused epilogues: lane m finishes the unit's outputs of row m
+        float v4[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < MR; ++mm)
+                if (mm == lane) t = acc[mm][r];
+            v4[r] = round_bf(t);                             // what the unfused GEMV stores
+        }
+        const int m = lane;
+        if constexpr (MODE == 1) {
+            float o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) o[e] = round_bf(v4[e] / (1.0f + __expf(-v4[e]))) * v4[2 + e];
+            *(uint32_t*)(a.out + (int64_t)m * a.ld_out + rows[0]) = pack2bf(o[0], o[1]);
+        } else {
+            const int nqk = (a.Hq + a.Hkv) * a.d;
+            const int pos = a.positions[m];
+            if (rows[0] < nqk) {
+                const int hd = rows[0] / a.d, j = rows[0] % a.d;
+                float y1[2], y2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float c = bf2f(a.cos_t[(int64_t)pos * a.d + j + e]), sn = bf2f(a.sin_t[(int64_t)pos * a.d + j + e]);
+                    y1[e] = round_bf(v4[e] * c) + round_bf(-v4[2 + e] * sn);
+                    y2[e] = round_bf(v4[2 + e] * c) + round_bf(v4[e] * sn);
+                }
+                uint16_t* dst = hd < a.Hq ? a.out + (int64_t)m * a.ld_out + rows[0]
+                                          : a.kc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (int64_t)(hd - a.Hq) * a.d + j;
+                *(uint32_t*)dst = pack2bf(y1[0], y1[1]);
+                *(uint32_t*)(dst + a.d / 2) = pack2bf(y2[0], y2[1]);
+            } else {
+                uint16_t* dst = a.vc + (int64_t)m * a.bs_kv + (int64_t)pos * a.ld_kv + (rows[0] - nqk);
+                *(u32x2*)dst = u32x2{pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
+            }
+        }
+    }
+}
+
+bool gemv_deep_applies(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
+    return M <= 2 && K <= 16384 && gemv_mfma_addressable(M, N, K, ldx, ldw);
+}
+
+template <int MODE>
+int launch_gemv_deep(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
+    const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
+    const int kpad = ((g.f.K + 1023) >> 10) << 10;
+    const int lds = (g.f.M == 1 ? 1 : 2) * kpad * 2;         // <= 64 KiB
+    const bool shortk = g.f.K <= 4096;                        // x vectors per thread and row: 2 (K <= 4096) or 8
+#define GD3(MR, PN, XVV) hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, XVV>), dim3(grid), dim3(NT), lds, s, g)
+#define GD2(MR, PN) do { if (shortk) GD3(MR, PN, 2); else GD3(MR, PN, 8); } while (0)
+#define GD(MR) do { if (prenorm) { if constexpr (MODE != 0) GD2(MR, true); } else GD2(MR, false); } while (0)
+    if (g.f.M == 1) GD(1);
+    else GD(2);
+#undef GD
+#undef GD2
+#undef GD3
+    return mm_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE + cache append
@@ -1029,17 +1101,21 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
         g.y = y; g.ldy = ldy; g.bias = bias; g.res = residual; g.ldr = ldr; g.flags = flags;
         return launch_gemv_mfma<0>(g, (N + 3) / 4, false, s);
     }
-    // few rows of a long K (down projection): split K over the waves of a workgroup; measured: K = 14336, N = 4096 28.5 -> 24.3 us,
-    // while at K = 4096 the extra LDS hand-over costs more than it buys (13.5 -> 17.7 us)
+    if (gemv_deep_applies(M, N, K, ldx, ldw)) {
+        GemvMfmaArgs g = {};
+        g.f.x = x; g.f.ldx = ldx; g.f.W = W; g.f.ldw = ldw; g.f.M = (int)M; g.f.N = (int)N; g.f.K = (int)K;
+        g.y = y; g.ldy = ldy; g.bias = bias; g.res = residual; g.ldr = ldr; g.flags = flags;
+        return launch_gemv_deep<0>(g, (N + 3) / 4, false, s);
+    }
+    // K > 16384 or a weight beyond 32-bit byte offsets: the plain stream (x re-read from L2 per chunk); few rows of a long K split K over
+    // the waves of a workgroup
     const int ksplit = (N <= 8192 && K >= 8192) ? 4 : 1;
     const int rows_per_wg = 16 / ksplit;
     const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
 #define GV2(MR, KSV) hipLaunchKernelGGL((gemv_kernel<MR, KSV>), dim3(grid), dim3(NT), 0, s, x, ldx, W, ldw, y, ldy, (int)M, (int)N, (int)K, bias, residual, ldr, flags)
 #define GV(MR) do { if (ksplit == 4) GV2(MR, 4); else if (ksplit == 2) GV2(MR, 2); else GV2(MR, 1); } while (0)
     if (M == 1) GV(1);
-    else if (M == 2) GV(2);
-    else if (M <= 4) GV(4);
-    else GV(8);
+    else GV(2);
 #undef GV2
 #undef GV
     return mm_launch_status();
@@ -1123,19 +1199,6 @@ extern "C" int mm355_attn_decode_variant(const mm355_bf16* q, int64_t ld_q, cons
 }
 
 namespace {
-template <int MODE>
-int launch_gemv_fused(const GemvFusedArgs& a, int units, bool prenorm, hipStream_t s) {
-    const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
-#define GF2(MR, PN) hipLaunchKernelGGL((gemv_fused_kernel<MR, MODE, PN>), dim3(grid), dim3(NT), 0, s, a)
-#define GF(MR) do { if (prenorm) GF2(MR, true); else GF2(MR, false); } while (0)
-    if (a.M == 1) GF(1);
-    else if (a.M == 2) GF(2);
-    else if (a.M <= 4) GF(4);
-    else GF(8);
-#undef GF
-#undef GF2
-    return mm_launch_status();
-}
 }  // namespace
 
 extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* act, int64_t ld_act,
@@ -1155,7 +1218,12 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
         g.f = a;
         return launch_gemv_mfma<1>(g, I / 2, norm_w != nullptr, (hipStream_t)stream);
     }
-    return launch_gemv_fused<1>(a, (int)(I / 2), norm_w != nullptr, (hipStream_t)stream);
+    if (gemv_deep_applies(M, 2 * I, K, ldx, ldw)) {
+        GemvMfmaArgs g = {};
+        g.f = a;
+        return launch_gemv_deep<1>(g, I / 2, norm_w != nullptr, (hipStream_t)stream);
+    }
+    return MM355_EUNSUPPORTED;                               // K > 16384 or a weight beyond 32-bit byte offsets: the unfused launch sequence
 }
 
 extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
@@ -1182,5 +1250,10 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
         g.f = a;
         return launch_gemv_mfma<2>(g, N / 4, norm_w != nullptr, (hipStream_t)stream);
     }
-    return launch_gemv_fused<2>(a, (int)(N / 4), norm_w != nullptr, (hipStream_t)stream);
+    if (gemv_deep_applies(M, N, K, ldx, ldw)) {
+        GemvMfmaArgs g = {};
+        g.f = a;
+        return launch_gemv_deep<2>(g, N / 4, norm_w != nullptr, (hipStream_t)stream);
+    }
+    return MM355_EUNSUPPORTED;                               // K > 16384 or a weight beyond 32-bit byte offsets: the unfused launch sequence
 }
