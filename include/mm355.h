@@ -274,11 +274,12 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 /* ------------------------------------------------------------------------------------------------
  * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
  * re-runs the prefix every step).  HBM-bound streaming kernels.
- *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16; one or two rows run on the
- *         vector ALU with the x rows parked in LDS, so that only weight loads sit in the in-order vector-memory queue; 3 .. 16 rows on
- *         v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout); flags BIAS / GELU_ERF / GELU_TANH /
- *         RESIDUAL / OUT_F32 as for the GEMM.  The weight is addressed with 32-bit byte offsets: N * ldw * 2 < 3.75 GiB for 3 .. 16
- *         rows and for the fused forms below (else MM355_EUNSUPPORTED); the fused forms of one or two rows also need K <= 16384.
+ *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16).  Up to eight rows run on the
+ *         vector ALU with the x rows parked in LDS (windows of 4096 columns), so that only weight loads sit in the in-order
+ *         vector-memory queue: one or two rows as an fp32 fma chain, three to eight on v_dot2c_f32_bf16; 9 .. 16 rows on
+ *         v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout.  flags BIAS / GELU_ERF / GELU_TANH /
+ *         RESIDUAL / OUT_F32 as for the GEMM.  The weight is addressed with 32-bit byte offsets: N * ldw * 2 < 3.75 GiB (else the plain
+ *         stream of mm355_gemv_bf16 for up to eight rows; MM355_EUNSUPPORTED for more rows and for the fused forms below).
  *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
  *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
  *         upper bound of them (sizes the launch and the workspace of mm355_attn_decode_ws_floats floats); GQA groups 1/2/4/8.

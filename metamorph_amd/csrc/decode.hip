@@ -3,9 +3,8 @@
 // prefix every step with use_cache=False).  Everything here is HBM-bound streaming, not MFMA work:
 //   * gemv_*_kernel    y[M,N] = x[M,K] W[N,K]^T for M <= 16: every weight row is read exactly once, 16 B per lane, four rows per
 //                      wave in flight, fp32 accumulation, the usual bias / GELU / residual epilogue (or SwiGLU / RoPE + cache append)
-//   * attn_decode_*    one query row per (sample, head) against [kv_len] cached keys: KV is split into 256-key chunks over
-//                      workgroups (all query heads of a GQA group share one read of their K / V chunk), partial (max, sum, o)
-//                      per chunk, merged by a second tiny kernel (flash-decoding)
+//   * attn_decode_*    one query row per (sample, head) against [kv_len] cached keys: one workgroup per 1024 cached rows (a cache bound of
+//                      <= 1024 rows: per query head, no merge), partial (max, sum, o) per group merged by the group that arrives last
 #include "mm355_common.h"
 
 namespace {
@@ -145,10 +144,11 @@ struct GemvFusedArgs {
     uint16_t* kc; uint16_t* vc; int64_t ld_kv, bs_kv;
 };
 
-// ------------------------------------------------------------------------------------------------ 3 .. 16 rows: the same GEMVs on MFMA
-// Round 5 (batched decode: all rows of a batch / all beams go through the layers in ONE pass).  The VALU kernels above spend 8 FMAs +
-// unpacking per weight element and row; beyond two rows they are instruction-bound (measured: 8 rows = 2.6 x the time of one, 1.5 TB/s of
-// weights).  Here the dot products run on v_mfma_f32_16x16x32_bf16 and the kernel stays a weight stream at any M <= 16:
+// ------------------------------------------------------------------------------------------------ 9 .. 16 rows: the same GEMVs on MFMA
+// Round 5 (batched decode: all rows of a batch / all beams go through the layers in ONE pass).  The vector-ALU form (gemv_deep_kernel below)
+// holds M x 4 accumulators and M x-vectors per lane: beyond eight rows it runs out of registers.  Here the dot products run on
+// v_mfma_f32_16x16x32_bf16 and the kernel stays a weight stream at any M <= 16 (used for 9 .. 16; at 3 .. 8 rows the dot2 form is faster:
+// gate|up at eight rows 48 - 54 us against 60):
 //   * a wave owns FOUR units (the 4-row units of the kernels above: plain = rows 4u .. 4u+3; SwiGLU = gate rows c, c+1 and up rows I+c,
 //     I+c+1; RoPE = the rotation partners j, j+1, j+d/2, j+1+d/2 of one head) = 16 weight rows as the A operand: lane (fr = lane & 15,
 //     fq = lane >> 4) loads 16 B of row fr at k + 8 fq straight from HBM in the fragment layout (64 contiguous bytes per row and
@@ -425,7 +425,7 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
     return launch_gemv_mfma_gr<MODE, 1>(g, units, prenorm, s);
 }
 
-// ------------------------------------------------------------------------------------------------ one or two rows: x in LDS, weights alone in the queue
+// ------------------------------------------------------------------------------------------------ up to eight rows: x in LDS, weights alone in the queue
 // Round 4's kernels (gemv_kernel at the top, and a fused twin of it) read the x chunk of every trip from L2 INSIDE the loop, i.e. behind
 // the weight loads they had just prefetched: the vector-memory counter retires in order, so each x chunk waited for the whole prefetch
 // block and the pipeline never ran ahead -- 2.9 / 3.1 TB/s on the N = 4096 / 6144 projections (o: 11.8 us, q|k|v: 16.3 us), 5.2 on
@@ -437,21 +437,31 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
 //     carries the out-of-range mark (buffer loads return zeros without touching memory: no branch around a prefetch);
 //   * chunk order, fma order and epilogues are those of gemv_kernel<MR, 1> (plain) and of the launch sequences the fused modes replace
 //     (GEMV -> SwiGLU; GEMV -> RoPE + cache append): the same bits (a lane beyond K adds fma(x, 0, acc): nothing).
-// Measured (profiles/r5_decode_*): o 8.3 us, q|k|v 12.3, gate|up 37.1 (6.3 TB/s), down 21.5 (was 22.5 with K split over four waves),
-// lm_head 155 (was 170): 2.89 ms per token = 5.2 TB/s of weights.  Ring depth 1 .. 4 is within noise of it (the in-order x loads were
-// the stall, not the depth).
-template <int MR, int MODE, bool PRENORM, int XV>
+//   * rows longer than 4096 columns pass through LDS in WINDOWS of 4096 (two buffers): the next window's vectors are loaded while the
+//     current one is consumed (eight rows: two rows per trip) and stored before the barrier that ends it -- any K, <= 128 KiB of LDS;
+//   * three to eight rows (MR = 4, 8) take v_dot2c_f32_bf16 on the packed pairs -- full rate (5.2 cycles per wave instruction, as
+//     v_fmac_f32: tools/probes) and no unpacking: 16 M instead of 40 M vector instructions per chunk; fp32 accumulation either way.
+// Measured (profiles/r5_decode_*): one row: o 8.3 us, q|k|v 12.3, gate|up 37.1 (6.3 TB/s), down 21.5 (was 22.5 with K split over four
+// waves), lm_head 155 (was 170): 2.89 ms per token = 5.2 TB/s of weights; ring depth 1 .. 4 is within noise of it (the in-order x loads
+// were the stall, not the depth).  Four rows: gate|up 41 us (5.7 TB/s); eight: 48 - 54 us (two waves per SIMD at 208 registers; the
+// 8 x 16-byte LDS reads per chunk and wave are what is left: 24 us of LDS time per CU and launch).
+template <int MR, int MODE, bool PRENORM, bool WINDOWS>
 __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     const GemvFusedArgs& a = g.f;
     constexpr int R = 4;
-    constexpr int NB = 2;                                    // trips in the register ring (measured 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token)
-    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // [MR][kpad] bf16 x rows as the dot products take them
-    __shared__ float red[NT / 64];
+    constexpr bool DOT2 = MR > 2;                            // (the fma chain at four / eight rows: gate|up 48.8 / 89.7 us against 42.0 / 63.9)
+    constexpr int NB = 2;                                    // trips in the register ring (measured at one row, 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token;
+                                                             // at eight rows one trip loses: gate|up 48 -> 55 us)
+    constexpr int WT = 4, WK = WT * 1024;                    // an x window: four trips = 4096 k
+    constexpr int XV = WK / 8 / NT;                          // 16-byte vectors per thread, row and window (2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // [1 or 2 windows][MR][wk] bf16 x rows as the dot products take them
+    __shared__ float red[MR][NT / 64];
     __shared__ float rstd_s[MR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = blockIdx.x * (NT / 64) + wave;          // four weight rows
     const int K = a.K, M = a.M;
-    const int ntrip = (K + 1023) >> 10, kpad = ntrip << 10, nv = K >> 3;
+    const int ntrip = (K + 1023) >> 10, nwin = (ntrip + WT - 1) / WT, nv = K >> 3;
+    const int wk = min(ntrip, WT) << 10;                     // elements per window row in LDS
     int rows[R];
     unit_rows<MODE>(a, unit, rows);
     bool live;
@@ -460,26 +470,53 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     else live = rows[3] < a.N;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (uint32_t)((uint64_t)(a.N - 1) * a.ldw * 2 + (uint64_t)K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (uint32_t)((uint64_t)(M - 1) * a.ldx * 2 + (uint64_t)K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(PRENORM ? a.norm_w : a.x), 0, (uint32_t)K * 2u, 0x00020000);
     const uint32_t OOB = 0xf0000000u;
     uint32_t wo[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wo[r] = (uint32_t)min(rows[r], a.N - 1) * (uint32_t)a.ldw * 2u;
-    // ---- (1) this thread's vectors v = t + 256 i of the x rows (and of the norm weight)
+    // this thread's vectors v = t + 256 i of window w of the x rows (and of the norm weight); beyond K: zeros, no memory access.  Behind the
+    // first window the rows are staged in HS parts (eight rows: two rows per trip, live in registers for that trip only: 256 -> 2xx registers,
+    // two waves per SIMD)
+    constexpr int HS = (WINDOWS && MR == 8) ? 4 : 1, MP = MR / HS;
     u32x4 xr[MR][XV], nr[XV];
+    auto stage_load = [&](int w, int m0, int m1) {
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int v = threadIdx.x + NT * i;
-        const uint32_t sk = v < nv ? 0u : OOB;
+        for (int i = 0; i < XV; ++i) {
+            const int v = w * (WK / 8) + threadIdx.x + NT * i;
+            const uint32_t sk = v < nv ? 0u : OOB;
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
-            xr[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ((uint32_t)min(m, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)v * 16u) | sk, 0, 0);
-        if constexpr (PRENORM) {
-            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)a.norm_w, 0, (uint32_t)K * 2u, 0x00020000);
-            nr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsN, ((uint32_t)v * 16u) | sk, 0, 0);
+            for (int m = 0; m < MR; ++m)
+                if (m >= m0 && m < m1)
+                    xr[m % (m1 - m0 == MR ? MR : MP)][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ((uint32_t)min(m, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)v * 16u) | sk, 0, 0);
+            if constexpr (PRENORM) nr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsN, ((uint32_t)v * 16u) | sk, 0, 0);
         }
-    }
-    // ---- (2) the first NB trips of the weight stream
-    u32x4 wb[NB][2][R];
+    };
+    auto stage_store = [&](int w, int m0, int m1) {          // -> LDS window buffer w & 1, in the form the dot products take
+        unsigned char* dst = xs + (size_t)(w & 1) * MR * wk * 2;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = threadIdx.x + NT * i;
+            if (v * 8 < wk) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (m < m0 || m >= m1) continue;
+                    const int ms = m % (m1 - m0 == MR ? MR : MP);
+                    u32x4 out = xr[ms][i];
+                    if constexpr (PRENORM) {
+                        float xv[8], nw[8];
+                        unpack8(xr[ms][i], xv);
+                        unpack8(nr[i], nw);
+                        const float rs = rstd_s[m];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xv[e] = nw[e] * round_bf(xv[e] * rs);
+                        out = pack8(xv);
+                    }
+                    *(u32x4*)(dst + ((size_t)m * wk + v * 8) * 2) = out;
+                }
+            }
+        }
+    };
     auto issue = [&](u32x4 (&w)[2][R], int t) {
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
@@ -489,46 +526,64 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
             for (int r = 0; r < R; ++r) w[ch][r] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (wo[r] + (uint32_t)k * 2u) | sk, 0, 2);
         }
     };
+    // rmsnorm_fwd_kernel's reduction (thread t sums elements 8 (t + 256 i) .. + 7 in order, block_sum<256>), all rows in one pass
+    auto finish_norm = [&](float (&ss)[MR]) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const float w = wave_sum(ss[m]);
+            if (lane == 0) red[m][wave] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < MR) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT / 64; ++i) t += red[threadIdx.x][i];
+            rstd_s[threadIdx.x] = rsqrtf(t / (float)K + a.eps);
+        }
+        __syncthreads();
+    };
+    if constexpr (PRENORM) {
+        if (nwin > 1) {                                      // rows longer than a window: their sums of squares first (x from L2, read again below)
+            float ss[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) ss[m] = 0.f;
+            for (int v = threadIdx.x; v < nv; v += NT) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    float xv[8];
+                    unpack8(*(const u32x4*)(a.x + (int64_t)min(m, M - 1) * a.ldx + v * 8), xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss[m] += xv[e] * xv[e];
+                }
+            }
+            finish_norm(ss);
+        }
+    }
+    // ---- (1) the first x window goes FIRST into the vector-memory queue, (2) then the first NB trips of the weight stream
+    stage_load(0, 0, MR);
+    u32x4 wb[NB][2][R];
 #pragma unroll
     for (int j = 0; j < NB; ++j) issue(wb[j], j);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- (3) the rows -> LDS in the form the dot products take
+    // ---- (3) the rows -> LDS
     if constexpr (PRENORM) {
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {                       // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order
-            float ss = 0.f;
-#pragma unroll
-            for (int i = 0; i < XV; ++i) {
-                float xv[8];
-                unpack8(xr[m][i], xv);                       // (beyond K: zeros)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += xv[e] * xv[e];
-            }
-            ss = block_sum<NT>(ss, red);
-            if (threadIdx.x == 0) rstd_s[m] = rsqrtf(ss / (float)K + a.eps);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int v = threadIdx.x + NT * i;
-        if (v * 8 < kpad) {
+        if (nwin == 1) {
+            float ss[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                u32x4 out = xr[m][i];
-                if constexpr (PRENORM) {
-                    float xv[8], nw[8];
-                    unpack8(xr[m][i], xv);
-                    unpack8(nr[i], nw);
-                    const float rs = rstd_s[m];
+                ss[m] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = nw[e] * round_bf(xv[e] * rs);
-                    out = pack8(xv);
+                for (int i = 0; i < XV; ++i) {
+                    float xv[8];
+                    unpack8(xr[m][i], xv);                   // (beyond K: zeros)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss[m] += xv[e] * xv[e];
                 }
-                *(u32x4*)(xs + ((int64_t)m * kpad + v * 8) * 2) = out;
             }
+            finish_norm(ss);
         }
     }
+    stage_store(0, 0, MR);
     __syncthreads();
     // ---- (4) the stream
     float acc[MR][R];
@@ -536,33 +591,63 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
-    auto consume = [&](const u32x4 (&w)[2][R], int t) {
-        const int tc = min(t, ntrip - 1);
+    auto consume = [&](const u32x4 (&w)[2][R], int win, int j) {          // trip j of window win
+        const unsigned char* src = xs + (size_t)(win & 1) * MR * wk * 2;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const int k = (tc * 2 + ch) * 512 + lane * 8;
-            float xf[MR][8];
+            const int k = min((j * 2 + ch) * 512, wk - 512) + lane * 8;       // (a trip behind the end is all zeros: any x will do)
+            if constexpr (!DOT2) {                           // gemv_kernel's arithmetic: fp32 fma chain over the eight elements
+                float xf[MR][8];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) unpack8(*(const u32x4*)(xs + ((int64_t)m * kpad + k) * 2), xf[m]);
+                for (int m = 0; m < MR; ++m) unpack8(*(const u32x4*)(src + ((size_t)m * wk + k) * 2), xf[m]);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float wf[8];
-                unpack8(w[ch][r], wf);
+                for (int r = 0; r < R; ++r) {
+                    float wf[8];
+                    unpack8(w[ch][r], wf);
 #pragma unroll
-                for (int m = 0; m < MR; ++m)
+                    for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
+                        for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
+                }
+            } else {                                         // 3 .. 8 rows: v_dot2c_f32_bf16 on the packed pairs (no unpacking: 16 MR VALU ops per chunk, not 40 MR)
+                u32x4 xv[MR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) xv[m] = *(const u32x4*)(src + ((size_t)m * wk + k) * 2);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t we = w[ch][r][e], xe = xv[m][e];   // (scalars first: a bit_cast OF a vector element reads element 0 whatever e -- hipcc 7.2)
+                            acc[m][r] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mm_bf16x2, we), __builtin_bit_cast(mm_bf16x2, xe), acc[m][r], false);
+                        }
             }
         }
     };
-    for (int t0 = 0; t0 < ntrip; t0 += NB) {
+    static_assert(WT % NB == 0, "the ring position of a trip must not depend on the window");
+    for (int win = 0; win < nwin; ++win) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            consume(wb[j], t0 + j);                          // (a trip behind the end is all zeros)
+        for (int j = 0; j < WT; ++j) {
+            if constexpr (WINDOWS) {                         // (K <= 4096: one window, and no staging registers live across the stream)
+                if (j % (WT / HS) == 0) {                    // part j / (WT / HS) of the NEXT window (behind the last: out of range, no access)
+                    stage_load(win + 1, j / (WT / HS) * MP, (j / (WT / HS) + 1) * MP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            consume(wb[j % NB], win, j);
+            // (the sums are pure arithmetic: without this pin hipcc sinks them below the loads of the whole window -- and below the barrier --,
+            // renaming the ring into 256 registers; the empty statement keeps "consume trip t, then refill its registers")
+#pragma unroll
+            for (int m = 0; m < MR; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]), "+v"(acc[m][2]), "+v"(acc[m][3]) : : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            issue(wb[j], t0 + j + NB);
+            issue(wb[j % NB], win * WT + j + NB);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WINDOWS) {                         // into the OTHER buffer: everyone left it at the barrier before this window
+                if (j % (WT / HS) == WT / HS - 1) stage_store(win + 1, j / (WT / HS) * MP, (j / (WT / HS) + 1) * MP);
+            }
         }
+        if constexpr (WINDOWS) __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -631,23 +716,27 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
 }
 
 bool gemv_deep_applies(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
-    return M <= 2 && K <= 16384 && gemv_mfma_addressable(M, N, K, ldx, ldw);
+    return M <= 8 && gemv_mfma_addressable(M, N, K, ldx, ldw);
 }
 
 template <int MODE>
 int launch_gemv_deep(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
     const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
-    const int kpad = ((g.f.K + 1023) >> 10) << 10;
-    const int lds = (g.f.M == 1 ? 1 : 2) * kpad * 2;         // <= 64 KiB
-    const bool shortk = g.f.K <= 4096;                        // x vectors per thread and row: 2 (K <= 4096) or 8
-#define GD3(MR, PN, XVV) hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, XVV>), dim3(grid), dim3(NT), lds, s, g)
-#define GD2(MR, PN) do { if (shortk) GD3(MR, PN, 2); else GD3(MR, PN, 8); } while (0)
-#define GD(MR) do { if (prenorm) { if constexpr (MODE != 0) GD2(MR, true); } else GD2(MR, false); } while (0)
-    if (g.f.M == 1) GD(1);
-    else GD(2);
+    const int ntrip = (g.f.K + 1023) >> 10;
+    const int mr = g.f.M == 1 ? 1 : (g.f.M == 2 ? 2 : (g.f.M <= 4 ? 4 : 8));
+    const int lds = (ntrip > 4 ? 2 : 1) * mr * (ntrip < 4 ? ntrip : 4) * 1024 * 2;       // <= 128 KiB (eight rows, two windows)
+#define GD4(MR, PN, WN) do { static std::atomic<uint64_t> ok{0};                                                                               \
+        if (mm_ensure_dynamic_lds((const void*)gemv_deep_kernel<MR, MODE, PN, WN>, 128 * 1024, ok) != MM355_OK) return MM355_ELAUNCH;          \
+        hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, WN>), dim3(grid), dim3(NT), lds, s, g); } while (0)
+#define GD3(MR, PN) do { if (ntrip > 4) GD4(MR, PN, true); else GD4(MR, PN, false); } while (0)
+#define GD(MR) do { if (prenorm) { if constexpr (MODE != 0) GD3(MR, true); } else GD3(MR, false); } while (0)
+    if (mr == 1) GD(1);
+    else if (mr == 2) GD(2);
+    else if (mr == 4) GD(4);
+    else GD(8);
 #undef GD
-#undef GD2
 #undef GD3
+#undef GD4
     return mm_launch_status();
 }
 
@@ -1094,7 +1183,7 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
     if (flags & MM355_GEMM_ACCUMULATE) return MM355_EUNSUPPORTED;
     if (N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (M >= 3) {                                            // 3 .. 16 rows: the MFMA form (one or two rows: the VALU kernels below)
+    if (M > 8) {                                             // 9 .. 16 rows: the MFMA form (up to eight rows: the VALU kernels below)
         if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f.x = x; g.f.ldx = ldx; g.f.W = W; g.f.ldw = ldw; g.f.M = (int)M; g.f.N = (int)N; g.f.K = (int)K;
@@ -1107,15 +1196,17 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
         g.y = y; g.ldy = ldy; g.bias = bias; g.res = residual; g.ldr = ldr; g.flags = flags;
         return launch_gemv_deep<0>(g, (N + 3) / 4, false, s);
     }
-    // K > 16384 or a weight beyond 32-bit byte offsets: the plain stream (x re-read from L2 per chunk); few rows of a long K split K over
-    // the waves of a workgroup
+    // a weight beyond 32-bit byte offsets: the plain stream (x re-read from L2 per chunk); few rows of a long K split K over the waves
+    // of a workgroup
     const int ksplit = (N <= 8192 && K >= 8192) ? 4 : 1;
     const int rows_per_wg = 16 / ksplit;
     const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
 #define GV2(MR, KSV) hipLaunchKernelGGL((gemv_kernel<MR, KSV>), dim3(grid), dim3(NT), 0, s, x, ldx, W, ldw, y, ldy, (int)M, (int)N, (int)K, bias, residual, ldr, flags)
 #define GV(MR) do { if (ksplit == 4) GV2(MR, 4); else if (ksplit == 2) GV2(MR, 2); else GV2(MR, 1); } while (0)
     if (M == 1) GV(1);
-    else GV(2);
+    else if (M == 2) GV(2);
+    else if (M <= 4) GV(4);
+    else GV(8);
 #undef GV2
 #undef GV
     return mm_launch_status();
@@ -1212,7 +1303,7 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
     GemvFusedArgs a = {};
     a.x = x; a.ldx = ldx; a.W = Wgu; a.ldw = ldw; a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = act; a.ld_out = ld_act; a.I = (int)I;
-    if (M >= 3) {
+    if (M > 8) {
         if (!gemv_mfma_addressable(M, 2 * I, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f = a;
@@ -1223,7 +1314,7 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
         g.f = a;
         return launch_gemv_deep<1>(g, I / 2, norm_w != nullptr, (hipStream_t)stream);
     }
-    return MM355_EUNSUPPORTED;                               // K > 16384 or a weight beyond 32-bit byte offsets: the unfused launch sequence
+    return MM355_EUNSUPPORTED;                               // a weight beyond 32-bit byte offsets: the unfused launch sequence
 }
 
 extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
@@ -1244,7 +1335,7 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
     a.x = x; a.ldx = ldx; a.W = Wqkv; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = qkv; a.ld_out = ld_qkv; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.d = (int)d;
     a.cos_t = cos_t; a.sin_t = sin_t; a.positions = positions; a.kc = k_cache; a.vc = v_cache; a.ld_kv = ld_kv; a.bs_kv = batch_stride_kv;
-    if (M >= 3) {
+    if (M > 8) {
         if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f = a;
@@ -1255,5 +1346,5 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
         g.f = a;
         return launch_gemv_deep<2>(g, N / 4, norm_w != nullptr, (hipStream_t)stream);
     }
-    return MM355_EUNSUPPORTED;                               // K > 16384 or a weight beyond 32-bit byte offsets: the unfused launch sequence
+    return MM355_EUNSUPPORTED;                               // a weight beyond 32-bit byte offsets: the unfused launch sequence
 }

@@ -32,7 +32,7 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             # the next until the optimizer rewrites the parameters: under gradient accumulation the four transposes per layer are made
             # once per optimizer step instead of once per micro-batch (+2 bytes per decoder parameter while a window is open)
             "wt_cache": False,
-            "decode_fold_rows": 2,                           # decode step: fold the RMSNorms into the GEMVs' operand reads up to this many rows
+            "decode_fold_rows": 4,                           # decode step: fold the RMSNorms into the GEMVs' operand reads up to this many rows
             # one launch for an input-gradient GEMM and the weight-gradient GEMM that reads the same dy: (dn2, dW_gate_up) and (dX_o, dW_o)
             # -- the mechanism of dw_pair (mm355_gemm_pair_bf16: same kernel body, same bits), saving one ramp and tail per pair
             "dx_pair": True}
@@ -807,7 +807,7 @@ def decoder_prefill(x, layers, meta, cache, row=0):
 
 def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bound):
     """<= 16 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
-    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: one or two rows on the vector ALU, 3 .. 16 on MFMA), attention per
+    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: up to eight rows on the vector ALU, 9 .. 16 on MFMA), attention per
     row at its own length."""
     nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
@@ -818,8 +818,8 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bou
         if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0:
             # five launches per layer: RMSNorm folded into the q|k|v and gate|up GEMVs' operand reads, RoPE + cache append and SwiGLU into
             # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below).
-            # Three rows and more (the MFMA GEMVs): the norm runs as its own launch -- folded in, every workgroup would normalise ALL rows
-            # again (measured at 8 / 16 rows: 66 / 100 us for the gate|up launch against 50 with the norm outside) -- seven launches, same bits.
+            # Five rows and more: the norm runs as its own launch -- folded in, every workgroup would normalise ALL rows again (measured, cached
+            # step of 32 layers: four rows 3.50 -> 3.38 ms with the norms folded, eight rows 4.03 -> 4.40) -- seven launches, same bits.
             fold = x.shape[0] <= VARIANTS["decode_fold_rows"]
             n1 = x if fold else ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
             qkv = ops.gemv_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],

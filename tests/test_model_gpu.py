@@ -650,7 +650,7 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
 @pytest.mark.parametrize("B", [3, 8, 11, 19])
 def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypatch):
     """The cached step of a batch (reference: the whole batch goes to ONE forward per step, metamorph_llama.py:711-717) takes all B rows
-    through every decoder layer in one pass -- 5 launches per layer (7 from three rows on: the norms run on their own) for B <= 16 (the GEMV
+    through every decoder layer in one pass -- 5 launches per layer (7 from five rows on: the norms run on their own) for B <= 16 (the GEMV
     kernels' M), ceil(B / 16) x that beyond -- not
     B passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
     logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal wherever the top two
@@ -683,7 +683,7 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     for b in range(B):
         alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
         for step, (x, y) in enumerate(zip(alone.scores, out.scores)):
-            # (alone: one row = the vector-ALU GEMVs; in the batch: 3 .. 16 rows = the MFMA GEMVs -- the same products in another fp32
+            # (alone: one row = an fp32 fma chain; in the batch: 3 .. 8 rows = v_dot2c_f32_bf16, 9 .. 16 = MFMA -- the same products in another fp32
             # summation order, re-rounded to bf16 after every projection: differences of a bf16 step of the hidden state, i.e. ~1e-2 on a logit)
             assert torch.allclose(x[0], y[b], rtol=2e-2, atol=2e-2), (b, step, float((x[0] - y[b]).abs().max()))
             if int(x[0].argmax()) != int(y[b].argmax()):
