@@ -740,14 +740,24 @@ def test_forward_with_host_mirrors_does_not_touch_the_device_for_its_plan():
     model = hip_model(cfg, init_state_dict(cfg, seed=11, dtype=torch.bfloat16))
     model.train()
     ids, msk, lab, img = T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]).to(DEV).bfloat16()
+    def poison(value):                                            # the caching allocator hands these blocks to the next torch.empty calls
+        junk = [torch.full((n,), value, device=DEV, dtype=torch.bfloat16) for n in (1 << 24, 1 << 20, 1 << 16, 1 << 12, 1 << 12, 1 << 10)]
+        del junk
+    poison(float("nan"))
     plain = model(input_ids=ids.to(DEV), attention_mask=msk.to(DEV), labels=lab.to(DEV), images=img)
+    assert bool(torch.isfinite(plain.hidden_states.float()).all()), "a forward buffer is read before it is written"
+    poison(3.0)
     s0 = dict(HM.STATS)
     mirrored = model(input_ids=HM.to_device(ids, DEV), attention_mask=HM.to_device(msk, DEV), labels=HM.to_device(lab, DEV), images=img)
     assert HM.STATS["sync"] == s0["sync"] and HM.STATS["mirror"] >= s0["mirror"] + 3, (s0, HM.STATS)
     cpu_in = model(input_ids=ids, attention_mask=msk, labels=lab, images=img)                 # CPU tensors are their own mirror
     assert HM.STATS["sync"] == s0["sync"]
-    for out in (mirrored, cpu_in):
-        assert torch.equal(out.loss, plain.loss) and torch.equal(out.hidden_states, plain.hidden_states)
+    for name, out in (("mirrored", mirrored), ("cpu inputs", cpu_in)):
+        # (the loss SCALAR is a sum of per-row terms by fp32 atomicAdd across workgroups: its last bit depends on the order of arrival -- seen
+        # once in a full-suite run: 11.9583979 vs 11.9583998 --; hidden states and gradients have no atomics on their path)
+        assert abs(float(out.loss) - float(plain.loss)) <= 4e-6 * abs(float(plain.loss)), (name, float(out.loss), float(plain.loss))
+        dh = (out.hidden_states.float() - plain.hidden_states.float()).abs()
+        assert torch.equal(out.hidden_states, plain.hidden_states), (name, float(dh.max()), torch.nonzero(dh.amax(-1))[:8].tolist(), msk.tolist())
     mirrored.loss.backward()
     assert HM.STATS["sync"] == s0["sync"]
 
