@@ -930,3 +930,20 @@ def test_pre_registered_multi_gpu_prediction_model():
         assert r["ring"]["all_gather_ms"] > r["direct"]["all_gather_ms"] or n == 2
         last = r
     assert 7.0 <= last["ring"]["scaling_vs_one_rank"] <= 7.7 and 7.8 <= last["direct"]["scaling_vs_one_rank"] <= 8.2, last
+
+
+def test_decode_attention_bound_follows_the_host_known_lengths():
+    """mm355_attn_decode sizes its launch by an upper bound on the cached lengths: 1024 (one key group, one workgroup per query head) while
+    every sequence INCLUDING the row about to be appended fits, the cache's capacity afterwards; a cache smaller than 1024 rows is its own
+    bound.  functional.decode_kv_bound reads the host mirror of the lengths only."""
+    import types
+    import metamorph_amd.functional as F
+
+    def cache(lengths, cap):
+        return types.SimpleNamespace(lengths=list(lengths), length=max(lengths), max_len=cap)
+    assert F.decode_kv_bound(cache([5, 700, 1022], 4096)) == 1024
+    assert F.decode_kv_bound(cache([5, 700, 1023], 4096)) == 1024          # the appended row makes 1024: still one group
+    assert F.decode_kv_bound(cache([5, 700, 1024], 4096)) == 4096
+    assert F.decode_kv_bound(cache([3000], 4096)) == 4096
+    assert F.decode_kv_bound(cache([10, 20], 644)) == 644                  # capacity below one group: the capacity
+    assert F.decode_kv_bound(cache([10, 20], 1024)) == 1024
