@@ -288,6 +288,8 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
  *   gemv_swiglu: act[M][I] = SiLU(g) * u with [g | u] = n . Wgu[2I][K]^T formed in the GEMV's epilogue (g, u rounded to bf16 first:
  *         the bits of mm355_gemv_bf16 + mm355_swiglu_fwd); norm_w != NULL: n = RMSNorm(x; norm_w, eps) formed per workgroup on the
  *         fly (the bits of mm355_rmsnorm_fwd), else n = x.  HF LlamaMLP / LlamaRMSNorm at decode shape (metamorph_llama.py:502-597).
+ *         With norm_w and 9 .. 16 rows all normalised rows stay in LDS: M * (K + 8) * 2 bytes <= 140 KiB, else MM355_EUNSUPPORTED
+ *         (run mm355_rmsnorm_fwd first); up to eight rows any K (windows of 4096 columns).  The same holds for gemv_rope_append.
  *   gemv_rope_append: the fused q|k|v projection of M new rows with RoPE at positions[m] (device) and the KV-cache append in the
  *         epilogue: q -> qkv[m][0 .. Hq*d), rotated k and v -> cache row positions[m] (the bits of mm355_gemv_bf16 +
  *         mm355_rope_kv_append); the k | v columns of `qkv` are not written.  norm_w as above.

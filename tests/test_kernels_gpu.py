@@ -980,8 +980,15 @@ def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
     I, K = IK
     x, w, nw = rnd(M, K, seed=1).to(DEV), rnd(2 * I, K, seed=2, scale=0.05).to(DEV), (1.0 + 0.1 * rnd(K, seed=3)).bfloat16().to(DEV)
     ref = ops.swiglu_fwd(ops.gemv(ops.rmsnorm_fwd(x, nw, 1e-5), w), I)
-    assert torch.equal(ops.gemv_swiglu(x, w, I, norm_w=nw, eps=1e-5), ref)
     assert torch.equal(ops.gemv_swiglu(x, w, I), ops.swiglu_fwd(ops.gemv(x, w), I))
+    if M > 8 and M * (K + 8) * 2 > 140 * 1024:
+        # 9 .. 16 rows with the norm folded in keep ALL normalised rows in LDS (no windows on the MFMA form): refused beyond 140 KiB,
+        # the caller runs mm355_rmsnorm_fwd first (functional.py folds the norms up to four rows only)
+        from metamorph_amd.lib import Mm355Error
+        with pytest.raises(Mm355Error):
+            ops.gemv_swiglu(x, w, I, norm_w=nw, eps=1e-5)
+        return
+    assert torch.equal(ops.gemv_swiglu(x, w, I, norm_w=nw, eps=1e-5), ref)
 
 
 @pytest.mark.parametrize("geo", [(1, 8, 2, 128, 512), (3, 4, 4, 64, 1032), (2, 32, 8, 128, 4096), (8, 2, 1, 80, 256), (8, 32, 8, 128, 4096), (16, 8, 2, 128, 1024),
