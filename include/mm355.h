@@ -274,12 +274,13 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 /* ------------------------------------------------------------------------------------------------
  * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
  * re-runs the prefix every step).  HBM-bound streaming kernels.
- *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16).  Up to eight rows run on the
+ *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16).  Up to four rows run on the
  *         vector ALU with the x rows parked in LDS (windows of 4096 columns), so that only weight loads sit in the in-order
- *         vector-memory queue: one or two rows as an fp32 fma chain, three to eight on v_dot2c_f32_bf16; 9 .. 16 rows on
- *         v_mfma_f32_16x16x32_bf16 with the weight rows loaded from HBM in fragment layout.  flags BIAS / GELU_ERF / GELU_TANH /
- *         RESIDUAL / OUT_F32 as for the GEMM.  The weight is addressed with 32-bit byte offsets: N * ldw * 2 < 3.75 GiB (else the plain
- *         stream of mm355_gemv_bf16 for up to eight rows; MM355_EUNSUPPORTED for more rows and for the fused forms below).
+ *         vector-memory queue: one or two rows as an fp32 fma chain, three and four on v_dot2c_f32_bf16; 5 .. 16 rows on
+ *         v_mfma_f32_16x16x32_bf16, the weight rows loaded coalesced and re-laid out into fragments through wave-private LDS.  flags
+ *         BIAS / GELU_ERF / GELU_TANH / RESIDUAL / OUT_F32 as for the GEMM.  The weight is addressed with 32-bit byte offsets:
+ *         N * ldw * 2 < 3.75 GiB (else the plain stream of mm355_gemv_bf16 for up to four rows; MM355_EUNSUPPORTED for more rows and for
+ *         the fused forms below).
  *   attn_decode: one query row per (sample, head), q [B][Hq*d] (ld_q), caches [B][max rows][Hkv*d] (row stride ld_kv,
  *         sample stride batch_stride_kv), kv_lens[B] (device) valid cached rows INCLUDING the current one, max_kv_len an
  *         upper bound of them (sizes the launch and the workspace of mm355_attn_decode_ws_floats floats); GQA groups 1/2/4/8.
@@ -288,8 +289,8 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
  *   gemv_swiglu: act[M][I] = SiLU(g) * u with [g | u] = n . Wgu[2I][K]^T formed in the GEMV's epilogue (g, u rounded to bf16 first:
  *         the bits of mm355_gemv_bf16 + mm355_swiglu_fwd); norm_w != NULL: n = RMSNorm(x; norm_w, eps) formed per workgroup on the
  *         fly (the bits of mm355_rmsnorm_fwd), else n = x.  HF LlamaMLP / LlamaRMSNorm at decode shape (metamorph_llama.py:502-597).
- *         With norm_w and 9 .. 16 rows all normalised rows stay in LDS: M * (K + 8) * 2 bytes <= 140 KiB, else MM355_EUNSUPPORTED
- *         (run mm355_rmsnorm_fwd first); up to eight rows any K (windows of 4096 columns).  The same holds for gemv_rope_append.
+ *         With norm_w and 5 .. 16 rows all normalised rows stay in LDS: M * (K rounded up to 32 + 8) * 2 bytes <= 140 KiB, else MM355_EUNSUPPORTED
+ *         (run mm355_rmsnorm_fwd first); up to four rows any K (windows of 4096 columns).  The same holds for gemv_rope_append.
  *   gemv_rope_append: the fused q|k|v projection of M new rows with RoPE at positions[m] (device) and the KV-cache append in the
  *         epilogue: q -> qkv[m][0 .. Hq*d), rotated k and v -> cache row positions[m] (the bits of mm355_gemv_bf16 +
  *         mm355_rope_kv_append); the k | v columns of `qkv` are not written.  norm_w as above.

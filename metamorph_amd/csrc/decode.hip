@@ -144,15 +144,19 @@ struct GemvFusedArgs {
     uint16_t* kc; uint16_t* vc; int64_t ld_kv, bs_kv;
 };
 
-// ------------------------------------------------------------------------------------------------ 9 .. 16 rows: the same GEMVs on MFMA
+// ------------------------------------------------------------------------------------------------ 5 .. 16 rows: the same GEMVs on MFMA
 // Round 5 (batched decode: all rows of a batch / all beams go through the layers in ONE pass).  The vector-ALU form (gemv_deep_kernel below)
-// holds M x 4 accumulators and M x-vectors per lane: beyond eight rows it runs out of registers.  Here the dot products run on
-// v_mfma_f32_16x16x32_bf16 and the kernel stays a weight stream at any M <= 16 (used for 9 .. 16; at 3 .. 8 rows the dot2 form is faster:
-// gate|up at eight rows 48 - 54 us against 60):
+// holds M x 4 accumulators and M x-vectors per lane and reads M x 16 bytes of LDS per chunk: fine up to four rows, LDS- and
+// register-bound at eight (gate|up 47 us).  Here the dot products run on v_mfma_f32_16x16x32_bf16 and the kernel stays a weight stream at
+// any M <= 16 (gate|up 44.6 us at eight rows, 52 at sixteen):
 //   * a wave owns FOUR units (the 4-row units of the kernels above: plain = rows 4u .. 4u+3; SwiGLU = gate rows c, c+1 and up rows I+c,
-//     I+c+1; RoPE = the rotation partners j, j+1, j+d/2, j+1+d/2 of one head) = 16 weight rows as the A operand: lane (fr = lane & 15,
-//     fq = lane >> 4) loads 16 B of row fr at k + 8 fq straight from HBM in the fragment layout (64 contiguous bytes per row and
-//     instruction, eight k-steps per row in flight, the next eight issued before the MFMAs of the current ones);
+//     I+c+1; RoPE = the rotation partners j, j+1, j+d/2, j+1+d/2 of one head) = 16 weight rows as the A operand (lane fr = lane & 15,
+//     fq = lane >> 4 holds row fr at k + 8 fq).  WLDS (the product form): a block of 256 columns is loaded COALESCED -- instruction u =
+//     rows 2u and 2u + 1, 512 contiguous bytes each, eight instructions per block, the next block issued before the MFMAs of the current
+//     one -- and re-laid out into fragments through 8.25 KiB of wave-private LDS (eight ds_write_b128 + eight ds_read_b128 per block, rows
+//     528 B apart: conflict-free; a wave's LDS operations execute in order, so no barrier).  The first form loaded straight into the
+//     fragment layout, i.e. 64 contiguous bytes per row and instruction: gate|up at 16 rows 69 us against 53 now, lm_head 275 -> 204
+//     (it remains for the folded-norm variant, whose x rows take the LDS);
 //   * the x rows are the B operand (row m = fr, zero beyond M): from L2 as they are, or -- PRENORM -- from LDS, where every workgroup
 //     forms bf16(w * bf16(x * rstd)) once (rmsnorm_fwd_kernel's arithmetic and reduction order);
 //   * D[16 weight rows][16 x rows]: lane (m = fr, unit fq) ends with the FOUR outputs of one unit for one x row -- exactly what the
@@ -186,9 +190,12 @@ MM_DEV void unit_rows(const GemvFusedArgs& a, int unit, int (&rows)[4]) {
     }
 }
 
-template <int MODE, bool PRENORM, int GR>
+template <int MODE, bool PRENORM, int GR, bool WLDS = false>
 __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
+    static_assert(!WLDS || GR == 1, "the LDS re-layout is written for one group of 16 rows per wave");
     const GemvFusedArgs& a = g.f;
+    constexpr int WROW = 512 + 16;                           // WLDS: bytes per weight row of a 256-column block in LDS (+ 16: the 16 rows of a fragment read fall on different banks)
+    __shared__ __attribute__((aligned(16))) unsigned char wl[WLDS ? NT / 64 : 1][WLDS ? 16 * WROW : 16];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // PRENORM: [M][xs_stride] normalised x rows (bf16)
     __shared__ float part[NT / 64][GR][64][4];
     __shared__ float red[NT / 64];
@@ -210,6 +217,20 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         wp[gi] = a.W + (int64_t)min(max(myrow, 0), a.N - 1) * a.ldw + fq * 8;
         wo[gi] = (uint32_t)min(max(myrow, 0), a.N - 1) * (uint32_t)a.ldw * 2u + (uint32_t)fq * 16u;
     }
+    // WLDS: the same 16 rows loaded COALESCED -- instruction u = rows 2u (lanes 0..31) and 2u + 1 (lanes 32..63), 512 contiguous bytes
+    // each -- and re-laid out into the fragment form through wave-private LDS
+    uint32_t woc[8];
+    if constexpr (WLDS) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ri = 2 * u + (lane >> 5);
+            unit_rows<MODE>(a, grp0 * 4 + (ri >> 2), rows);
+            int row = rows[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) row = (ri & 3) == r ? rows[r] : row;
+            woc[u] = (uint32_t)min(max(row, 0), a.N - 1) * (uint32_t)a.ldw * 2u + (uint32_t)(lane & 31) * 16u;
+        }
+    }
     const uint16_t* xp = a.x + (int64_t)min(fr, M - 1) * a.ldx + fq * 8;
     const uint32_t xo = (uint32_t)min(fr, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)fq * 16u;
     // buffer descriptors: a load whose offset lies beyond num_records returns zeros WITHOUT touching memory -- the branch-free way to
@@ -230,10 +251,15 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     const int e1 = min(s1, (K & 31) ? nst - 1 : nst);        // end of the steps that are complete in k
     const int nb = max(e1 - s0, 0) / U;
     auto loadw = [&](u32x4 (&w)[GR][U], int s, uint32_t skip) {   // skip = 0 | OOB (wave-uniform)
+        if constexpr (WLDS) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) w[0][u] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (woc[u] + (uint32_t)s * 64u) | skip, 0, 2);
+        } else {
 #pragma unroll
-            for (int gi = 0; gi < GR; ++gi) w[gi][u] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (wo[gi] + (uint32_t)(s + u) * 64u) | skip, 0, 2);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int gi = 0; gi < GR; ++gi) w[gi][u] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (wo[gi] + (uint32_t)(s + u) * 64u) | skip, 0, 2);
+        }
     };
     auto loadx = [&](u32x4 (&xv)[U], int s, uint32_t skip) {
 #pragma unroll
@@ -267,12 +293,29 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             for (int e = 0; e < 8; ++e) xv[e] = nw[e] * round_bf(xv[e] * rs);
             *(u32x4*)(xs + (int64_t)m * g.xs_stride + v * 16) = pack8(xv);
         }
+        // the columns between K and the end of its last 32-column step: a prefetched block behind the slice reads them against zero
+        // weights, and 0 x (whatever the previous kernel left in LDS) may be NaN
+        const int npad = ((K + 31) >> 5) * 4 - nv;
+        for (int i = threadIdx.x; i < M * npad; i += NT)
+            *(u32x4*)(xs + (int64_t)(i / npad) * g.xs_stride + (nv + i % npad) * 16) = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
     f32x4 acc[GR][2];
 #pragma unroll
     for (int gi = 0; gi < GR; ++gi) acc[gi][0] = acc[gi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mm = [&](const u32x4 (&w)[GR][U], const u32x4 (&xv)[U]) {
+        if constexpr (WLDS) {
+            unsigned char* my = wl[wave];                    // (one wave's LDS operations execute in order: no barrier)
+#pragma unroll
+            for (int u = 0; u < U; ++u) *(u32x4*)(my + (2 * u + (lane >> 5)) * WROW + (lane & 31) * 16) = w[0][u];
+            u32x4 fa[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) fa[u] = *(const u32x4*)(my + fr * WROW + u * 64 + fq * 16);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc[0][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u]), __builtin_bit_cast(bf16x8, xv[u]), acc[0][u & 1], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)                          // 2 GR independent chains: no MFMA waits for the one before it
 #pragma unroll
@@ -399,14 +442,14 @@ int launch_gemv_mfma_gr(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_
     const int bpw = (NT / 64) / g.ks;
     const unsigned grid = (unsigned)((blocks + bpw - 1) / bpw);
     if (prenorm) {
-        g.xs_stride = (g.f.K + 8) * 2;                       // + 16 B per row: the 16 x rows of a fragment read fall on different banks
+        g.xs_stride = (((g.f.K + 31) >> 5) * 32 + 8) * 2;    // whole 32-column steps + 16 B per row: the 16 x rows of a fragment read fall on different banks
         const int lds = g.f.M * g.xs_stride;
         if (lds > 140 * 1024) return MM355_EUNSUPPORTED;
         static std::atomic<uint64_t> ok{0};                  // (one opt-in per device, to the largest size any call may ask for)
         if (mm_ensure_dynamic_lds((const void*)gemv_mfma_kernel<MODE, true, GR>, 140 * 1024, ok) != MM355_OK) return MM355_ELAUNCH;
         hipLaunchKernelGGL((gemv_mfma_kernel<MODE, true, GR>), dim3(grid), dim3(NT), lds, s, g);
     } else {
-        hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, GR>), dim3(grid), dim3(NT), 0, s, g);
+        hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, GR, GR == 1>), dim3(grid), dim3(NT), 0, s, g);   // weights coalesced + re-laid out through LDS
     }
     return mm_launch_status();
 }
@@ -425,7 +468,7 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
     return launch_gemv_mfma_gr<MODE, 1>(g, units, prenorm, s);
 }
 
-// ------------------------------------------------------------------------------------------------ up to eight rows: x in LDS, weights alone in the queue
+// ------------------------------------------------------------------------------------------------ up to four rows: x in LDS, weights alone in the queue
 // Round 4's kernels (gemv_kernel at the top, and a fused twin of it) read the x chunk of every trip from L2 INSIDE the loop, i.e. behind
 // the weight loads they had just prefetched: the vector-memory counter retires in order, so each x chunk waited for the whole prefetch
 // block and the pipeline never ran ahead -- 2.9 / 3.1 TB/s on the N = 4096 / 6144 projections (o: 11.8 us, q|k|v: 16.3 us), 5.2 on
@@ -439,19 +482,19 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
 //     (GEMV -> SwiGLU; GEMV -> RoPE + cache append): the same bits (a lane beyond K adds fma(x, 0, acc): nothing).
 //   * rows longer than 4096 columns pass through LDS in WINDOWS of 4096 (two buffers): the next window's vectors are loaded while the
 //     current one is consumed (eight rows: two rows per trip) and stored before the barrier that ends it -- any K, <= 128 KiB of LDS;
-//   * three to eight rows (MR = 4, 8) take v_dot2c_f32_bf16 on the packed pairs -- full rate (5.2 cycles per wave instruction, as
+//   * three and four rows (MR = 4) take v_dot2c_f32_bf16 on the packed pairs -- full rate (5.2 cycles per wave instruction, as
 //     v_fmac_f32: tools/probes) and no unpacking: 16 M instead of 40 M vector instructions per chunk; fp32 accumulation either way.
+//     (An eight-row instantiation was measured too -- 208 registers, two waves per SIMD, 8 x 16-byte LDS reads per chunk: gate|up 47 us --
+//     and lost to the MFMA form above once that loaded its weights coalesced: five rows and more go there.)
 // Measured (profiles/r5_decode_*): one row: o 8.3 us, q|k|v 12.3, gate|up 37.1 (6.3 TB/s), down 21.5 (was 22.5 with K split over four
 // waves), lm_head 155 (was 170): 2.89 ms per token = 5.2 TB/s of weights; ring depth 1 .. 4 is within noise of it (the in-order x loads
-// were the stall, not the depth).  Four rows: gate|up 41 us (5.7 TB/s); eight: 48 - 54 us (two waves per SIMD at 208 registers; the
-// 8 x 16-byte LDS reads per chunk and wave are what is left: 24 us of LDS time per CU and launch).
+// were the stall, not the depth).  Four rows: gate|up 41 us (5.7 TB/s).
 template <int MR, int MODE, bool PRENORM, bool WINDOWS>
 __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     const GemvFusedArgs& a = g.f;
     constexpr int R = 4;
     constexpr bool DOT2 = MR > 2;                            // (the fma chain at four / eight rows: gate|up 48.8 / 89.7 us against 42.0 / 63.9)
-    constexpr int NB = 2;                                    // trips in the register ring (measured at one row, 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token;
-                                                             // at eight rows one trip loses: gate|up 48 -> 55 us)
+    constexpr int NB = 2;                                    // trips in the register ring (measured at one row, 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token)
     constexpr int WT = 4, WK = WT * 1024;                    // an x window: four trips = 4096 k
     constexpr int XV = WK / 8 / NT;                          // 16-byte vectors per thread, row and window (2)
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // [1 or 2 windows][MR][wk] bf16 x rows as the dot products take them
@@ -476,9 +519,8 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
 #pragma unroll
     for (int r = 0; r < R; ++r) wo[r] = (uint32_t)min(rows[r], a.N - 1) * (uint32_t)a.ldw * 2u;
     // this thread's vectors v = t + 256 i of window w of the x rows (and of the norm weight); beyond K: zeros, no memory access.  Behind the
-    // first window the rows are staged in HS parts (eight rows: two rows per trip, live in registers for that trip only: 256 -> 2xx registers,
-    // two waves per SIMD)
-    constexpr int HS = (WINDOWS && MR == 8) ? 4 : 1, MP = MR / HS;
+    // first window the rows are staged in HS parts
+    constexpr int HS = 1, MP = MR / HS;                      // (parts per window: an eight-row form staged two rows per trip to stay under 256 registers)
     u32x4 xr[MR][XV], nr[XV];
     auto stage_load = [&](int w, int m0, int m1) {
 #pragma unroll
@@ -716,24 +758,21 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
 }
 
 bool gemv_deep_applies(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
-    return M <= 8 && gemv_mfma_addressable(M, N, K, ldx, ldw);
+    return M <= 4 && gemv_mfma_addressable(M, N, K, ldx, ldw);
 }
 
 template <int MODE>
 int launch_gemv_deep(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
     const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
     const int ntrip = (g.f.K + 1023) >> 10;
-    const int mr = g.f.M == 1 ? 1 : (g.f.M == 2 ? 2 : (g.f.M <= 4 ? 4 : 8));
-    const int lds = (ntrip > 4 ? 2 : 1) * mr * (ntrip < 4 ? ntrip : 4) * 1024 * 2;       // <= 128 KiB (eight rows, two windows)
-#define GD4(MR, PN, WN) do { static std::atomic<uint64_t> ok{0};                                                                               \
-        if (mm_ensure_dynamic_lds((const void*)gemv_deep_kernel<MR, MODE, PN, WN>, 128 * 1024, ok) != MM355_OK) return MM355_ELAUNCH;          \
-        hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, WN>), dim3(grid), dim3(NT), lds, s, g); } while (0)
+    const int mr = g.f.M == 1 ? 1 : (g.f.M == 2 ? 2 : 4);
+    const int lds = (ntrip > 4 ? 2 : 1) * mr * (ntrip < 4 ? ntrip : 4) * 1024 * 2;       // <= 64 KiB (four rows, two windows)
+#define GD4(MR, PN, WN) hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, WN>), dim3(grid), dim3(NT), lds, s, g)
 #define GD3(MR, PN) do { if (ntrip > 4) GD4(MR, PN, true); else GD4(MR, PN, false); } while (0)
 #define GD(MR) do { if (prenorm) { if constexpr (MODE != 0) GD3(MR, true); } else GD3(MR, false); } while (0)
     if (mr == 1) GD(1);
     else if (mr == 2) GD(2);
-    else if (mr == 4) GD(4);
-    else GD(8);
+    else GD(4);
 #undef GD
 #undef GD3
 #undef GD4
@@ -1183,7 +1222,7 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
     if (flags & MM355_GEMM_ACCUMULATE) return MM355_EUNSUPPORTED;
     if (N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (M > 8) {                                             // 9 .. 16 rows: the MFMA form (up to eight rows: the VALU kernels below)
+    if (M > 4) {                                             // 5 .. 16 rows: the MFMA form (up to four rows: the VALU kernels below)
         if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f.x = x; g.f.ldx = ldx; g.f.W = W; g.f.ldw = ldw; g.f.M = (int)M; g.f.N = (int)N; g.f.K = (int)K;
@@ -1205,8 +1244,7 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
 #define GV(MR) do { if (ksplit == 4) GV2(MR, 4); else if (ksplit == 2) GV2(MR, 2); else GV2(MR, 1); } while (0)
     if (M == 1) GV(1);
     else if (M == 2) GV(2);
-    else if (M <= 4) GV(4);
-    else GV(8);
+    else GV(4);
 #undef GV2
 #undef GV
     return mm_launch_status();
@@ -1303,7 +1341,7 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
     GemvFusedArgs a = {};
     a.x = x; a.ldx = ldx; a.W = Wgu; a.ldw = ldw; a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = act; a.ld_out = ld_act; a.I = (int)I;
-    if (M > 8) {
+    if (M > 4) {
         if (!gemv_mfma_addressable(M, 2 * I, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f = a;
@@ -1335,7 +1373,7 @@ extern "C" int mm355_gemv_rope_append_bf16(const mm355_bf16* x, int64_t ldx, con
     a.x = x; a.ldx = ldx; a.W = Wqkv; a.ldw = ldw; a.M = (int)M; a.N = (int)N; a.K = (int)K; a.norm_w = norm_w; a.eps = eps;
     a.out = qkv; a.ld_out = ld_qkv; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.d = (int)d;
     a.cos_t = cos_t; a.sin_t = sin_t; a.positions = positions; a.kc = k_cache; a.vc = v_cache; a.ld_kv = ld_kv; a.bs_kv = batch_stride_kv;
-    if (M > 8) {
+    if (M > 4) {
         if (!gemv_mfma_addressable(M, N, K, ldx, ldw)) return MM355_EUNSUPPORTED;
         GemvMfmaArgs g = {};
         g.f = a;

@@ -807,7 +807,7 @@ def decoder_prefill(x, layers, meta, cache, row=0):
 
 def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bound):
     """<= 16 new rows (one per sequence) through every decoder layer against their cache rows k / v [layers, rows, max_len, width]:
-    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: up to eight rows on the vector ALU, 9 .. 16 on MFMA), attention per
+    every weight is streamed ONCE for all rows (mm355_gemv* take M <= 16: up to four rows on the vector ALU, 5 .. 16 on MFMA), attention per
     row at its own length."""
     nq = meta.Hq * meta.d
     for i, layer in enumerate(layers):
@@ -818,8 +818,8 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bou
         if VARIANTS["decode_fused"] and meta.I % 2 == 0 and meta.d % 4 == 0:
             # five launches per layer: RMSNorm folded into the q|k|v and gate|up GEMVs' operand reads, RoPE + cache append and SwiGLU into
             # their epilogues, the flash-decoding merge into the chunk that finishes last (same bits as the nine-launch sequence below).
-            # Five rows and more: the norm runs as its own launch -- folded in, every workgroup would normalise ALL rows again (measured, cached
-            # step of 32 layers: four rows 3.50 -> 3.38 ms with the norms folded, eight rows 4.03 -> 4.40) -- seven launches, same bits.
+            # Five rows and more (the MFMA GEMVs): the norm runs as its own launch -- folded in, every workgroup would normalise ALL rows again
+            # (measured, cached step of 32 layers: four rows 3.50 -> 3.38 ms with the norms folded, eight rows slower) -- seven launches, same bits.
             fold = x.shape[0] <= VARIANTS["decode_fold_rows"]
             n1 = x if fold else ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
             qkv = ops.gemv_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i],

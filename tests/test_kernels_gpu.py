@@ -981,8 +981,8 @@ def test_gemv_swiglu_fused_equals_the_launch_sequence(ops, M, IK):
     x, w, nw = rnd(M, K, seed=1).to(DEV), rnd(2 * I, K, seed=2, scale=0.05).to(DEV), (1.0 + 0.1 * rnd(K, seed=3)).bfloat16().to(DEV)
     ref = ops.swiglu_fwd(ops.gemv(ops.rmsnorm_fwd(x, nw, 1e-5), w), I)
     assert torch.equal(ops.gemv_swiglu(x, w, I), ops.swiglu_fwd(ops.gemv(x, w), I))
-    if M > 8 and M * (K + 8) * 2 > 140 * 1024:
-        # 9 .. 16 rows with the norm folded in keep ALL normalised rows in LDS (no windows on the MFMA form): refused beyond 140 KiB,
+    if M > 4 and M * ((K + 31) // 32 * 32 + 8) * 2 > 140 * 1024:
+        # 5 .. 16 rows with the norm folded in keep ALL normalised rows in LDS (no windows on the MFMA form): refused beyond 140 KiB,
         # the caller runs mm355_rmsnorm_fwd first (functional.py folds the norms up to four rows only)
         from metamorph_amd.lib import Mm355Error
         with pytest.raises(Mm355Error):

@@ -683,7 +683,7 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     for b in range(B):
         alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
         for step, (x, y) in enumerate(zip(alone.scores, out.scores)):
-            # (alone: one row = an fp32 fma chain; in the batch: 3 .. 8 rows = v_dot2c_f32_bf16, 9 .. 16 = MFMA -- the same products in another fp32
+            # (alone: one row = an fp32 fma chain; in the batch: 3 .. 4 rows = v_dot2c_f32_bf16, 5 .. 16 = MFMA -- the same products in another fp32
             # summation order, re-rounded to bf16 after every projection: differences of a bf16 step of the hidden state, i.e. ~1e-2 on a logit)
             assert torch.allclose(x[0], y[b], rtol=2e-2, atol=2e-2), (b, step, float((x[0] - y[b]).abs().max()))
             if int(x[0].argmax()) != int(y[b].argmax()):
