@@ -153,8 +153,8 @@ struct GemvFusedArgs {
 //     I+c+1; RoPE = the rotation partners j, j+1, j+d/2, j+1+d/2 of one head) = 16 weight rows as the A operand (lane fr = lane & 15,
 //     fq = lane >> 4 holds row fr at k + 8 fq).  WLDS (the product form): a block of 256 columns is loaded COALESCED -- instruction u =
 //     rows 2u and 2u + 1, 512 contiguous bytes each, eight instructions per block, the next block issued before the MFMAs of the current
-//     one -- and re-laid out into fragments through 8.25 KiB of wave-private LDS (eight ds_write_b128 + eight ds_read_b128 per block, rows
-//     528 B apart: conflict-free; a wave's LDS operations execute in order, so no barrier).  The first form loaded straight into the
+//     one -- and re-laid out into fragments through 8.5 KiB of wave-private LDS (eight ds_write_b128 + eight ds_read_b128 per block, rows
+//     544 B apart: conflict-free; a wave's LDS operations execute in order, so no barrier).  The first form loaded straight into the
 //     fragment layout, i.e. 64 contiguous bytes per row and instruction: gate|up at 16 rows 69 us against 53 now, lm_head 275 -> 204
 //     (it remains for the folded-norm variant, whose x rows take the LDS);
 //   * the x rows are the B operand (row m = fr, zero beyond M): from L2 as they are, or -- PRENORM -- from LDS, where every workgroup
@@ -194,7 +194,8 @@ template <int MODE, bool PRENORM, int GR, bool WLDS = false>
 __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     static_assert(!WLDS || GR == 1, "the LDS re-layout is written for one group of 16 rows per wave");
     const GemvFusedArgs& a = g.f;
-    constexpr int WROW = 512 + 16;                           // WLDS: bytes per weight row of a 256-column block in LDS (+ 16: the 16 rows of a fragment read fall on different banks)
+    constexpr int WROW = 512 + 32;                           // WLDS: bytes per weight row of a 256-column block in LDS (+ 32: every 16-lane group the hardware services together
+                                                             // reads 16 different 16-byte slots of the 256-byte bank row; + 16 leaves two-way conflicts: tests/test_host_logic.py)
     __shared__ __attribute__((aligned(16))) unsigned char wl[WLDS ? NT / 64 : 1][WLDS ? 16 * WROW : 16];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // PRENORM: [M][xs_stride] normalised x rows (bf16)
     __shared__ float part[NT / 64][GR][64][4];

@@ -798,8 +798,34 @@ def test_compiler_stays_out_of_the_streams_registers():
         assert not bad, (name, bad[:5])
 
 
+def test_batched_gemv_lds_relayout_is_conflict_free():
+    """csrc/decode.hip, gemv_mfma_kernel<.., WLDS>: a 256-column block of 16 weight rows is loaded coalesced (instruction u: rows 2u and
+    2u + 1, lanes 0..31 / 32..63, 16 B per lane), written to wave-private LDS with rows WROW = 544 bytes apart and read back as MFMA
+    fragments (lane fr = lane & 15, fq = lane >> 4: row fr, 16 B at k-step u, quarter fq).  Restated here: every lane of a read gets the
+    16 bytes its row / step / quarter were written with, and both the writes and the reads are bank-conflict free in each of the four
+    16-lane groups the hardware services together (MI355X_MICROARCH.md, LDS table) -- 16 different 16-byte slots of the 256-byte bank row."""
+    WROW = 544
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+    where = {}                                                   # LDS byte address -> (row of the 16, first column of the 8)
+    for u in range(8):
+        wr = {lane: (2 * u + (lane >> 5)) * WROW + (lane & 31) * 16 for lane in range(64)}
+        for lane, addr in wr.items():
+            assert addr not in where
+            where[addr] = (2 * u + (lane >> 5), (lane & 31) * 8)
+        for g in groups:
+            assert len({(wr[l] >> 4) & 15 for l in g}) == 16, ("write", u)
+    assert len(where) == 16 * 32 and max(where) + 16 <= 16 * WROW
+    for u in range(8):
+        rd = {lane: (lane & 15) * WROW + u * 64 + (lane >> 4) * 16 for lane in range(64)}
+        for lane, addr in rd.items():
+            assert where[addr] == (lane & 15, u * 32 + (lane >> 4) * 8)      # A operand: row fr, k = 32 u + 8 fq .. + 7
+        for g in groups:
+            assert len({(rd[l] >> 4) & 15 for l in g}) == 16, ("read", u)
+
+
 def test_fused_decode_gemv_row_ownership_is_a_partition():
-    """csrc/decode.hip, gemv_fused_kernel: a wave owns four weight rows chosen so that its epilogue finds its partners in its own
+    """csrc/decode.hip, unit_rows<MODE> (gemv_deep_kernel, gemv_mfma_kernel): a wave owns four-row units chosen so that its epilogue finds its partners in its own
     accumulators -- MODE 1 (SwiGLU): gate rows c, c + 1 and up rows I + c, I + c + 1; MODE 2 (RoPE + cache append): the rotation partners
     j, j + 1, j + d/2, j + 1 + d/2 of one q / k head, four neighbours of a v head.  The formulas, restated here, must cover every weight
     row exactly once for the geometries the models use (a row owned twice or never would be a silent wrong answer only for some heads)."""
