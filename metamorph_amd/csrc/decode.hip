@@ -190,9 +190,10 @@ MM_DEV void unit_rows(const GemvFusedArgs& a, int unit, int (&rows)[4]) {
     }
 }
 
-template <int MODE, bool PRENORM, int GR, bool WLDS = false>
+template <int MODE, bool PRENORM, int GR, bool WLDS = false, int XK = 0>
 __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     static_assert(!WLDS || GR == 1, "the LDS re-layout is written for one group of 16 rows per wave");
+    static_assert(XK == 0 || (WLDS && !PRENORM), "x windows come with the coalesced weight stream");
     const GemvFusedArgs& a = g.f;
     constexpr int WROW = 512 + 32;                           // WLDS: bytes per weight row of a 256-column block in LDS (+ 32: every 16-lane group the hardware services together
                                                              // reads 16 different 16-byte slots of the 256-byte bank row; + 16 leaves two-way conflicts: tests/test_host_logic.py)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     __shared__ float rstd_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int K = a.K, M = a.M, KS = g.ks;
+    const int K = a.K, M = a.M, KS = XK ? XK : g.ks;
     // a wave owns GR groups of 16 weight rows (= 4 GR units) over its K slice: one x fragment feeds GR MFMAs
     const int grp0 = (blockIdx.x * ((NT / 64) / KS) + wave / KS) * GR, ks = wave % KS;
     int rows[4];
@@ -269,7 +270,53 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             else xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (xo + (uint32_t)(s + u) * 64u) | skip, 0, 0);
         }
     };
+    // XK (the product form for 5 .. 16 rows): the x rows of a block go through LDS once per WORKGROUP instead of once per wave from L2 --
+    // at 16 rows the x fragments were as many bytes as the weights.  Two buffers of XK slices (one per K slice of the workgroup's waves) x
+    // 16 rows x 256 columns, rows XROW bytes apart (the fragment reads are those of the weight re-layout: conflict-free); every thread
+    // stages 2 XK vectors per block, loaded two blocks ahead and stored behind the barrier that retires the buffer's previous block.  All
+    // waves run the same number of block pairs (nbu: the longest slice), a wave past its own slice multiplies zero weights.
+    constexpr int XROW = 512 + 32, XVN = XK ? 2 * XK : 1;
+    uint32_t xsb[XVN], xld[XVN];
+    int xnb[XVN];
+    int nbu = nb;
+    if constexpr (XK > 0) {
+        const int complete = (K & 31) ? nst - 1 : nst;
+        nbu = 0;
+#pragma unroll
+        for (int q = 0; q < XK; ++q) nbu = max(nbu, max(min((nst * (q + 1)) / XK, complete) - (nst * q) / XK, 0) / U);
+#pragma unroll
+        for (int i = 0; i < XVN; ++i) {
+            const int vi = threadIdx.x + NT * i, q = vi >> 9, m = (vi >> 5) & 15, c = vi & 31;
+            const int q0 = (nst * q) / XK, q1 = min((nst * (q + 1)) / XK, complete);
+            xnb[i] = m < M ? max(q1 - q0, 0) / U : 0;
+            xsb[i] = (uint32_t)min(m, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)(q0 * 32 + c * 8) * 2u;
+            xld[i] = (uint32_t)((q * 16 + m) * XROW + c * 16);
+        }
+    }
+    auto xstage_load = [&](u32x4 (&r)[XVN], int b) {
+#pragma unroll
+        for (int i = 0; i < XVN; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (xsb[i] + (uint32_t)b * 512u) | (b < xnb[i] ? 0u : OOB), 0, 0);
+    };
+    auto xstage_store = [&](const u32x4 (&r)[XVN], int b) {
+#pragma unroll
+        for (int i = 0; i < XVN; ++i) *(u32x4*)(xs + (size_t)(b & 1) * XK * 16 * XROW + xld[i]) = r[i];
+    };
+    auto xfrag = [&](u32x4 (&xv)[U], int b) {
+        const unsigned char* base = xs + (size_t)((b & 1) * XK + ks) * 16 * XROW + min(fr, M - 1) * XROW + fq * 16;
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = *(const u32x4*)(base + u * 64);
+    };
+    u32x4 ra[XVN], rb[XVN];
+    if constexpr (XK > 0) {                                  // x first into the in-order vector-memory queue
+        xstage_load(ra, 0);
+        xstage_load(rb, 1);
+    }
     loadw(wa, s0, nb > 0 ? 0u : OOB);                        // the weight stream starts before the norm reduction
+    if constexpr (XK > 0) {
+        xstage_store(ra, 0);
+        xstage_store(rb, 1);
+        __syncthreads();
+    }
     if constexpr (PRENORM) {
         const int nv = K >> 3;
         for (int m = 0; m < M; ++m) {                        // rmsnorm_fwd_kernel's reduction: thread t sums elements 8 (t + 256 i) .. + 7 in order
@@ -324,6 +371,28 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
                 acc[gi][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[gi][u]), __builtin_bit_cast(bf16x8, xv[u]),
                                                                          acc[gi][u & 1], 0, 0, 0);
     };
+    if constexpr (XK > 0) {
+        for (int bk = 0; bk < nbu; bk += 2) {
+            const int s = s0 + bk * U;
+            const uint32_t skb = bk + 1 < nb ? 0u : OOB, ska = bk + 2 < nb ? 0u : OOB;
+            xstage_load(ra, bk + 2);
+            xstage_load(rb, bk + 3);
+            loadw(wb, s + U, skb);
+            __builtin_amdgcn_sched_barrier(0);
+            xfrag(xa, bk);
+            mm(wa, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // every wave is done with buffer 0's block
+            xstage_store(ra, bk + 2);
+            loadw(wa, s + 2 * U, ska);
+            __builtin_amdgcn_sched_barrier(0);
+            xfrag(xb, bk + 1);
+            mm(wb, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                 // ... with buffer 1's; and block bk + 2 is in buffer 0 for everyone
+            xstage_store(rb, bk + 3);
+        }
+    } else {
     loadx(xa, s0, nb > 0 ? 0u : OOB);
     for (int bk = 0; bk < nb; bk += 2) {                     // (sched_barrier: hipcc otherwise sinks the prefetch loads behind the MFMAs that do not need them)
         const int s = s0 + bk * U;
@@ -338,6 +407,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mm(wb, xb);                                          // (a skipped block is all zeros: adds nothing)
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     for (int st = s0 + nb * U; st < s1; ++st) {              // the tail: one step at a time, the k tail selected to zero
         const bool in = st * 32 + fq * 8 < K;
@@ -450,7 +520,20 @@ int launch_gemv_mfma_gr(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_
         if (mm_ensure_dynamic_lds((const void*)gemv_mfma_kernel<MODE, true, GR>, 140 * 1024, ok) != MM355_OK) return MM355_ELAUNCH;
         hipLaunchKernelGGL((gemv_mfma_kernel<MODE, true, GR>), dim3(grid), dim3(NT), lds, s, g);
     } else {
-        hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, GR, GR == 1>), dim3(grid), dim3(NT), 0, s, g);   // weights coalesced + re-laid out through LDS
+        if constexpr (GR == 1) {                             // weights coalesced + re-laid out through LDS, x rows through LDS windows
+            // measured (profiles/r5_gemv_rows.log): the windows win wherever the waves of a workgroup share one K range (wide weights:
+            // gate|up 47 -> 42 us at 8 rows, 53 -> 42 at 16, lm_head 208 -> 174) and, with K split over the waves, from nine rows on
+            // (down 26.8 -> 23.6 at 16); below that the per-block barriers of four slices cost more than the L2 reads they replace
+            if (g.ks > 1 && g.f.M <= 8) { hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, 1, true>), dim3(grid), dim3(NT), 0, s, g); return mm_launch_status(); }
+            const int xlds = 2 * g.ks * 16 * 544;
+#define GX(KSC) do { static std::atomic<uint64_t> okx{0};                                                                                      \
+                if (mm_ensure_dynamic_lds((const void*)gemv_mfma_kernel<MODE, false, 1, true, KSC>, 2 * 4 * 16 * 544, okx) != MM355_OK) return MM355_ELAUNCH; \
+                hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, 1, true, KSC>), dim3(grid), dim3(NT), xlds, s, g); } while (0)
+            if (g.ks == 4) GX(4); else if (g.ks == 2) GX(2); else GX(1);
+#undef GX
+        } else {
+            hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, GR>), dim3(grid), dim3(NT), 0, s, g);
+        }
     }
     return mm_launch_status();
 }
