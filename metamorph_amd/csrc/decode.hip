@@ -157,7 +157,8 @@ struct GemvFusedArgs {
 //     544 B apart: conflict-free; a wave's LDS operations execute in order, so no barrier).  The first form loaded straight into the
 //     fragment layout, i.e. 64 contiguous bytes per row and instruction: gate|up at 16 rows 69 us against 53 now, lm_head 275 -> 204
 //     (it remains for the folded-norm variant, whose x rows take the LDS);
-//   * the x rows are the B operand (row m = fr, zero beyond M): from L2 as they are, or -- PRENORM -- from LDS, where every workgroup
+//   * the x rows are the B operand (row m = fr, zero beyond M): XK (the product form wherever it wins, see the launcher): through
+//     double-buffered LDS windows of one block, staged once per workgroup; else from L2 as they are, or -- PRENORM -- from LDS, where every workgroup
 //     forms bf16(w * bf16(x * rstd)) once (rmsnorm_fwd_kernel's arithmetic and reduction order);
 //   * D[16 weight rows][16 x rows]: lane (m = fr, unit fq) ends with the FOUR outputs of one unit for one x row -- exactly what the
 //     epilogues of the kernels above take (bias / GELU / residual; SiLU(g) u; RoPE + cache append);
