@@ -547,9 +547,7 @@ bool gemv_mfma_addressable(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t
 template <int MODE>
 int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s) {
     int gr;
-    gemv_mfma_shape(units, gr, g.ks);
-    if (gr == 4) return launch_gemv_mfma_gr<MODE, 4>(g, units, prenorm, s);
-    if (gr == 2) return launch_gemv_mfma_gr<MODE, 2>(g, units, prenorm, s);
+    gemv_mfma_shape(units, gr, g.ks);                        // (gr is 1: two / four groups of 16 rows per wave were measured and bought nothing; the kernel keeps the parameter)
     return launch_gemv_mfma_gr<MODE, 1>(g, units, prenorm, s);
 }
 
