@@ -824,6 +824,37 @@ def test_batched_gemv_lds_relayout_is_conflict_free():
             assert len({(rd[l] >> 4) & 15 for l in g}) == 16, ("read", u)
 
 
+def test_batched_gemv_x_window_protocol():
+    """csrc/decode.hip, gemv_mfma_kernel<.., XK>: the x rows of block b live in LDS buffer b & 1.  Program order of every wave, restated:
+    store blocks 0, 1; barrier; then per pair (bk, bk + 1): read buffer 0 (block bk); barrier; store block bk + 2 into buffer 0; read
+    buffer 1 (block bk + 1); barrier; store block bk + 3 into buffer 1.  Waves run freely between barriers, so within one barrier phase
+    any wave's stores may precede or follow any other wave's reads: the protocol is right iff (1) no phase holds a store to and a read
+    of the same buffer, and (2) every read finds the block it wants, stored in an EARLIER phase and not overwritten since.  All waves run
+    the same number of pairs (nbu) -- a barrier count that depended on the wave's own slice would hang the workgroup."""
+    for nbu in range(0, 9):
+        phases = [[("store", 0, 0), ("store", 1, 1)], []]        # ops of ONE wave per barrier phase (all waves run the same list); the
+        for bk in range(0, nbu, 2):                              # barrier behind the first two stores opens the second phase
+            phases[-1].append(("read", 0, bk))                   # ... read buffer 0, then the barrier ends the phase
+            phases.append([("store", 0, bk + 2), ("read", 1, bk + 1)])
+            phases.append([("store", 1, bk + 3)])
+        content = {0: None, 1: None}                             # what a buffer holds once the phase's stores are all done
+        for ph in phases:
+            stores = {buf: blk for op, buf, blk in ph if op == "store"}
+            reads = [(buf, blk) for op, buf, blk in ph if op == "read"]
+            for buf, blk in reads:
+                assert buf not in stores, (nbu, ph)              # (1): another wave could be on either side of it
+                assert content[buf] == blk, (nbu, ph, content)   # (2)
+            content.update(stores)
+        n_barriers = len(phases) - 1
+        assert n_barriers == 1 + 2 * ((nbu + 1) // 2)            # a function of nbu only
+    # the uniform pair count: the longest slice's number of complete 8-step blocks, from (K, slices) only
+    def nbu_of(K, XK):
+        nst = (K + 31) // 32
+        complete = nst - 1 if K % 32 else nst
+        return max(max(min(nst * (q + 1) // XK, complete) - nst * q // XK, 0) // 8 for q in range(XK))
+    assert nbu_of(4096, 1) == 16 and nbu_of(4096, 4) == 4 and nbu_of(14336, 4) == 14 and nbu_of(1032, 4) == 1 and nbu_of(512, 4) == 0
+
+
 def test_fused_decode_gemv_row_ownership_is_a_partition():
     """csrc/decode.hip, unit_rows<MODE> (gemv_deep_kernel, gemv_mfma_kernel): a wave owns four-row units chosen so that its epilogue finds its partners in its own
     accumulators -- MODE 1 (SwiGLU): gate rows c, c + 1 and up rows I + c, I + c + 1; MODE 2 (RoPE + cache append): the rotation partners
