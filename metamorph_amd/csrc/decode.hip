@@ -734,7 +734,7 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(xf[m][e], wf[e], acc[m][r]);
                 }
-            } else {                                         // 3 .. 8 rows: v_dot2c_f32_bf16 on the packed pairs (no unpacking: 16 MR VALU ops per chunk, not 40 MR)
+            } else {                                         // 3 .. 4 rows: v_dot2c_f32_bf16 on the packed pairs (no unpacking: 16 MR VALU ops per chunk, not 40 MR)
                 u32x4 xv[MR];
 #pragma unroll
                 for (int m = 0; m < MR; ++m) xv[m] = *(const u32x4*)(src + ((size_t)m * wk + k) * 2);
