@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""mm355_attn_decode by cache length, batch and kernel variant (0 = 1024-thread wide, 1 = 256-row chunks): launches for rocprofv3
+"""mm355_attn_decode by cache length, batch and kernel variant (0 = product: 1024-thread workgroups, one per query head -- pairs from 64
+workgroups on -- while the bound on the cached lengths is <= 1024 rows, one per GQA group beyond; 1 = 256-row chunks; 2 = one per GQA
+group whatever the bound; VARS=0,1,2): launches for rocprofv3
 (`rocprofv3 --kernel-trace -d DIR -o ad -- python tools/bench_attn_decode.py`, then tools/rocpd_kernels.py DIR/ad_results.db --runs): the
 wall times printed here are launch-bound (~19 us per Python call), only the profiler's kernel durations mean anything."""
 import os, sys
