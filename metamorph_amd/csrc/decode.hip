@@ -563,8 +563,8 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
 //     carries the out-of-range mark (buffer loads return zeros without touching memory: no branch around a prefetch);
 //   * chunk order, fma order and epilogues are those of gemv_kernel<MR, 1> (plain) and of the launch sequences the fused modes replace
 //     (GEMV -> SwiGLU; GEMV -> RoPE + cache append): the same bits (a lane beyond K adds fma(x, 0, acc): nothing).
-//   * rows longer than 4096 columns pass through LDS in WINDOWS of 4096 (two buffers): the next window's vectors are loaded while the
-//     current one is consumed (eight rows: two rows per trip) and stored before the barrier that ends it -- any K, <= 128 KiB of LDS;
+//   * rows longer than a window (16384 columns for one or two rows, 4096 for four) pass through LDS in WINDOWS (two buffers): the next
+//     window's vectors are loaded while the current one is consumed and stored before the barrier that ends it -- any K;
 //   * three and four rows (MR = 4) take v_dot2c_f32_bf16 on the packed pairs -- full rate (5.2 cycles per wave instruction, as
 //     v_fmac_f32: tools/probes) and no unpacking: 16 M instead of 40 M vector instructions per chunk; fp32 accumulation either way.
 //     (An eight-row instantiation was measured too -- 208 registers, two waves per SIMD, 8 x 16-byte LDS reads per chunk: gate|up 47 us --
@@ -572,14 +572,15 @@ int launch_gemv_mfma(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
 // Measured (profiles/r5_decode_*): one row: o 8.3 us, q|k|v 12.3, gate|up 37.1 (6.3 TB/s), down 21.5 (was 22.5 with K split over four
 // waves), lm_head 155 (was 170): 2.89 ms per token = 5.2 TB/s of weights; ring depth 1 .. 4 is within noise of it (the in-order x loads
 // were the stall, not the depth).  Four rows: gate|up 41 us (5.7 TB/s).
-template <int MR, int MODE, bool PRENORM, bool WINDOWS>
+template <int MR, int MODE, bool PRENORM, bool WINDOWS, int WT = 4>
 __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     const GemvFusedArgs& a = g.f;
     constexpr int R = 4;
     constexpr bool DOT2 = MR > 2;                            // (the fma chain at four / eight rows: gate|up 48.8 / 89.7 us against 42.0 / 63.9)
     constexpr int NB = 2;                                    // trips in the register ring (measured at one row, 1 .. 4: 2.87 / 2.89 / 3.08 / 3.00 ms per token)
-    constexpr int WT = 4, WK = WT * 1024;                    // an x window: four trips = 4096 k
-    constexpr int XV = WK / 8 / NT;                          // 16-byte vectors per thread, row and window (2)
+    constexpr int WK = WT * 1024;                            // an x window: WT trips = 4096 columns; 16384 for the plain GEMV of long rows
+                                                             // (K = 14336 is then ONE window, no barrier in the stream: down 22.5 -> 21.7 us at one row, 25.1 -> 23.3 at four)
+    constexpr int XV = WK / 8 / NT;                          // 16-byte vectors per thread, row and window (2; 8)
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // [1 or 2 windows][MR][wk] bf16 x rows as the dot products take them
     __shared__ float red[MR][NT / 64];
     __shared__ float rstd_s[MR];
@@ -601,9 +602,8 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     uint32_t wo[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wo[r] = (uint32_t)min(rows[r], a.N - 1) * (uint32_t)a.ldw * 2u;
-    // this thread's vectors v = t + 256 i of window w of the x rows (and of the norm weight); beyond K: zeros, no memory access.  Behind the
-    // first window the rows are staged in HS parts
-    constexpr int HS = 1, MP = MR / HS;                      // (parts per window: an eight-row form staged two rows per trip to stay under 256 registers)
+    // this thread's vectors v = t + 256 i of window w of the x rows (and of the norm weight); beyond K: zeros, no memory access
+    constexpr int MP = MR;
     u32x4 xr[MR][XV], nr[XV];
     auto stage_load = [&](int w, int m0, int m1) {
 #pragma unroll
@@ -752,27 +752,28 @@ __global__ __launch_bounds__(NT) void gemv_deep_kernel(GemvMfmaArgs g) {
     };
     static_assert(WT % NB == 0, "the ring position of a trip must not depend on the window");
     for (int win = 0; win < nwin; ++win) {
-#pragma unroll
-        for (int j = 0; j < WT; ++j) {
-            if constexpr (WINDOWS) {                         // (K <= 4096: one window, and no staging registers live across the stream)
-                if (j % (WT / HS) == 0) {                    // part j / (WT / HS) of the NEXT window (behind the last: out of range, no access)
-                    stage_load(win + 1, j / (WT / HS) * MP, (j / (WT / HS) + 1) * MP);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            consume(wb[j % NB], win, j);
-            // (the sums are pure arithmetic: without this pin hipcc sinks them below the loads of the whole window -- and below the barrier --,
-            // renaming the ring into 256 registers; the empty statement keeps "consume trip t, then refill its registers")
-#pragma unroll
-            for (int m = 0; m < MR; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]), "+v"(acc[m][2]), "+v"(acc[m][3]) : : "memory");
+        const int nt = min(WT, ntrip - win * WT);            // trips of this window
+        if constexpr (WINDOWS) {                             // (a row that fits one window: no staging registers live across the stream)
+            stage_load(win + 1, 0, MR);                      // the NEXT window (behind the last: out of range, no access) lands while this one is consumed
             __builtin_amdgcn_sched_barrier(0);
-            issue(wb[j % NB], win * WT + j + NB);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (WINDOWS) {                         // into the OTHER buffer: everyone left it at the barrier before this window
-                if (j % (WT / HS) == WT / HS - 1) stage_store(win + 1, j / (WT / HS) * MP, (j / (WT / HS) + 1) * MP);
+        }
+        for (int j0 = 0; j0 < nt; j0 += NB) {
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) {
+                consume(wb[jj], win, j0 + jj);               // (a trip behind the end is all zeros)
+                // (the sums are pure arithmetic: without this pin hipcc sinks them below the loads that follow, renaming the ring into 256
+                // registers; the empty statement keeps "consume trip t, then refill its registers")
+#pragma unroll
+                for (int m = 0; m < MR; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]), "+v"(acc[m][2]), "+v"(acc[m][3]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                issue(wb[jj], win * WT + j0 + jj + NB);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (WINDOWS) __syncthreads();
+        if constexpr (WINDOWS) {                             // into the OTHER buffer: everyone left it at the barrier before this window
+            stage_store(win + 1, 0, MR);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -849,9 +850,15 @@ int launch_gemv_deep(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_t s
     const unsigned grid = (unsigned)((units + NT / 64 - 1) / (NT / 64));
     const int ntrip = (g.f.K + 1023) >> 10;
     const int mr = g.f.M == 1 ? 1 : (g.f.M == 2 ? 2 : 4);
-    const int lds = (ntrip > 4 ? 2 : 1) * mr * (ntrip < 4 ? ntrip : 4) * 1024 * 2;       // <= 64 KiB (four rows, two windows)
-#define GD4(MR, PN, WN) hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, WN>), dim3(grid), dim3(NT), lds, s, g)
-#define GD3(MR, PN) do { if (ntrip > 4) GD4(MR, PN, true); else GD4(MR, PN, false); } while (0)
+    const int wt = (MODE == 0 && !prenorm && ntrip > 4 && ntrip <= 16) ? 16 : 4;   // trips per x window (gemv_deep_kernel: WT)
+    const int lds = (ntrip > wt ? 2 : 1) * mr * (ntrip < wt ? ntrip : wt) * 1024 * 2;    // <= 64 KiB unless two rows are longer than 16384 columns
+#define GD4(MR, PN, WN) do { if (lds > 65536) { static std::atomic<uint64_t> ok{0};                                                            \
+            if (mm_ensure_dynamic_lds((const void*)gemv_deep_kernel<MR, MODE, PN, WN>, 128 * 1024, ok) != MM355_OK) return MM355_ELAUNCH; }     \
+        hipLaunchKernelGGL((gemv_deep_kernel<MR, MODE, PN, WN>), dim3(grid), dim3(NT), lds, s, g); } while (0)
+#define GD3(MR, PN) do { if (wt == 16) { if constexpr (MODE == 0 && !PN) { static std::atomic<uint64_t> ok16{0};                               \
+            if (mm_ensure_dynamic_lds((const void*)gemv_deep_kernel<MR, 0, false, false, 16>, 128 * 1024, ok16) != MM355_OK) return MM355_ELAUNCH; \
+            hipLaunchKernelGGL((gemv_deep_kernel<MR, 0, false, false, 16>), dim3(grid), dim3(NT), lds, s, g); } }                               \
+        else if (ntrip > wt) GD4(MR, PN, true); else GD4(MR, PN, false); } while (0)
 #define GD(MR) do { if (prenorm) { if constexpr (MODE != 0) GD3(MR, true); } else GD3(MR, false); } while (0)
     if (mr == 1) GD(1);
     else if (mr == 2) GD(2);
