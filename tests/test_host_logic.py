@@ -824,6 +824,34 @@ def test_batched_gemv_lds_relayout_is_conflict_free():
             assert len({(rd[l] >> 4) & 15 for l in g}) == 16, ("read", u)
 
 
+def test_decode_gemv_window_addressing():
+    """csrc/decode.hip, gemv_deep_kernel: the x rows sit in LDS in windows of WT trips (a trip = 1024 columns = two 512-column chunks, a
+    lane takes 8 columns of a chunk).  Restated: for every K the trips of all windows cover every column below K exactly once, the LDS
+    column a lane reads for trip j of window `win` is the global column minus the window's first column, lies inside the window row
+    (`wk` columns), and the clamp that keeps the reads of a trip BEHIND the end inside the row never moves a valid read."""
+    for WT in (4, 16):
+        for K in (8, 64, 512, 1032, 1152, 4096, 4104, 5120, 8192, 12288, 14336, 16384, 16392, 16896, 40000):
+            ntrip = (K + 1023) // 1024
+            nwin = (ntrip + WT - 1) // WT
+            wk = min(ntrip, WT) * 1024
+            seen = set()
+            for win in range(nwin):
+                nt = min(WT, ntrip - win * WT)
+                for j0 in range(0, nt, 2):                       # the ring holds two trips: pairs, the second may lie behind the end
+                    for j in (j0, j0 + 1):
+                        t = win * WT + j
+                        for ch in range(2):
+                            for lane in (0, 1, 31, 63):
+                                k = (t * 2 + ch) * 512 + lane * 8
+                                col = min((j * 2 + ch) * 512, wk - 512) + lane * 8
+                                assert 0 <= col and col + 8 <= wk, (WT, K, win, j, ch, lane)
+                                if k < K:
+                                    assert col == k - win * WT * 1024, (WT, K, win, j, ch, lane)
+                                    if lane == 0:
+                                        seen.add(k // 512)
+            assert seen == set(range((K + 511) // 512)), (WT, K)
+
+
 def test_batched_gemv_x_window_protocol():
     """csrc/decode.hip, gemv_mfma_kernel<.., XK>: the x rows of block b live in LDS buffer b & 1.  Program order of every wave, restated:
     store blocks 0, 1; barrier; then per pair (bk, bk + 1): read buffer 0 (block bk); barrier; store block bk + 2 into buffer 0; read
