@@ -14,8 +14,8 @@
  *   - 16-byte aligned base pointers and leading dimensions that are multiples of 8 elements;
  *   - asynchronous on `stream` (a hipStream_t passed as void*);
  *   - returns 0 or a negative MM355_E* code; never throws, never exits;
- *   - re-entrant; the only process-wide state is one-time kernel attribute setup (LDS size caps) and read-once tuning
- *     environment variables (MM355_*), nothing that depends on the call sequence.
+ *   - re-entrant; the only process-wide state is one-time kernel attribute setup (LDS size caps) -- no environment variable is read,
+ *     nothing depends on the call sequence.
  */
 #ifndef MM355_H
 #define MM355_H
@@ -181,6 +181,13 @@ int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, const mm355_b
  * (backward).  Position of row (b,l) is l.
  * ------------------------------------------------------------------------------------------------ */
 int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, float theta, void* stream);
+/* Tables of a SCALED RoPE (config.rope_scaling / rope_parameters -- LLaMA-3.1's rope_type "llama3", "linear"; reference: MetaMorphConfig
+ * inherits the field from LlamaConfig, metamorph_llama.py:129-133, and HF's LlamaRotaryEmbedding, reached at :349-359, rescales inv_freq
+ * per wavelength band once at construction): inv_freq = float[d/2] on the DEVICE, computed by the caller exactly as
+ * ROPE_INIT_FUNCTIONS[rope_type] does; table[l][j] = table[l][d/2 + j] = bf16(cos|sin(l * inv_freq[j]) * attention_scaling).  Every
+ * consumer of the tables (mm355_rope_qk*, mm355_gemm_rope_bf16, the attention backward epilogues, the decode kernels) is unchanged. */
+int mm355_rope_table_freq(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, const float* inv_freq, float attention_scaling,
+                          void* stream);
 int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d,
                   const mm355_bf16* cos_t, const mm355_bf16* sin_t, int inverse, void* stream);
 /* the same with a per-sample position offset (int32[B], device): position of row (b,l) is l + pos_offset[b]; the tables need

@@ -28,6 +28,20 @@ __global__ void rope_table_kernel(uint16_t* __restrict__ cos_o, uint16_t* __rest
     }
 }
 
+// The same tables from per-band inverse frequencies the HOST computed (scaled RoPE variants: HF ROPE_INIT_FUNCTIONS rescale inv_freq per
+// wavelength band once at construction; LlamaRotaryEmbedding.forward is then cos / sin(position * inv_freq) * attention_scaling -> bf16).
+__global__ void rope_table_freq_kernel(uint16_t* __restrict__ cos_o, uint16_t* __restrict__ sin_o, int L, int d,
+                                       const float* __restrict__ inv_freq, float scaling) {
+    const int half = d >> 1;
+    for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < (int64_t)L * half; i += (int64_t)gridDim.x * NT) {
+        const int l = (int)(i / half), j = (int)(i % half);
+        const float ang = (float)l * inv_freq[j];
+        const uint16_t c = f2bf(cosf(ang) * scaling), s = f2bf(sinf(ang) * scaling);
+        cos_o[(int64_t)l * d + j] = c; cos_o[(int64_t)l * d + half + j] = c;
+        sin_o[(int64_t)l * d + j] = s; sin_o[(int64_t)l * d + half + j] = s;
+    }
+}
+
 // In-place rotation of the q and k column blocks of a fused qkv activation.  One thread handles 8
 // consecutive elements of the first half of a head together with their partners in the second half.
 // forward : y1 = bf(bf(x1*c) + bf(-x2*s)),  y2 = bf(bf(x2*c) + bf(x1*s))     (HF rounding order)
@@ -351,6 +365,12 @@ extern "C" int mm355_rope_table(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!cos_out || !sin_out || L <= 0 || d <= 0 || (d & 1)) return MM355_EINVAL;
     LAUNCH(rope_table_kernel, grid_for(L * d / 2), cos_out, sin_out, (int)L, (int)d, theta);
+}
+extern "C" int mm355_rope_table_freq(mm355_bf16* cos_out, mm355_bf16* sin_out, int64_t L, int64_t d, const float* inv_freq,
+                                     float attention_scaling, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!cos_out || !sin_out || !inv_freq || L <= 0 || d <= 0 || (d & 1)) return MM355_EINVAL;
+    LAUNCH(rope_table_freq_kernel, grid_for(L * d / 2), cos_out, sin_out, (int)L, (int)d, inv_freq, attention_scaling);
 }
 extern "C" int mm355_rope_qk(mm355_bf16* qkv, int64_t ld, int64_t B, int64_t L, int64_t Hq, int64_t Hkv, int64_t d, const mm355_bf16* cos_t,
                              const mm355_bf16* sin_t, int inverse, void* stream) {

@@ -17,7 +17,9 @@ def build_model(llm: dict, vision_geometry: dict | None = None, *, num_image_tok
                 padding_side="right", image_start_id=None, image_token_reduction="interpolation", state_dict=None, device=None,
                 dtype=torch.bfloat16, init_on_device=False):
     llm = dict(llm)
-    cfg = MetaMorphConfig(max_position_embeddings=8192, attention_bias=False, tie_word_embeddings=False, **llm)
+    llm.setdefault("max_position_embeddings", 8192)
+    llm.setdefault("tie_word_embeddings", False)
+    cfg = MetaMorphConfig(attention_bias=False, **llm)
     cfg.mm_vision_tower = "siglip/CLIP-ViT-SO400M-14-384"
     cfg.mm_projector_type = mm_projector_type
     cfg.mm_hidden_size = (vision_geometry or {}).get("hidden_size", 1152) * (4 if image_token_reduction == "concat_interpolation" else 1)

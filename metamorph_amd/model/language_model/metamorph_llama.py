@@ -31,6 +31,7 @@ from ... import ops
 from ...constants import DEFAULT_IMAGE_END_ID, DEFAULT_IMAGE_START_ID, IGNORE_INDEX
 from ...splice_plan import SplicePlan
 from ...hostmirror import host_array
+from ...rope import head_dim as _head_dim, rope_params
 from ..metamorph_arch import MetaMorphMetaForCausalLM, MetaMorphMetaModel, upload_plan
 from ..modules import HipEmbedding, HipGELU, HipLinear, HipRMSNorm
 
@@ -39,17 +40,6 @@ BF16 = torch.bfloat16
 
 class MetaMorphConfig(LlamaConfig):
     model_type = "metamorph_llama"
-
-
-def _rope_theta(config):
-    rp = getattr(config, "rope_parameters", None)
-    if isinstance(rp, dict) and "rope_theta" in rp:
-        if rp.get("rope_type", "default") != "default":
-            raise NotImplementedError(f"rope_type={rp.get('rope_type')!r}: only the default RoPE has a HIP kernel")
-        return float(rp["rope_theta"])
-    if getattr(config, "rope_scaling", None):
-        raise NotImplementedError("rope_scaling: only the default RoPE has a HIP kernel")
-    return float(getattr(config, "rope_theta", 10000.0))
 
 
 def _left_pad_maps(seqlens, B, L):
@@ -68,7 +58,7 @@ def _left_pad_maps(seqlens, B, L):
 class _Attention(nn.Module):
     def __init__(self, config):
         super().__init__()
-        h, d = config.hidden_size, config.hidden_size // config.num_attention_heads
+        h, d = config.hidden_size, _head_dim(config)
         self.q_proj = HipLinear(h, config.num_attention_heads * d, bias=False)
         self.k_proj = HipLinear(h, config.num_key_value_heads * d, bias=False)
         self.v_proj = HipLinear(h, config.num_key_value_heads * d, bias=False)
@@ -175,6 +165,7 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         self.layers = nn.ModuleList([_DecoderLayer(config) for _ in range(config.num_hidden_layers)])
         self.norm = HipRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._init_vision(config, vision_delay_load=vision_delay_load)
+        self.rope = rope_params(config)         # refuses the RoPE variants without a kernel path at construction, by name
         self._rope = None
         # set by PreTrainedModel.gradient_checkpointing_enable() (HF looks for this attribute on the sub-modules): per-layer
         # recompute in DecoderLayerFn / SiglipLayerFn instead of torch.utils.checkpoint
@@ -189,11 +180,11 @@ class MetaMorphLlamaModel(MetaMorphMetaModel, nn.Module):
         self.layer_output_hook = None
 
     def rope_tables(self, L, device):
-        d = self.config.hidden_size // self.config.num_attention_heads
-        key = (L, str(device))
+        """cos / sin [>= L, head_dim] bf16 of the config's RoPE variant (metamorph_amd.rope: default, llama3, linear)."""
         if self._rope is None or self._rope[0][0] < L or self._rope[0][1] != str(device):
             Lc = max(L, 256)
-            cos, sin = ops.rope_table(Lc, d, _rope_theta(self.config), device)
+            rp = self.rope
+            cos, sin = ops.rope_table_freq(Lc, rp.head_dim, rp.inv_freq, rp.attention_scaling, device)
             self._rope = ((Lc, str(device)), cos, sin)
         return self._rope[1], self._rope[2]
 
@@ -205,6 +196,10 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
     accepts_loss_kwargs = False                 # like the reference's forward(): no `num_items_in_batch` normalisation inside the model
     _no_split_modules = ["_DecoderLayer"]
     _keys_to_ignore_on_load_unexpected = [r"model\.vision_tower\.vision_tower\.head\..*", r".*rotary_emb\.inv_freq"]
+    # config.tie_word_embeddings (LLaMA-3.2 1B / 3B bases): lm_head.weight IS model.embed_tokens.weight, as in HF's LlamaForCausalLM the
+    # reference subclasses (metamorph_llama.py:223); post_init() / from_pretrained tie them through this mapping.  One Parameter, one
+    # gradient buffer: the fused CE's weight gradient and the splice's embedding-row sums accumulate into it (functional.grad_target).
+    _tied_weights_keys = {"lm_head.weight": "model.embed_tokens.weight"}
 
     def __init__(self, config, use_vision_ar=True, vision_head="None", vision_coef=1.0, normalize_vision=False,
                  apply_softmax=False, vision_delay_load=True, full_ar=False):
@@ -267,7 +262,11 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
     def resize_token_embeddings(self, new_num_tokens=None, pad_to_multiple_of=None, mean_resizing=True):
         if new_num_tokens is None or new_num_tokens == self.config.vocab_size:
             return self.get_input_embeddings()
+        tied = self.lm_head.weight is self.model.embed_tokens.weight
         for mod in (self.model.embed_tokens, self.lm_head):
+            if tied and mod is self.lm_head:
+                mod.weight = self.model.embed_tokens.weight          # stays ONE parameter
+                break
             old = mod.weight.data
             new = torch.empty((new_num_tokens, old.shape[1]), device=old.device, dtype=old.dtype)
             nn.init.normal_(new, std=getattr(self.config, "initializer_range", 0.02))
@@ -359,7 +358,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
                 if rows.size > 1 and not (np.diff(pid[b, rows]) == 1).all():
                     raise NotImplementedError("position_ids must advance by one over each sample's valid rows (custom positions are not supported)")
         Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
-        d = h // Hq
+        d = _head_dim(cfg)
         # Left padding (tokenizer_padding_side = "left", reference metamorph_arch.py:362-386): the attention kernels take per-sample
         # lengths counted from row 0, so the batch is moved to the right-padded row layout for the decoder and back afterwards; the
         # RoPE position of a moved row stays its ORIGINAL row index (HF: position_ids = arange(L), padding included), which the
@@ -552,7 +551,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
     def _decode_meta(self, L):
         cfg = self.config
         h, Hq, Hkv = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads
-        return h, F.LayerMeta(1, L, Hq, Hkv, h // Hq, cfg.intermediate_size, cfg.rms_norm_eps, None, None, None)
+        return h, F.LayerMeta(1, L, Hq, Hkv, _head_dim(cfg), cfg.intermediate_size, cfg.rms_norm_eps, None, None, None)
 
     @torch.no_grad()
     def _head_row(self, x, in_image_mode):

@@ -359,6 +359,18 @@ def rope_table(L, d, theta, device):
     return cos, sin
 
 
+def rope_table_freq(L, d, inv_freq, attention_scaling, device):
+    """cos / sin [L, d] bf16 from host-computed inverse frequencies (float32 [d/2]: numpy array or tensor) -- metamorph_amd.rope."""
+    inv = torch.as_tensor(inv_freq, dtype=torch.float32).reshape(-1).to(device)
+    assert inv.numel() * 2 == d, (inv.numel(), d)
+    cos = torch.empty((L, d), device=device, dtype=BF16)
+    sin = torch.empty((L, d), device=device, dtype=BF16)
+    _chk_dev(cos, inv)
+    _lib.check(_L().mm355_rope_table_freq(cos.data_ptr(), sin.data_ptr(), L, d, inv.data_ptr(), float(attention_scaling), _stream()),
+               "mm355_rope_table_freq")
+    return cos, sin
+
+
 def rope_qk_(qkv, B, L, Hq, Hkv, d, cos, sin, inverse=False, pos_offset=None):
     """In place on the q (first Hq*d columns) and k (next Hkv*d columns) blocks of qkv [B*L, ld]; pos_offset (int32 [B], device):
     position of row (b, l) is l + pos_offset[b] (the caller guarantees the tables are long enough)."""

@@ -91,8 +91,10 @@ def build_reference(cfg: OracleConfig, sd, dtype, **ctor):
     hf = MetaMorphConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                          num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                          num_key_value_heads=cfg.num_key_value_heads, vocab_size=cfg.vocab_size,
-                         max_position_embeddings=8192, rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps,
-                         attention_bias=False, tie_word_embeddings=False)
+                         max_position_embeddings=cfg.max_position_embeddings, rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps,
+                         attention_bias=False, tie_word_embeddings=cfg.tie_word_embeddings,
+                         **({"rope_scaling": dict(cfg.rope_scaling)} if cfg.rope_scaling else {}),
+                         **({"head_dim": cfg.head_dim_explicit} if cfg.head_dim_explicit else {}))
     hf.mm_vision_tower = "siglip/CLIP-ViT-SO400M-14-384"
     hf.mm_projector_type = cfg.mm_projector_type
     hf.mm_hidden_size = cfg.v_hidden * (4 if cfg.image_token_reduction == "concat_interpolation" else 1)
@@ -509,6 +511,8 @@ def grad_summary(t):
     return torch.cat([f.norm()[None], f[idx]])
 
 
+ROPE31 = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+ROPE31_TINY = dict(ROPE31, original_max_position_embeddings=32)
 E2E_CASES = [
     # (kind, T, use_vision_ar, head variant): "cos" = normalize_vision (every shipped recipe); "l1" = the constructor default
     # (mean-abs `mse_loss_fn`); "softce" = apply_softmax on normalised features; "softce_raw" = apply_softmax alone
@@ -534,13 +538,26 @@ E2E_CASES = [
     ("multi_frame", 4, True, "cos", "right", {"num_hidden_layers": 8, "v_layers": 4, "num_attention_heads": 4}),
     # the 'identity' connector (builder.py:60-61) needs an LLM as wide as the tower: h = 1152 = 9 heads x 128 over 3 KV heads
     ("mixed", 4, True, "cos", "right", {"mm_projector_type": "identity", "hidden_size": 1152, "num_attention_heads": 9, "num_key_value_heads": 3}),
+    # round 6: the config fields a real base checkpoint carries.  LLaMA-3.1's RoPE (rope_type "llama3": the reference README's own base
+    # model, README.md:178,187; inherited through MetaMorphConfig(LlamaConfig), metamorph_llama.py:129-133) with the pre-training context
+    # shrunk to 32 positions so that all three wavelength bands (kept < 8, blended 8..32, stretched > 32) act within these 12..21-row
+    # samples (d = 128: bands 0-1 kept, 2-7 blended, 8-63 stretched); the real 3.1 constants at L = 4096 are gen_rope31's long case
+    ("mixed", 4, True, "cos", "right", {"rope_scaling": ROPE31_TINY, "max_position_embeddings": 256}, "_rope-llama3"),
+    ("multi_frame", 4, True, "cos", "left", {"rope_scaling": ROPE31_TINY, "max_position_embeddings": 256}, "_left_rope-llama3"),
+    ("mixed", 4, True, "cos", "right", {"rope_scaling": {"rope_type": "linear", "factor": 4.0}}, "_rope-linear"),
+    ("mixed", 4, True, "cos", "right", {"tie_word_embeddings": True}, "_tied"),              # lm_head.weight IS embed_tokens.weight (LLaMA-3.2 1B / 3B)
+    # explicit head_dim != hidden_size / heads: 2 heads x 64 over a 256-wide model (q_proj [128, 256], o_proj [256, 128])
+    ("mixed", 4, True, "cos", "right", {"head_dim_explicit": 64}, "_headdim64"),
 ]
 HEAD_VARIANTS = {"cos": (True, False), "l1": (False, False), "softce": (True, True), "softce_raw": (False, True)}
 
 
-def gen_e2e():
+def gen_e2e(first=0):
     shared = np.random.default_rng(41)               # the first five cases draw their images from ONE stream, in this order
     for i, case in enumerate(E2E_CASES):
+        if i < first:                                # (`first` > 5 only: the shared stream is consumed in order)
+            assert first > 5
+            continue
         kind, T, use_ar, variant = case[:4]
         side = case[4] if len(case) > 4 else "right"
         extra = case[5] if len(case) > 5 else {}
@@ -557,8 +574,11 @@ def gen_e2e():
         images = torch.from_numpy(rng.standard_normal((n_img, 3, 56, 56), dtype=np.float32))
         suffix = ("" if variant == "cos" else "_" + variant) + ("" if side == "right" else "_" + side) + "".join(
             "_" + ("head-" if k == "vision_head_type" else "coef" if k == "vision_coef" else "") + str(v) for k, v in extra.items())
-        structural = {k: v for k, v in extra.items() if k in ("num_hidden_layers", "v_layers", "num_attention_heads", "num_key_value_heads", "hidden_size")}
-        if "num_hidden_layers" in structural:
+        structural = {k: v for k, v in extra.items() if k in ("num_hidden_layers", "v_layers", "num_attention_heads", "num_key_value_heads", "hidden_size",
+                                                              "rope_scaling", "max_position_embeddings", "tie_word_embeddings", "head_dim_explicit")}
+        if len(case) > 6:
+            suffix = case[6]
+        elif "num_hidden_layers" in structural:
             suffix = f"_deep{extra['num_hidden_layers']}"
         elif structural:
             suffix = "_" + str(extra["mm_projector_type"])
@@ -755,7 +775,10 @@ def decode_lm_head(sd, rows):
     return W
 
 
-def gen_decode():
+DECODE_SEEDS = {"image_prompt_rope31": 64}   # (seed 63 leaves the last decision a 1.7-logit margin: below the 2.0 bar)
+
+
+def gen_decode(only=None):
     """Runs the reference's `generate` -> `greedy_decode` (metamorph_llama.py:502-597, 665-717; image-mode feedback :363-377)
     unchanged on a tiny random model and records the emitted token ids, the per-step top-2 logit margins and the predicted visual
     embeddings (`pred_z`).  The weights are the seeded ones except for lm_head (see decode_lm_head): the rows of the tokens the
@@ -765,13 +788,19 @@ def gen_decode():
     (The hidden row of step k depends only on the tokens emitted before k, never on lm_head, so the construction converges by
     extending the correct prefix one step per pass.)"""
     A = 128000
-    cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1)}
+    # round 6: the same walk under LLaMA-3.1's RoPE (ROPE31_TINY: all three wavelength bands act within these ~20 positions) -- prompt pass and
+    # every cached step read the scaled tables
+    rope31 = {"rope_scaling": ROPE31_TINY, "max_position_embeddings": 256}
+    cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0, {}), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1, {}),
+             "image_prompt_rope31": ([[A, A, 11, ST, IM, EN, 12, 13]], 1, rope31)}
     plan = [(0, ST), (5, EN), (6, 41), (7, 42), (8, 128009)]     # (loop iteration, token it must emit); iterations 1-4 = image mode
     image_steps = [1, 2, 3, 4]
-    for ci, (name, (ids, n_img)) in enumerate(cases.items()):
+    for ci, (name, (ids, n_img, extra)) in enumerate(cases.items()):
+        if only is not None and name not in only:
+            continue
         ids_t = torch.tensor(ids)
-        seed = 61 + ci
-        cfg = tiny_cfg(num_image_tokens=4)
+        seed = DECODE_SEEDS.get(name, 61 + ci)
+        cfg = tiny_cfg(num_image_tokens=4, **extra)
         sd = init_state_dict(cfg, seed=seed)
         images = None
         if n_img:
@@ -848,7 +877,8 @@ def gen_decode():
                  step_argmax=np.array([int(t.indices[0]) for t in top2], dtype=np.int64),
                  active_logits=torch.stack([l[DECODE_ACTIVE] for l in logits]),
                  active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]),
-                 pred_z=emb, pred_z_bf16=emb16, max_new_tokens=np.int64(12), **cut)
+                 pred_z=emb, pred_z_bf16=emb16, max_new_tokens=np.int64(12), **cut,
+                 **({"cfg_json": np.array(json.dumps(extra))} if extra else {}))
         print(f"    {name}: seed {seed} tokens {toks} min decision margin {float(margins[decision].min()):.3f} "
               f"pred_z bf16-vs-f32 rel {float((emb16 - emb).norm() / emb.norm()):.3e}")
 
@@ -1025,19 +1055,23 @@ def gen_r3():
             print(f"    {kind} {tag}: loss {float(outp.loss):.6f} lang {model.loss_language:.6f} img {model.loss_image_ar:.6f}")
 
 
-def gen_hfgen():
+def gen_hfgen(only=None):
     """Row "HF generate": the reference's `generate(use_customize_greedy=False)` (metamorph_llama.py:711-717) -> transformers
     GenerationMixin driving the reference's forward with a KV cache.  Weights as in gen_decode (sparse lm_head whose planned rows are
     solved on the hidden rows the reference itself produces, so every decision has a margin far above bf16 noise); recorded: the
     greedy ids, and a SAMPLING run (do_sample, temperature 0.7, top_p 0.9) -- the planned token holds > 0.9 of the probability mass at
     every step, so the nucleus is that one token and the sampled ids are seed-independent (checked with three seeds); and a beam search (num_beams = 2, both hypotheses returned with their scores)."""
     A = 128000
-    cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1)}
+    rope31 = {"rope_scaling": ROPE31_TINY, "max_position_embeddings": 256}      # round 6: HF generate + KV cache under LLaMA-3.1's RoPE
+    cases = {"text": ([[A, A, 11, 12, 13, 14, 15]], 0, {}), "image_prompt": ([[A, A, 11, ST, IM, EN, 12, 13]], 1, {}),
+             "text_rope31": ([[A, A, 11, 12, 13, 14, 15]], 0, rope31)}
     plan = [(0, 41), (1, 42), (2, ST), (3, 43), (4, 44), (5, 128009)]      # HF path: <image_start> is an ordinary token, no image mode
-    for ci, (name, (ids, n_img)) in enumerate(cases.items()):
+    for ci, (name, (ids, n_img, extra)) in enumerate(cases.items()):
+        if only is not None and name not in only:
+            continue
         ids_t = torch.tensor(ids)
         seed = 71 + ci
-        cfg = tiny_cfg(num_image_tokens=4)
+        cfg = tiny_cfg(num_image_tokens=4, **extra)
         sd = init_state_dict(cfg, seed=seed)
         images = None
         if n_img:
@@ -1132,7 +1166,8 @@ def gen_hfgen():
                  row_values=torch.stack(list(rows.values())), tokens=np.array(toks, dtype=np.int64), margins=margins,
                  top_prob_at_T07=probs, sampled_tokens=np.array(sampled[0], dtype=np.int64),
                  active_logits=torch.stack([l[DECODE_ACTIVE] for l in logits]),
-                 active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]), max_new_tokens=np.int64(10), **batch)
+                 active_logits_bf16=torch.stack([l[DECODE_ACTIVE] for l in logits16]), max_new_tokens=np.int64(10), **batch,
+                 **({"cfg_json": np.array(json.dumps(extra))} if extra else {}))
         print(f"    {name}: seed {seed} tokens {toks} min margin {float(margins.min()):.2f} min top prob at T=0.7 {float(probs.min()):.4f}")
 
 
@@ -1324,11 +1359,112 @@ def gen_optgroups():
         print("   ", c["train_tower"], c["mm_projector_lr"], c["vision_lr"], [(g["weight_decay"], g["lr"], len(g["names"])) for g in c["groups"]])
 
 
+# ----------------------------------------------------------------------------- round 6: LLaMA-3.1 RoPE (rope_type "llama3")
+
+ROPE_TABLE_CASES = {
+    # name: (head_dim, theta, rope_scaling, max_position_embeddings)
+    "llama31_8b": (128, 500000.0, ROPE31, 131072),                                  # meta-llama/Llama-3.1-8B config.json
+    "llama32_1b": (64, 500000.0, dict(ROPE31, factor=32.0), 131072),               # Llama-3.2-1B: d = 64, factor 32
+    "tiny_ctx32": (128, 500000.0, ROPE31_TINY, 256),                                # the e2e / decode fixtures' shrunk context
+    "linear4": (128, 500000.0, {"rope_type": "linear", "factor": 4.0}, 8192),
+    "default": (128, 500000.0, None, 8192),
+}
+
+
+def gen_rope31():
+    """(a) r6_rope_tables.npz: the `inv_freq` buffer and cos / sin rows HF's own LlamaRotaryEmbedding -- the module the reference's decoder
+    runs (metamorph_llama.py:349-359) -- produces for LLaMA-3.1 / 3.2 / linear / default configs, at positions up to 4095.
+    (b) r6_rope31_long_{f32,bf16}.npz: the reference's forward + backward on ONE 4096-row sample (image + text) under the REAL LLaMA-3.1
+    constants, where the stretched bands turn by up to ~pi less than the default RoPE's: loss, every 16th hidden row, gradient summaries --
+    plus how far the same weights land under the default RoPE (the fixture's discriminating power)."""
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    pos = torch.tensor(sorted(set(list(range(0, 4096, 41)) + [1, 2, 3, 31, 32, 33, 2047, 2048, 4095])))
+    rec = {"positions": pos}
+    for name, (d, theta, rs, mp) in ROPE_TABLE_CASES.items():
+        c = LlamaConfig(hidden_size=d * 2, num_attention_heads=2, rope_theta=theta, max_position_embeddings=mp, **({"rope_scaling": dict(rs)} if rs else {}))
+        emb = LlamaRotaryEmbedding(c)
+        rec[f"{name}::inv_freq"] = emb.inv_freq.clone()
+        rec[f"{name}::attention_scaling"] = np.float64(emb.attention_scaling)
+        rec[f"{name}::cfg"] = np.array(json.dumps(dict(head_dim=d, rope_theta=theta, rope_scaling=rs, max_position_embeddings=mp)))
+        for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            cos, sin = emb(torch.zeros(1, 1, dtype=dt), pos[None])
+            rec[f"{name}::cos_{tag}"], rec[f"{name}::sin_{tag}"] = cos[0], sin[0]
+    save_npz("r6_rope_tables.npz", **rec)
+
+    L, T = 4096, 4
+    extra = {"rope_scaling": ROPE31, "max_position_embeddings": 131072}
+    cfg = tiny_cfg(num_image_tokens=T, tokenizer_model_max_length=L, **extra)
+    sd = init_state_dict(cfg, seed=67)
+    # N(0, 0.02) projections give attention logits of std ~0.1: softmax is then flat over 4096 keys and NO positional encoding matters.
+    # q_proj / k_proj x 5.5 puts the logits at std ~3, so which keys a query favours depends on the rotation
+    QK_GAIN = 5.5
+    for k in sd:
+        if k.endswith("q_proj.weight") or k.endswith("k_proj.weight"):
+            if "vision_tower" not in k:
+                sd[k] = sd[k] * QK_GAIN
+    rng = np.random.default_rng(6700)
+    n_text = L - (T + 2) - 3
+    text = rng.integers(0, 127999, size=n_text).tolist()
+    ids = [[128000, 128000] + text + [ST, IM, EN, 128009]]                         # spliced length = 2 + n_text + 2 + T + 1 = L: an ANSWER image at the far end
+    lab = [[-100] * len(ids[0])]
+    for j in list(range(300, 364)) + list(range(len(ids[0]) - 64, len(ids[0]))):  # 64 live targets early, 64 at the far end (incl. the image span)
+        lab[0][j] = ids[0][j]
+    ids_t, lab_t = torch.tensor(ids), torch.tensor(lab)
+    msk_t = torch.ones_like(ids_t, dtype=torch.bool)
+    images = torch.from_numpy(rng.standard_normal((1, 3, 56, 56), dtype=np.float32))
+    rows = torch.arange(0, L, 16)
+    hid_default = None
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        model = build_reference(cfg, sd, dt)
+        for n, p in model.named_parameters():
+            p.requires_grad_("vision_tower" not in n)
+        out = model(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images.to(dt))
+        assert out.hidden_states.shape[1] == L, out.hidden_states.shape
+        rec = dict(input_ids=ids_t, labels=lab_t, attention_mask=msk_t, images=images, seed=np.int64(67), rows_per_image=np.int64(T),
+                   cfg_json=np.array(json.dumps(dict(extra, tokenizer_model_max_length=L))), hidden_rows=rows, qk_gain=np.float64(QK_GAIN),
+                   loss=out.loss.detach().float(), loss_language=np.float64(model.loss_language), loss_image_ar=np.float64(model.loss_image_ar),
+                   hidden=out.hidden_states[0, rows])
+        out.loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None and "vision_proj" not in n:
+                rec["grad::" + n] = grad_summary(p.grad)
+        if dt == torch.float32:
+            plain = build_reference(tiny_cfg(num_image_tokens=T, tokenizer_model_max_length=L), sd, dt)
+            with torch.no_grad():
+                o2 = plain(input_ids=ids_t, attention_mask=msk_t, labels=lab_t, images=images)
+            h1, h0 = out.hidden_states[0, rows].detach(), o2.hidden_states[0, rows]
+            far = rows >= 2048
+            rec["default_rope_hidden_rel"] = np.float64(float((h0 - h1).norm() / h1.norm()))
+            rec["default_rope_hidden_rel_far"] = np.float64(float((h0[far] - h1[far]).norm() / h1[far].norm()))
+            rec["default_rope_loss"] = o2.loss.detach().float()
+            print(f"    long: loss {float(out.loss):.6f}; under the DEFAULT RoPE the same weights give loss {float(o2.loss):.6f}, hidden rows differ by "
+                  f"{rec['default_rope_hidden_rel']:.3e} (rows >= 2048: {rec['default_rope_hidden_rel_far']:.3e})")
+            assert rec["default_rope_hidden_rel_far"] > 5e-2
+        save_npz(f"r6_rope31_long_{tag}.npz", **rec)
+
+
+def gen_r6():
+    """Everything round 6 added, without re-running the older generators: the new e2e cases, the rope31 decode / HF-generate cases, tables."""
+    first = next(i for i, c in enumerate(E2E_CASES) if len(c) > 6)
+    gen_e2e(first=first)
+    gen_decode(only=("image_prompt_rope31",))
+    gen_hfgen(only=("text_rope31",))
+    gen_rope31()
+
+
+def gen_r6tail():
+    gen_decode(only=("image_prompt_rope31",))
+    gen_hfgen(only=("text_rope31",))
+    gen_rope31()
+
+
+
 if __name__ == "__main__":
     # every generator, in an order that reproduces the committed fixtures bit for bit in ONE process (`optgroups` last: it registers
     # LlamaRMSNorm as a layer-norm type for the rest of the process); ~4 minutes on 8 threads
     ALL = ["a1", "a5", "a5rand", "a3", "a3sel", "ops", "e2e", "n2", "n2rand", "images", "conv", "decode", "names", "n3", "r3", "hfgen", "surface", "textonly",
-           "optgroups"]
+           "rope31", "optgroups"]
     which = sys.argv[1:] or ALL
     for w in which:
         print(f"[gen_golden] {w}")

@@ -37,6 +37,10 @@ class OracleConfig:
     vocab_size: int = 128258
     rms_norm_eps: float = 1e-5
     rope_theta: float = 500000.0
+    rope_scaling: dict | None = None                   # LlamaConfig.rope_scaling: {"rope_type": "llama3" | "linear", ...} (ref_ops.rope_inv_freq)
+    max_position_embeddings: int = 8192
+    head_dim_explicit: int | None = None               # LlamaConfig.head_dim when the checkpoint states it (q_proj is then [Hq * d, h], d != h / Hq)
+    tie_word_embeddings: bool = False                  # lm_head.weight IS model.embed_tokens.weight (LLaMA-3.2 1B / 3B)
     # vision tower (SigLIP geometry; reference hard-codes SO400M/14-384, siglip_encoder.py:113)
     v_hidden: int = 1152
     v_layers: int = 27
@@ -61,7 +65,11 @@ class OracleConfig:
 
     @property
     def head_dim(self):
-        return self.hidden_size // self.num_attention_heads
+        return self.head_dim_explicit or self.hidden_size // self.num_attention_heads
+
+    @property
+    def rope_kw(self):
+        return dict(rope_scaling=self.rope_scaling, max_position_embeddings=self.max_position_embeddings)
 
 
 # ------------------------------------------------------------------ SigLIP tower (A3)
@@ -182,7 +190,7 @@ def llama_decoder(sd, cfg: OracleConfig, x, key_valid, position_ids=None):
     B, L, h = x.shape
     if position_ids is None:
         position_ids = torch.arange(L)[None].expand(B, L)
-    cos, sin = ops.rope_tables(position_ids, cfg.head_dim, cfg.rope_theta, x.dtype)
+    cos, sin = ops.rope_tables(position_ids, cfg.head_dim, cfg.rope_theta, x.dtype, **cfg.rope_kw)
     for i in range(cfg.num_hidden_layers):
         x = llama_layer(sd, cfg, i, x, key_valid, cos, sin)
     return ops.rmsnorm(x, sd["model.norm.weight"], cfg.rms_norm_eps)
@@ -444,6 +452,8 @@ def init_state_dict(cfg: OracleConfig, seed: int, dtype=torch.float32, std: floa
     sd["model.vision_proj.weight"] = rnd(h, 4096)       # dead Linear(4096, h), metamorph_arch.py:31
     sd["model.vision_proj.bias"] = rnd(h)
     sd["lm_head.weight"] = rnd(V, h)
+    if cfg.tie_word_embeddings:                           # one tensor under both names (the draw above keeps the stream of the other keys)
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
     if cfg.vision_head_type == "mlp":
         sd["vision_head.0.weight"] = rnd(h, h); sd["vision_head.0.bias"] = rnd(h)
         sd["vision_head.2.weight"] = rnd(hv, h); sd["vision_head.2.bias"] = rnd(hv)

@@ -30,10 +30,38 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
 # K9  RoPE (rotate-half convention; cos/sin computed in fp32 then cast to model dtype)
 # --------------------------------------------------------------------------------------
 
-def rope_tables(positions: torch.Tensor, head_dim: int, theta: float, dtype: torch.dtype):
+def rope_inv_freq(head_dim: int, theta: float, rope_scaling: dict | None = None, max_position_embeddings: int | None = None):
+    """Inverse frequencies [d/2] fp32 of the RoPE variant a LLaMA config names -- what HF's LlamaRotaryEmbedding (reached from the reference
+    at metamorph_llama.py:349-359 through MetaMorphConfig(LlamaConfig), :129-133) fixes once at construction:
+      default   theta^(-2j/d)
+      linear    the same divided by `factor`
+      llama3    (LLaMA-3.1, the reference README's base model) per wavelength band: longer than ctx/low_freq_factor -> divided by `factor`;
+                shorter than ctx/high_freq_factor -> unchanged; between -> linear blend in ctx/wavelength.  ctx =
+                original_max_position_embeddings.
+    Pinned by tests/golden/r6_rope_tables.npz (HF's own buffers)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    kind = (rope_scaling or {}).get("rope_type") or (rope_scaling or {}).get("type") or "default"
+    if kind == "default":
+        return inv
+    f = float(rope_scaling["factor"])
+    if kind == "linear":
+        return inv / f
+    if kind != "llama3":
+        raise NotImplementedError(kind)
+    lo, hi = float(rope_scaling["low_freq_factor"]), float(rope_scaling["high_freq_factor"])
+    ctx = rope_scaling.get("original_max_position_embeddings") or max_position_embeddings
+    lam = 2 * math.pi / inv                                   # wavelength of every band, in positions
+    long_band, short_band = lam > ctx / lo, lam < ctx / hi
+    stretched = torch.where(long_band, inv / f, inv)
+    t = (ctx / lam - lo) / (hi - lo)                          # 0 at the long edge, 1 at the short edge
+    blended = (1 - t) * stretched / f + t * stretched
+    return torch.where(~short_band & ~long_band, blended, stretched)
+
+
+def rope_tables(positions: torch.Tensor, head_dim: int, theta: float, dtype: torch.dtype, rope_scaling: dict | None = None,
+                max_position_embeddings: int | None = None):
     """positions: int tensor [...]; returns cos, sin of shape [..., head_dim] in `dtype`."""
-    half = torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim
-    inv_freq = 1.0 / (theta ** half)                       # [d/2]
+    inv_freq = rope_inv_freq(head_dim, theta, rope_scaling, max_position_embeddings)     # [d/2]
     ang = positions.to(torch.float32)[..., None] * inv_freq  # [..., d/2]
     emb = torch.cat([ang, ang], dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)

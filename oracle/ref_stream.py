@@ -79,7 +79,7 @@ def full_depth(fetch, cfg: RM.OracleConfig, input_ids, attention_mask, labels, i
         if not bool(key_valid[b, :n_rows[b]].all()):
             raise ValueError("full_depth handles right-padded batches")
     pos = torch.arange(L)[None]
-    cos, sin = ops.rope_tables(pos, cfg.head_dim, cfg.rope_theta, x.dtype)
+    cos, sin = ops.rope_tables(pos, cfg.head_dim, cfg.rope_theta, x.dtype, **cfg.rope_kw)
     xs = [x[b, :n_rows[b]].detach().clone() for b in range(B)]
     inputs = []                                                  # inputs[i][b]: rows entering decoder layer i
     probes = {}

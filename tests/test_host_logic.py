@@ -8,6 +8,7 @@ import os
 import re
 
 import numpy as np
+from types import SimpleNamespace
 import pytest
 import torch
 
@@ -274,6 +275,40 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
         if "vision_tower" not in k:
             assert torch.equal(v, sd2[k]), k
     assert m2.config.num_image_tokens == 4 and m2.config.model_type == "metamorph_llama"
+
+
+def test_llama31_checkpoint_config_round_trips_and_unsupported_fields_are_refused_by_name(tmp_path):
+    """A LLaMA-3.1-shaped config.json (rope_scaling rope_type "llama3" -- the reference README's base model, README.md:178,187 -- plus tied
+    embeddings and an explicit head_dim) constructs, saves and loads back: same RoPE frequencies, lm_head still tied, q_proj sized by head_dim.
+    dynamic / yarn / longrope RoPE, attention_bias and mlp_bias are refused at construction, by name."""
+    from metamorph_amd.factory import build_model
+    from metamorph_amd.model import MetaMorphConfig, MetaMorphLlamaForCausalLM
+    from metamorph_amd.rope import rope_params
+    r31 = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+    llm = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=300,
+               rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=131072, rope_scaling=r31, tie_word_embeddings=True, head_dim=16)
+    geo = dict(num_hidden_layers=1, intermediate_size=144, image_size=28)
+    m = build_model(llm, geo, num_image_tokens=4)
+    assert m.model.rope.rope_type == "llama3" and m.model.rope.head_dim == 16
+    assert m.lm_head.weight is m.model.embed_tokens.weight
+    assert m.model.layers[0].self_attn.q_proj.weight.shape == (32, 64) and m.model.layers[0].self_attn.o_proj.weight.shape == (64, 32)
+    assert len([n for n, _ in m.named_parameters() if n == "lm_head.weight"]) == 0       # one Parameter: optimizers / ZeRO buffers see it once
+    m.save_pretrained(tmp_path)
+    m2 = MetaMorphLlamaForCausalLM.from_pretrained(tmp_path, torch_dtype=torch.bfloat16, vision_head="mlp", normalize_vision=True)
+    assert m2.lm_head.weight is m2.model.embed_tokens.weight and torch.equal(m2.lm_head.weight, m.lm_head.weight)
+    assert np.array_equal(m2.model.rope.inv_freq, m.model.rope.inv_freq) and m2.model.rope.rope_type == "llama3"
+    assert not np.array_equal(m.model.rope.inv_freq, rope_params(MetaMorphConfig(**{k: v for k, v in llm.items() if k != "rope_scaling"})).inv_freq)
+    m.resize_token_embeddings(302)
+    assert m.lm_head.weight is m.model.embed_tokens.weight and m.lm_head.weight.shape[0] == 302
+    base = {k: v for k, v in llm.items() if k not in ("rope_scaling", "tie_word_embeddings", "head_dim")}
+    for kind in ("dynamic", "yarn", "longrope"):
+        with pytest.raises(NotImplementedError, match=kind):
+            rope_params(SimpleNamespace(hidden_size=64, num_attention_heads=2, rope_theta=1e4, rope_scaling={"rope_type": kind, "factor": 2.0}))
+    with pytest.raises(NotImplementedError, match="dynamic"):
+        build_model(dict(base, rope_scaling={"rope_type": "dynamic", "factor": 2.0}), geo, num_image_tokens=4)
+    for field in ("attention_bias", "mlp_bias"):
+        with pytest.raises(NotImplementedError, match="bias"):
+            MetaMorphLlamaForCausalLM(MetaMorphConfig(**base, **{field: True}))
 
 
 # ------------------------------------------------------------------ row N2: batch producer vs the reference's own outputs

@@ -439,6 +439,32 @@ def test_rope(ops):
     assert abs(float(lhs - rhs)) < 2e-2 * max(1.0, abs(float(lhs))), (float(lhs), float(rhs))
 
 
+def test_rope_table_freq_matches_hf_recorded_tables(ops):
+    """mm355_rope_table_freq (scaled RoPE: LLaMA-3.1 "llama3", 3.2, linear, and the default through the same entry point) against the cos / sin
+    rows HF's own LlamaRotaryEmbedding produced (tests/golden/r6_rope_tables.npz), positions up to 4095: at most one bf16 step anywhere
+    (device vs host cosf), and bit-identical on >= 99.5 % of the entries."""
+    import json
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "r6_rope_tables.npz"))
+    pos = torch.from_numpy(g["positions"])
+    for name in sorted({k.split("::")[0] for k in g.files if "::" in k}):
+        c = json.loads(str(g[f"{name}::cfg"]))
+        d = c["head_dim"]
+        cos, sin = ops.rope_table_freq(4096, d, g[f"{name}::inv_freq"], float(g[f"{name}::attention_scaling"]), DEV)
+        assert cos.shape == (4096, d) and torch.equal(cos[:, :d // 2], cos[:, d // 2:]) and torch.equal(sin[:, :d // 2], sin[:, d // 2:])
+        for got, key in ((cos, "cos"), (sin, "sin")):
+            want = torch.from_numpy(g[f"{name}::{key}_bf16"])
+            have = got.cpu()[pos].float()
+            close(have, want, 0, 8e-3, f"{name} {key}")
+            same = float((have == want).float().mean())
+            assert same >= 0.995, (name, key, same)
+    # the theta entry point (mm355_rope_table) builds the default table on the device from theta alone: same table
+    cd, sd_ = ops.rope_table(4096, 128, 500000.0, DEV)
+    cf, sf = ops.rope_table_freq(4096, 128, g["default::inv_freq"], 1.0, DEV)
+    assert float((cd != cf).float().mean()) < 5e-3 and float((cd.float() - cf.float()).abs().max()) <= 8e-3
+    assert float((sd_ != sf).float().mean()) < 5e-3
+
+
 # ------------------------------------------------------------------------------------------------ attention
 
 ATT_CASES = [  # B, L, Hq, Hkv, d, causal, seqlens

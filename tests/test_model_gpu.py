@@ -41,7 +41,10 @@ def hip_model(cfg: OracleConfig, sd, **kw):
     from metamorph_amd.factory import build_model
     llm = dict(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers,
                num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
-               vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta)
+               vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+               max_position_embeddings=cfg.max_position_embeddings, tie_word_embeddings=cfg.tie_word_embeddings,
+               **({"rope_scaling": dict(cfg.rope_scaling)} if cfg.rope_scaling else {}),
+               **({"head_dim": cfg.head_dim_explicit} if cfg.head_dim_explicit else {}))
     geo = dict(hidden_size=cfg.v_hidden, intermediate_size=cfg.v_intermediate, num_hidden_layers=cfg.v_layers,
                num_attention_heads=cfg.v_heads, image_size=cfg.v_image, patch_size=cfg.v_patch, layer_norm_eps=cfg.v_ln_eps)
     return build_model(llm, geo, num_image_tokens=cfg.num_image_tokens, use_vision_ar=cfg.use_vision_ar,
@@ -540,7 +543,7 @@ def test_greedy_decode_cached_equals_reprefill():
 
 
 @pytest.mark.parametrize("use_cache", [True, False])
-@pytest.mark.parametrize("name", ["text", "image_prompt"])
+@pytest.mark.parametrize("name", ["text", "image_prompt", "image_prompt_rope31"])
 def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
     """Row N1 pinned to the reference: tests/golden/n1_decode_*.npz hold what the reference's OWN `generate` -> `greedy_decode`
     (metamorph_llama.py:665-717, 502-597) emitted on these weights -- token mode -> <image_start> -> four continuous image tokens
@@ -549,8 +552,9 @@ def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
     `pred_z` rows (as close to the fp32 run as the reference's bf16 run, x2)."""
     from oracle.ref_model import decode_fixture_state_dict
     g = np.load(os.path.join(GOLDEN, f"n1_decode_{name}.npz"))
-    cfg = tiny_cfg(num_image_tokens=4)
+    cfg = tiny_cfg(num_image_tokens=4, **(json.loads(str(g["cfg_json"])) if "cfg_json" in g else {}))     # *_rope31: LLaMA-3.1 RoPE
     model = hip_model(cfg, decode_fixture_state_dict(g, cfg, torch.bfloat16)).eval()
+    assert model.model.rope.rope_type == ((cfg.rope_scaling or {}).get("rope_type", "default"))
     images = T(g["images"]).to(DEV).bfloat16() if g["images"].size else None
     out, emb = model.generate(inputs=T(g["input_ids"]).to(DEV), images=images, output_image=True,
                               max_new_tokens=int(g["max_new_tokens"]), use_cache=use_cache)
@@ -571,7 +575,7 @@ def test_greedy_decode_matches_reference_recorded_loop(name, use_cache):
     assert isinstance(only, list) and len(only) == 1 and only[0].tolist() == g["tokens_max2"].tolist()
 
 
-@pytest.mark.parametrize("name", ["text", "image_prompt"])
+@pytest.mark.parametrize("name", ["text", "image_prompt", "text_rope31"])
 def test_hf_generate_matches_reference_recorded(name):
     """`generate(use_customize_greedy=False, ...)` (reference metamorph_llama.py:711-717: transformers' GenerationMixin driving forward
     with a KV cache): greedy search and top-p sampling must emit the ids the REFERENCE's own HF-generate run emitted on these weights
@@ -582,7 +586,7 @@ def test_hf_generate_matches_reference_recorded(name):
     from oracle.ref_model import decode_fixture_state_dict
     from metamorph_amd.model.language_model.metamorph_llama import HipKVCache
     g = np.load(os.path.join(GOLDEN, f"hfgen_{name}.npz"))
-    cfg = tiny_cfg(num_image_tokens=4)
+    cfg = tiny_cfg(num_image_tokens=4, **(json.loads(str(g["cfg_json"])) if "cfg_json" in g else {}))
     model = hip_model(cfg, decode_fixture_state_dict(g, cfg, torch.bfloat16)).eval()
     images = T(g["images"]).to(DEV).bfloat16() if g["images"].size else None
     ids = T(g["input_ids"]).to(DEV)
@@ -645,6 +649,65 @@ def test_hf_generate_batch_of_left_padded_prompts_on_device():
     with pytest.raises(NotImplementedError):                      # right padding would put pad rows between the prompt and the generated tokens
         model.generate(inputs=ids.flip(1), attention_mask=mask.flip(1), use_customize_greedy=False, do_sample=False, max_new_tokens=2,
                        eos_token_id=128009, pad_token_id=128001)
+
+
+def test_rope31_long_sample_real_llama31_constants_on_device():
+    """The reference's forward + backward on ONE 4096-row sample under the REAL LLaMA-3.1 RoPE constants (rope_type "llama3", factor 8,
+    context 8192 -- README.md:178,187's base model), recorded in tests/golden/r6_rope31_long_*.npz with attention sharp enough that
+    positions matter: under the DEFAULT RoPE the same weights put the hidden rows 0.75 (relative) away, so a table that ignored
+    rope_scaling cannot pass.  HIP bf16 must be as close to the reference's fp32 run as the reference's own bf16 run (x 1.5)."""
+    from test_oracle_vs_golden import long_rope_state_dict
+    g, g32 = (np.load(os.path.join(GOLDEN, f"r6_rope31_long_{t}.npz")) for t in ("bf16", "f32"))
+    assert float(g32["default_rope_hidden_rel_far"]) > 0.5
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), **json.loads(str(g["cfg_json"])))
+    model = hip_model(cfg, long_rope_state_dict(cfg, g, torch.bfloat16))
+    assert model.model.rope.rope_type == "llama3"
+    model.train()
+    out = model(input_ids=T(g["input_ids"]).to(DEV), attention_mask=T(g["attention_mask"]).to(DEV), labels=T(g["labels"]).to(DEV),
+                images=T(g["images"]).to(DEV).bfloat16())
+    l_hip, l16, l32 = float(out.loss.detach()), float(g["loss"]), float(g32["loss"])
+    rows = T(g["hidden_rows"])
+    hs = out.hidden_states[0].float().cpu()[rows]
+    e_hip, e_ref = rel(hs, T(g32["hidden"])), rel(T(g["hidden"]), T(g32["hidden"]))
+    far = rows >= 2048
+    e_far, e_far_ref = rel(hs[far], T(g32["hidden"])[far]), rel(T(g["hidden"])[far], T(g32["hidden"])[far])
+    print(f"\n   [rope31 long] loss hip={l_hip:.5f} reference bf16={l16:.5f} fp32={l32:.5f}; hidden rel err vs fp32 hip={e_hip:.3e} "
+          f"reference-bf16={e_ref:.3e} (rows >= 2048: {e_far:.3e} / {e_far_ref:.3e}); default-RoPE distance {float(g32['default_rope_hidden_rel']):.2f}")
+    assert abs(l_hip - l32) <= max(1.5 * abs(l16 - l32), 1e-3 * abs(l32)), (l_hip, l16, l32)
+    assert e_hip <= 1.5 * e_ref and e_far <= 1.5 * e_far_ref
+    out.loss.backward()
+    n = 0
+    for k in g32.files:
+        if not k.startswith("grad::"):
+            continue
+        p = dict(model.named_parameters())[k[6:]]
+        got = grad_summary(p.grad)
+        e_h, e_r = rel(got[1:], T(g32[k])[1:]), rel(T(g[k])[1:], T(g32[k])[1:])
+        assert e_h <= max(2.0 * e_r, 3.3e-2), (k, e_h, e_r)
+        n += 1
+    assert n >= 20
+
+
+def test_config_fields_of_real_checkpoints_are_supported_or_refused_by_name():
+    """LLaMA-3.1 rope_scaling constructs (it raised NotImplementedError through round 5); dynamic / yarn RoPE, attention_bias and mlp_bias
+    are refused at construction, by name."""
+    from metamorph_amd.factory import build_model
+    base = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=1000,
+                rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=131072)
+    geo = dict(num_hidden_layers=1, intermediate_size=144, image_size=56)
+    r31 = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+    m = build_model(dict(base, rope_scaling=r31), geo, num_image_tokens=4, max_length=64, device=DEV)
+    assert m.model.rope.rope_type == "llama3"
+    cos, _ = m.model.rope_tables(4096, DEV)
+    cos_d, _ = build_model(base, geo, num_image_tokens=4, max_length=64, device=DEV).model.rope_tables(4096, DEV)
+    assert not torch.equal(cos, cos_d) and torch.equal(cos[:, :2], cos_d[:, :2])     # the two shortest wavelengths are kept, long ones stretched
+    for bad in ({"rope_type": "dynamic", "factor": 2.0}, {"rope_type": "yarn", "factor": 2.0}):
+        with pytest.raises(NotImplementedError, match=bad["rope_type"]):
+            build_model(dict(base, rope_scaling=bad), geo, num_image_tokens=4, max_length=64)
+    for field in ("attention_bias", "mlp_bias"):
+        with pytest.raises(NotImplementedError, match="bias"):
+            from metamorph_amd.model import MetaMorphConfig, MetaMorphLlamaForCausalLM
+            MetaMorphLlamaForCausalLM(MetaMorphConfig(**base, **{field: True}))
 
 
 @pytest.mark.parametrize("B", [3, 8, 11, 19])

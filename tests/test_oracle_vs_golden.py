@@ -226,11 +226,11 @@ def test_e2e_bf16(path):
 
 # ------------------------------------------------------------------ N1: the greedy decode loop
 
-@pytest.mark.parametrize("name", ["text", "image_prompt"])
+@pytest.mark.parametrize("name", ["text", "image_prompt", "image_prompt_rope31"])
 def test_n1_greedy_decode_matches_reference_loop(name):
     from oracle.ref_model import decode_fixture_state_dict, greedy_decode
     g = np.load(os.path.join(GOLDEN, f"n1_decode_{name}.npz"))
-    cfg = tiny_cfg(num_image_tokens=4)
+    cfg = tiny_cfg(num_image_tokens=4, **(json.loads(str(g["cfg_json"])) if "cfg_json" in g else {}))
     sd = decode_fixture_state_dict(g, cfg)
     images = T(g["images"]) if g["images"].size else None
     toks, pz, logits = greedy_decode(sd, cfg, T(g["input_ids"]), images, max_new_tokens=int(g["max_new_tokens"]))
@@ -316,3 +316,80 @@ def test_text_only_forward_without_images(tag, stem):
         for k in g.files:
             if k.startswith("grad::"):
                 torch.testing.assert_close(_grad_summary(sd[k[6:]].grad), T(g[k]), rtol=2e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------ round 6: LLaMA-3.1 RoPE (rope_type "llama3") and friends
+
+ROPE_TABLES = np.load(os.path.join(GOLDEN, "r6_rope_tables.npz"))
+ROPE_CASES = sorted({k.split("::")[0] for k in ROPE_TABLES.files if "::" in k})
+
+
+@pytest.mark.parametrize("name", ROPE_CASES)
+def test_rope_inv_freq_and_tables_match_hf_buffers(name):
+    """oracle.ref_ops.rope_inv_freq / rope_tables AND the product's host step (metamorph_amd.rope.rope_params -- pure host code, no kernel)
+    against the buffers HF's LlamaRotaryEmbedding built for the same config: inv_freq bit for bit, cos / sin rows at positions <= 4095."""
+    from types import SimpleNamespace
+    from metamorph_amd.rope import rope_params
+    g = ROPE_TABLES
+    c = json.loads(str(g[f"{name}::cfg"]))
+    want = T(g[f"{name}::inv_freq"])
+    got = ops.rope_inv_freq(c["head_dim"], c["rope_theta"], c["rope_scaling"], c["max_position_embeddings"])
+    assert torch.equal(got, want), float((got - want).abs().max())
+    hf_like = SimpleNamespace(hidden_size=2 * c["head_dim"], num_attention_heads=2, rope_theta=c["rope_theta"], rope_scaling=c["rope_scaling"],
+                              max_position_embeddings=c["max_position_embeddings"])
+    rp = rope_params(hf_like)
+    assert np.array_equal(rp.inv_freq, g[f"{name}::inv_freq"]) and rp.attention_scaling == float(g[f"{name}::attention_scaling"]) == 1.0
+    assert rp.head_dim == c["head_dim"] and rp.rope_type == ((c["rope_scaling"] or {}).get("rope_type", "default"))
+    pos = T(g["positions"])
+    for tag, dt in DT.items():
+        cos, sin = ops.rope_tables(pos, c["head_dim"], c["rope_theta"], dt, c["rope_scaling"], c["max_position_embeddings"])
+        assert torch.equal(cos.float(), T(g[f"{name}::cos_{tag}"])) and torch.equal(sin.float(), T(g[f"{name}::sin_{tag}"]))
+    if name != "default":                                      # the scaled tables are not the default ones in disguise
+        assert not np.array_equal(g[f"{name}::cos_bf16"], g["default::cos_bf16"])
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_rope31_long_sample_real_llama31_constants(tag):
+    """One 4096-row sample under the REAL LLaMA-3.1 RoPE constants, recorded from the reference (oracle/gen_golden.py rope31): loss, every 16th
+    hidden row, gradient summaries.  The fixture itself states how far the default RoPE lands on the same weights (hidden rows 0.75 apart)."""
+    g = np.load(os.path.join(GOLDEN, f"r6_rope31_long_{tag}.npz"))
+    g32 = np.load(os.path.join(GOLDEN, "r6_rope31_long_f32.npz"))
+    assert float(g32["default_rope_hidden_rel_far"]) > 0.5
+    cfg = tiny_cfg(num_image_tokens=int(g["rows_per_image"]), **json.loads(str(g["cfg_json"])))
+    sd = long_rope_state_dict(cfg, g, DT[tag])
+    if tag == "f32":
+        for k, v in sd.items():
+            if "vision_tower" not in k:
+                v.requires_grad_(True)
+    with torch.set_grad_enabled(tag == "f32"):
+        out = forward(sd, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]).to(DT[tag]), return_logits=False,
+                      ce_rows_only=True)
+    rows = T(g["hidden_rows"])
+    if tag == "f32":
+        assert abs(float(out["loss"]) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+        torch.testing.assert_close(out["hidden_states"][0, rows], T(g["hidden"]), rtol=2e-4, atol=2e-5)
+        out["loss"].backward()
+        n = 0
+        for k in g.files:
+            if k.startswith("grad::"):
+                torch.testing.assert_close(_grad_summary(sd[k[6:]].grad), T(g[k]), rtol=5e-4, atol=2e-6)
+                n += 1
+        assert n >= 20
+    else:
+        # sharp attention over 4096 keys in bf16: the reference's own bf16 run sits 4.4e-3 (relative) off its fp32 run; the yardstick for
+        # any bf16 implementation is the fp32 truth, at the reference-bf16 run's distance
+        l32 = float(g32["loss"])
+        assert abs(float(out["loss"]) - l32) <= max(1.5 * abs(float(g["loss"]) - l32), 1e-3 * abs(l32)), (float(out["loss"]), float(g["loss"]), l32)
+        e = float((out["hidden_states"][0, rows].float() - T(g32["hidden"])).norm() / T(g32["hidden"]).norm())
+        e_ref = float((T(g["hidden"]) - T(g32["hidden"])).norm() / T(g32["hidden"]).norm())
+        assert e <= 1.5 * e_ref, (e, e_ref)
+
+
+def long_rope_state_dict(cfg, g, dtype):
+    """The rope31 long fixture's weights: seeded state dict with q_proj / k_proj x qk_gain (attention logits of std ~3, so positions matter)."""
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    gain = float(g["qk_gain"])
+    for k in sd:
+        if (k.endswith("q_proj.weight") or k.endswith("k_proj.weight")) and "vision_tower" not in k:
+            sd[k] = sd[k] * gain
+    return {k: v.to(dtype) for k, v in sd.items()}
