@@ -730,7 +730,8 @@ class BilinearL2NormFn(Function):
 
 
 def linear(x2d, module):
-    if x2d.shape[0] <= 16 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad)):
+    if (x2d.shape[0] <= 16 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad))
+            and ops.gemv_supported(x2d, module.weight.data)):
         # decode shape: a handful of rows, inference only -> stream the weight once (mm355_gemv_bf16)
         return ops.gemv(x2d, module.weight.data, bias=None if module.bias is None else module.bias.data)
     return LinearFn.apply(x2d, module.weight, module.bias, module)
@@ -865,6 +866,9 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin, kv_bound=None):
     if B != cache.batch:
         raise ValueError(f"{B} rows for a cache of {cache.batch} sequences")
     bound = decode_kv_bound(cache) if kv_bound is None else kv_bound
+    if cache.length + 1 > bound:
+        # the bound is a launch parameter (number of key groups): a sequence longer than it would silently attend to its first `bound` keys
+        raise ValueError(f"decode bound {bound} is below the longest sequence + 1 ({cache.length + 1}); lengths change only through set_lengths")
     if B <= 16:
         y = _decode_rows16(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, bound)
     else:

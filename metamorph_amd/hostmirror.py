@@ -22,7 +22,9 @@ STATS = {"mirror": 0, "cpu": 0, "sync": 0}                   # how host_array wa
 
 def attach(device_tensor: torch.Tensor, host) -> torch.Tensor:
     """Remember `host` (a CPU tensor or numpy array with the same shape and values) as the host copy of `device_tensor`."""
-    arr = host.detach().numpy() if isinstance(host, torch.Tensor) else np.asarray(host)
+    # a COPY: the caller may reuse or edit its host buffer (collator / pinned staging buffers, in-place label edits) after the move, and the
+    # plan must be built from the values the device tensor holds (these are [B, L] integer arrays: a few tens of KB)
+    arr = np.array(host.detach().numpy() if isinstance(host, torch.Tensor) else host, copy=True)
     if tuple(arr.shape) != tuple(device_tensor.shape):
         raise ValueError(f"host copy {arr.shape} does not match the device tensor {tuple(device_tensor.shape)}")
     key = id(device_tensor)

@@ -144,6 +144,8 @@ class HipKVCache(DynamicCache):
     def crop(self, max_length):
         """HF's convention: keep the first `max_length` positions of the PADDED sequence (what get_seq_length counts); negative = drop
         the last -max_length positions.  Every row keeps max_length - pad real rows."""
+        if self.kv is None:                                   # nothing cached yet (an empty DynamicCache.crop is a no-op as well)
+            return
         max_length = int(max_length)
         if max_length < 0:
             max_length = self.get_seq_length() + max_length
@@ -664,7 +666,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
     def _rows_logits(self, rows, return_hidden=False):
         """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399); return_hidden: (logits, normed rows)."""
         hid = self.model.norm(rows)
-        if hid.shape[0] <= 16:
+        if hid.shape[0] <= 16 and ops.gemv_supported(hid, self.lm_head.weight.data):
             logits = ops.gemv(hid.contiguous(), self.lm_head.weight.data,
                               out=torch.empty((hid.shape[0], self.lm_head.weight.shape[0]), device=rows.device, dtype=torch.float32))
         else:

@@ -164,6 +164,17 @@ def gemm_nn_supported(a, bt):
             and ((M + 255) // 256) * ((N + 255) // 256) >= 128)
 
 
+def gemv_supported(x, w):
+    """mm355_gemv_bf16 takes this (x [M <= 16, K], w [N, K]) pair: up to 4 rows always; 5 - 16 rows (the MFMA form) only while the weight and
+    the x rows are addressable with 32-bit byte offsets (< 3.75 GiB; gemv_mfma_addressable in csrc/decode.hip) -- beyond that the call
+    returns MM355_EUNSUPPORTED and callers use the GEMM."""
+    _, M, K, ldx = _rows2d(x)
+    _, N, _, ldw = _rows2d(w)
+    if M > 16:
+        return False
+    return M <= 4 or ((N - 1) * ldw * 2 + K * 2 < 0xf0000000 and (M - 1) * ldx * 2 + K * 2 < 0xf0000000)
+
+
 def gemv(x, w, out=None, bias=None, residual=None, gelu=None):
     """out[M,N] = x[M,K] . w[N,K]^T for M <= 16 rows (decode shape): streams the weight once at HBM rate (1 - 2 rows: vector ALU; 3 - 16: MFMA)."""
     _chk_dev(x, w, out, bias, residual)

@@ -100,6 +100,16 @@ class MetaMorphTrainer(Trainer):
 
         acc.prepare_model = prepare_model
 
+        # Batches stay on the HOST until `_prepare_inputs`: accelerate's prepared DataLoader would move them to the device itself
+        # (device_placement defaults to True), `_prepare_inputs` would then see device tensors only, no host original could be registered as
+        # a mirror, and every step's splice plan would pull ids / labels / mask back with a synchronising `.cpu()` (hostmirror.py).
+        inner_dl = acc.prepare_data_loader
+
+        def prepare_data_loader(data_loader, device_placement=None, slice_fn_for_dispatch=None):
+            return inner_dl(data_loader, device_placement=False, slice_fn_for_dispatch=slice_fn_for_dispatch)
+
+        acc.prepare_data_loader = prepare_data_loader
+
     # ------------------------------------------------------------------ optimizer
     def create_optimizer(self):
         if self.optimizer is not None:
