@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--zero2-overlap", type=int, default=1, choices=(0, 1), help="0: the gradient reduce-scatters all start at step() instead of from "
                     "inside backward (driver-side A/B of the overlap; default 1)")
     ap.add_argument("--pool", type=int, default=8, help="distinct seeded batches rotated through the steps (the loss is then a training loss, not a memorised batch)")
+    ap.add_argument("--llama31-rope", action="store_true", help="LLaMA-3.1's rope_scaling (rope_type llama3) instead of the plain theta = 5e5 RoPE of "
+                    "BASELINE's LLaMA-3-8B: only the cos / sin TABLES differ, every kernel is the same; said in config.workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -94,12 +96,17 @@ def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
             images.to(device).to(torch.bfloat16))
 
 
-def build_bench_model(dev, layers=32, vit_layers=27, image_tokens=256, seed=1234):
+LLAMA31_ROPE = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+
+
+def build_bench_model(dev, layers=32, vit_layers=27, image_tokens=256, seed=1234, llama31_rope=False):
     """The model this benchmark times: LLaMA-3-8B geometry + SO400M tower, random weights from torch's device generator under a
     fixed seed (identical on every rank; the BATCH is seeded per rank).  tests/test_fulldepth_gpu.py builds the same model with the
     same seed and compares its step-0 forward / backward with the fp32 oracle at full depth."""
     from metamorph_amd.factory import LLAMA3_8B, build_model
     llm = dict(LLAMA3_8B, num_hidden_layers=layers)
+    if llama31_rope:                                             # meta-llama/Llama-3.1-8B's config.json (the reference README's base model)
+        llm.update(rope_scaling=dict(LLAMA31_ROPE), max_position_embeddings=131072)
     geo = dict(num_hidden_layers=vit_layers)
     torch.manual_seed(seed)
     model = build_model(llm, geo, num_image_tokens=image_tokens, max_length=4096, device=dev, init_on_device=True)
@@ -486,6 +493,18 @@ def self_launch(n):
         raise SystemExit(rc)
 
 
+def newest_profiles(stem):
+    """profiles/r<N>_<stem>*.json, newest round first (the counter evidence the bench line cites: taken on the shipped kernels of that round)."""
+    import glob
+    import re
+    found = []
+    for pth in glob.glob(os.path.join(REPO, "profiles", f"r*_{stem}*.json")):
+        m = re.match(r"r(\d+)_", os.path.basename(pth))
+        if m:
+            found.append((int(m.group(1)), os.path.basename(pth), pth))
+    return [pth for _, _, pth in sorted(found, reverse=True)]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -535,7 +554,7 @@ def main():
     from metamorph_amd.zero2 import Zero2AdamW, tag_segments
 
     t_build = time.time()
-    model = build_bench_model(dev, layers=args.layers, vit_layers=args.vit_layers, image_tokens=args.image_tokens)
+    model = build_bench_model(dev, layers=args.layers, vit_layers=args.vit_layers, image_tokens=args.image_tokens, llama31_rope=args.llama31_rope)
     if args.train_vision:                                        # reference: freeze_vision=False + `vision_lr` parameter group
         tower = model.get_model().vision_tower
         tower.freeze_vision = False
@@ -691,14 +710,25 @@ def main():
         # correction) over this same command, summarised by tools/hbm_traffic_summary.py and committed under profiles/; they only
         # apply to the configuration they were taken on.  Mean over all GEMM launches, weighted by launch count.
         traffic, traffic_src = None, None
-        for tname in ("r4_step_b16_hbm_traffic.json", "r3_step_b16_hbm_traffic_c.json") if args.batch == 16 else ():
-            tpath = os.path.join(REPO, "profiles", tname)
-            if args.layers == 32 and args.seq == 2048 and args.frames == 1 and os.path.exists(tpath):
-                ks = [k for k in json.load(open(tpath))["kernels"] if k["kernel"].startswith("gemm_")]
-                if ks:
-                    traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / sum(k["launches"] for k in ks))
-                    traffic_src = "profiles/" + tname
-                    break
+        canonical = args.batch == 16 and args.layers == 32 and args.seq == 2048 and args.frames == 1
+        for tpath in newest_profiles("step_b16_hbm_traffic") if canonical else ():      # newest round first
+            ks = [k for k in json.load(open(tpath))["kernels"] if k["kernel"].startswith("gemm_")]
+            if ks:
+                traffic = round(sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / sum(k["launches"] for k in ks))
+                traffic_src = "profiles/" + os.path.basename(tpath)
+                break
+        # MFMA-pipe utilisation from the counters (north_star: "evidenced by rocprof MFMA utilisation"): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs /
+        # active cycles, one rocprofv3 --pmc pass over this same command (tools/pmc_mfma_busy.py); GEMM family weighted by active cycles
+        mfma_busy, mfma_busy_src, mfma_busy_attn = None, None, None
+        for bpath in newest_profiles("step_b16_mfma_busy") if canonical else ():
+            ks = json.load(open(bpath))["kernels"]
+            gs = [k for k in ks if k["kernel"].startswith("gemm_")]
+            if gs:
+                wsum = sum(k["active_cycles_per_launch"] * k["launches"] for k in gs)
+                mfma_busy = round(sum(k["mfma_busy"] * k["active_cycles_per_launch"] * k["launches"] for k in gs) / wsum, 4)
+                mfma_busy_attn = {k["kernel"]: round(k["mfma_busy"], 4) for k in ks if k["kernel"].startswith("attn4")}
+                mfma_busy_src = "profiles/" + os.path.basename(bpath)
+                break
         ach = fl_all / t_all_g / 1e12
         bytes_all = sum(r[4] for r in timer.records)
         roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family, ALL launches of the timed steps: gemm_pp_kernel, gemm_pp_pair_kernel (two problems, one grid), "
@@ -707,6 +737,8 @@ def main():
                     "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (L2 misses incl. Infinity-Cache hits), mean over all GEMM launches",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_all / n_all),
+                    "mfma_busy": mfma_busy, "mfma_busy_attention": mfma_busy_attn, "mfma_busy_source": mfma_busy_src,
+                    "mfma_busy_unit": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8): share of the dispatch's active cycles the matrix pipe is busy",
                     "launches": n_all, "gemm_seconds_per_step": round(t_all_g / args.steps, 4),
                     "algorithmic_flops_per_step": fl_all / args.steps}
         if n_gemm:
@@ -736,7 +768,8 @@ def main():
                 f"; INPUTS FROM PINNED HOST MEMORY every step ({host_bytes} B/step over PCIe: not the headline configuration)" if args.host_inputs else ""),
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
-                                   "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2",
+                                   "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2" + (
+                                       "; LLaMA-3.1 rope_scaling (rope_type llama3) instead of BASELINE's plain RoPE" if args.llama31_rope else ""),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        **({"variants": sorted(args.set_variant)} if args.set_variant else {}),

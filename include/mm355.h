@@ -364,9 +364,32 @@ int mm355_axpy_f32_to_bf16_dev(mm355_bf16* y, const float* x, int64_t n, const f
  * loss_sum += sum_r (lse_r - logit_r[target]);  then, IN PLACE, logits <- grad_scale*(softmax - onehot)
  * (zero on ignored rows and padding columns).  fp32 math on the bf16-rounded logits like the reference's
  * `.float()`; rows are compacted by the host so ignored rows normally never reach this kernel.
+ * row_ws (nullable, R floats): the per-row NLL values are written there and added to loss_sum in a FIXED order by one workgroup
+ * (bit-reproducible loss); NULL = one fp32 atomicAdd per row (order, hence the last bits, vary from run to run).  The same parameter
+ * exists on the three image-AR loss entry points below.  loss_sum may be NULL when row_ws is given (per-row values only).
  * ------------------------------------------------------------------------------------------------ */
 int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V,
-                  float grad_scale, float* loss_sum, void* stream);
+                  float grad_scale, float* loss_sum, float* row_ws, void* stream);
+/* out[0] = (accumulate ? out[0] : 0) + scale * sum(values[0..n)) in a fixed order (one workgroup; the reduction behind row_ws) */
+int mm355_sum_rows_f32(const float* values, int64_t n, float scale, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * lm_head + shifted cross entropy, forward and both gradients, as ONE call (SURVEY 8(b) `linear_ce`; reference metamorph_llama.py:393-413:
+ * `logits = lm_head(hidden).float()`, shift, `CrossEntropyLoss()` = mean NLL over the positions whose next label is live).
+ *   hidden [*, ldh] bf16 rows of the final-norm output; rows[i] (int32, device; NULL = rows 0..n-1) = the row that predicts targets[i]
+ *   (int32, device, in [0, V)) -- the host plan lists only positions with a live next label, so no flop is spent on ignored ones;
+ *   W [V, ldw] = lm_head.weight.
+ *   loss[0]        = (1/n) sum_i NLL_i, the per-row values summed in a fixed order (bit-reproducible);
+ *   d_hidden [n,h] = d loss / d hidden[rows[i]] (compact, bf16; NULL = not wanted);
+ *   dW [V,h]       = d loss / d W, OVERWRITTEN (bf16, or fp32 when dw_f32 != 0; NULL = not wanted).
+ * The rows go through the logits GEMM in chunks of 8192: bf16 logits (the reference's bf16 nn.Linear output) -> mm355_ce_rows (fp32 math,
+ * gradient in place) -> the two gradient GEMMs; the [n, V] fp32 logits tensor never exists.  Workspace: mm355_linear_ce_ws_bytes(n, V, h,
+ * gather = rows != NULL, need_dh = d_hidden != NULL, need_dw = dW != NULL) bytes, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t mm355_linear_ce_ws_bytes(int64_t n, int64_t V, int64_t h, int gather, int need_dh, int need_dw);
+int mm355_linear_ce(const mm355_bf16* hidden, int64_t ldh, const int32_t* rows, const int32_t* targets, int64_t n,
+                    const mm355_bf16* W, int64_t ldw, int64_t V, int64_t h, float* loss, mm355_bf16* d_hidden, void* dW,
+                    int dw_f32, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Splice (metamorph_arch.py:259-399; K6) driven by the host gather plan (bit-exact int bookkeeping):
@@ -409,7 +432,7 @@ int mm355_bilinear_l2norm_bwd(const mm355_bf16* in, const mm355_bf16* d_out, flo
  *   loss_sum += sum_r cos(target_r, p_r)  (caller turns it into -mean);  dpred = d(-mean cos)/d pred_raw * 1
  * ------------------------------------------------------------------------------------------------ */
 int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
-                      float* cos_sum, mm355_bf16* dpred, void* stream);
+                      float* cos_sum, mm355_bf16* dpred, float* row_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The other two image-AR head variants (metamorph_llama.py:437-447 soft-CE, :459 + :211-219 mean-abs) and the
@@ -424,9 +447,9 @@ int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int6
  *   softmax_rows_bwd: dx = y * (dy - sum_j dy_j y_j) / temperature.
  * ------------------------------------------------------------------------------------------------ */
 int mm355_mean_abs_loss(const mm355_bf16* pred, const mm355_bf16* target, int64_t R, int64_t C, float* abs_sum,
-                        mm355_bf16* dpred, void* stream);
+                        mm355_bf16* dpred, float* row_ws, void* stream);
 int mm355_soft_ce_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
-                       float temperature, float* loss_sum, mm355_bf16* dpred, void* stream);
+                       float temperature, float* loss_sum, mm355_bf16* dpred, float* row_ws, void* stream);
 int mm355_softmax_rows(const mm355_bf16* x, mm355_bf16* y, int64_t R, int64_t C, float temperature, void* stream);
 int mm355_softmax_rows_bwd(const mm355_bf16* y, const mm355_bf16* dy, mm355_bf16* dx, int64_t R, int64_t C,
                            float temperature, void* stream);

@@ -14,10 +14,12 @@ LIB = os.path.join(LIBDIR, "libmm355.so")
 # (attn3.hip, attention variant 3), the one-wave-per-SIMD GEMM stream (gemm_st.hip, GEMM variants 13 / 14) and GEMM variants 3-6, 8, 10, 12 --
 # for A/B timing (tools/bench_attn4*.py, tools/bench_gemm_*.py) and their tests (MM355_TEST_LEGACY=1).  The product library has none of them.
 LEGACY = os.environ.get("MM355_LEGACY_VARIANTS") == "1"
-SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn4.hip", "attn4_bwd.hip", "decode.hip", "losses.hip"]
+SOURCES = ["gemm_bf16.hip", "rowwise.hip", "elementwise.hip", "attn.hip", "attn2.hip", "attn4.hip", "attn4_bwd.hip", "decode.hip", "losses.hip", "linear_ce.hip"]
 if LEGACY:
     SOURCES += ["attn3.hip", "gemm_st.hip"]
-HEADERS = ["mm355_common.h", "gemm_common.h", "attn2.h", "attn3_kernels.h"] + sorted(
+# (attn3_kernels.h stays in the digest of the default build: attn4.hip / attn4_bwd.hip include it for its tile-DMA and lane helpers; the
+# round-2 kernel templates in it are instantiated only by attn3.hip, i.e. only under MM355_LEGACY_VARIANTS)
+HEADERS = ["mm355_common.h", "gemm_common.h", "attn2.h", "rowsum.h", "attn3_kernels.h"] + sorted(
     os.path.join(d, f) for d in ("attn4_gen", "attn4_bwd_gen") + (("gemm_st_gen",) if LEGACY else ())
     for f in os.listdir(os.path.join(CSRC, d)) if f.endswith(".inc"))   # tools/gen_attn4*.py output
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DMM355_LEGACY_VARIANTS"] if LEGACY else [])

@@ -5,6 +5,7 @@
 //   the temperature softmax itself (tower side siglip_encoder.py:210-211, decode side metamorph_llama.py:372-373) + backward.
 // Rows are short (C = mm_hidden_size = 1152): every pass re-reads the row from L1/L2, 16 B per lane.
 #include "mm355_common.h"
+#include "rowsum.h"
 
 namespace {
 
@@ -17,7 +18,7 @@ MM_DEV float signf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
 // abs_sum += sum |round_bf(t - p)|;  dpred = sign(p - t) / (R*C)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void mean_abs_loss_kernel(const uint16_t* __restrict__ pred, const uint16_t* __restrict__ tgt, int R, int C,
-                                                           float* __restrict__ abs_sum, uint16_t* __restrict__ dpred) {
+                                                           float* __restrict__ abs_sum, uint16_t* __restrict__ dpred, float* __restrict__ row_out) {
     const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -40,7 +41,10 @@ __global__ __launch_bounds__(NT) void mean_abs_loss_kernel(const uint16_t* __res
         if (gr) *(u32x4*)(gr + v * 8) = pack8(g);
     }
     acc = wave_sum(acc);
-    if (lane == 0) atomicAdd(abs_sum, acc);
+    if (lane == 0) {
+        if (row_out) row_out[row] = acc;                    // summed in a fixed order afterwards (mm_sum_rows_kernel)
+        else atomicAdd(abs_sum, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(NT) void softmax_rows_bwd_kernel(const uint16_t* __
 //   loss_sum += -sum_j target_j * log(q_j + 1e-10);   dpred = d(mean_r loss_r) / d pred_raw
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void soft_ce_loss_kernel(const uint16_t* __restrict__ pred, const uint16_t* __restrict__ tgt, int R, int C,
-                                                          int normalize, float inv_temp, float* __restrict__ loss_sum, uint16_t* __restrict__ dpred) {
+                                                          int normalize, float inv_temp, float* __restrict__ loss_sum, uint16_t* __restrict__ dpred,
+                                                          float* __restrict__ row_out) {
     const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -178,7 +183,10 @@ __global__ __launch_bounds__(NT) void soft_ce_loss_kernel(const uint16_t* __rest
     }
     loss = wave_sum(loss);
     gq = wave_sum(gq);
-    if (lane == 0) atomicAdd(loss_sum, loss);
+    if (lane == 0) {
+        if (row_out) row_out[row] = loss;
+        else atomicAdd(loss_sum, loss);
+    }
     if (!dpred) return;
     uint16_t* gr = dpred + (int64_t)row * C;
     const float rs = inv_temp / (float)R;                      // mean over rows, d z / d u
@@ -220,19 +228,21 @@ inline unsigned row_grid(int64_t R) { return (unsigned)((R + NT / 64 - 1) / (NT 
 }  // namespace
 
 extern "C" int mm355_mean_abs_loss(const mm355_bf16* pred, const mm355_bf16* target, int64_t R, int64_t C, float* abs_sum,
-                                   mm355_bf16* dpred, void* stream) {
+                                   mm355_bf16* dpred, float* row_ws, void* stream) {
     (void)hipGetLastError();
     if (!pred || !target || !abs_sum || R <= 0 || C <= 0 || (C & 7) || R > 0x7fffffff) return MM355_EINVAL;
-    hipLaunchKernelGGL(mean_abs_loss_kernel, dim3(row_grid(R)), dim3(NT), 0, (hipStream_t)stream, pred, target, (int)R, (int)C, abs_sum, dpred);
+    hipLaunchKernelGGL(mean_abs_loss_kernel, dim3(row_grid(R)), dim3(NT), 0, (hipStream_t)stream, pred, target, (int)R, (int)C, abs_sum, dpred, row_ws);
+    if (row_ws) hipLaunchKernelGGL(mm_sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)row_ws, R, 1.0f, abs_sum, 1);
     return mm_launch_status();
 }
 
 extern "C" int mm355_soft_ce_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize, float temperature,
-                                  float* loss_sum, mm355_bf16* dpred, void* stream) {
+                                  float* loss_sum, mm355_bf16* dpred, float* row_ws, void* stream) {
     (void)hipGetLastError();
     if (!pred_raw || !target || !loss_sum || R <= 0 || C <= 0 || (C & 7) || R > 0x7fffffff || !(temperature > 0.f)) return MM355_EINVAL;
     hipLaunchKernelGGL(soft_ce_loss_kernel, dim3(row_grid(R)), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize,
-                       1.0f / temperature, loss_sum, dpred);
+                       1.0f / temperature, loss_sum, dpred, row_ws);
+    if (row_ws) hipLaunchKernelGGL(mm_sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)row_ws, R, 1.0f, loss_sum, 1);
     return mm_launch_status();
 }
 

@@ -2,6 +2,7 @@
 // cross-entropy over logits rows, cosine regression loss, bilinear token reduction + L2 normalise.
 // All loads/stores are 16-byte vectors (8 bf16); reductions are wave shuffles + one LDS hop.
 #include "mm355_common.h"
+#include "rowsum.h"
 #include <type_traits>
 
 namespace {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const uint16_t* __res
 // ------------------------------------------------------------------------------------------------
 constexpr int CE_NT = 512;
 __global__ __launch_bounds__(CE_NT) void ce_rows_kernel(uint16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ targets,
-                                                        int V, float grad_scale, float* __restrict__ loss_sum) {
+                                                        int V, float grad_scale, float* __restrict__ loss_sum, float* __restrict__ row_out) {
     __shared__ float red[CE_NT / 64];
     const int64_t row = blockIdx.x;
     uint16_t* lr = logits + row * ld;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(CE_NT) void ce_rows_kernel(uint16_t* __restrict__ l
     const int nvec = (int)(ld >> 3);
     if (tgt < 0) {                                           // ignored row: zero gradient
         for (int v = threadIdx.x; v < nvec; v += CE_NT) *(u32x4*)(lr + v * 8) = u32x4{0u, 0u, 0u, 0u};
+        if (row_out && threadIdx.x == 0) row_out[row] = 0.f;
         return;
     }
     float m = -INFINITY, s = 0.f;
@@ -349,7 +351,10 @@ __global__ __launch_bounds__(CE_NT) void ce_rows_kernel(uint16_t* __restrict__ l
     s = (m > -INFINITY) ? s * __expf(m - gmax) : 0.f;
     const float gsum = block_sum<CE_NT>(s, red);
     const float lse = gmax + __logf(gsum);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(lr[tgt]));
+    if (threadIdx.x == 0) {
+        if (row_out) row_out[row] = lse - bf2f(lr[tgt]);    // summed in a fixed order afterwards (mm_sum_rows_kernel)
+        else atomicAdd(loss_sum, lse - bf2f(lr[tgt]));
+    }
     __syncthreads();                                         // target logit read before it is overwritten
     for (int v = threadIdx.x; v < nvec; v += CE_NT) {
         float f[8];
@@ -369,7 +374,8 @@ __global__ __launch_bounds__(CE_NT) void ce_rows_kernel(uint16_t* __restrict__ l
 // Cosine regression loss, one wave per row.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void cosine_loss_kernel(const uint16_t* __restrict__ pred, const uint16_t* __restrict__ tgt, int R, int C,
-                                                         int normalize, float* __restrict__ cos_sum, uint16_t* __restrict__ dpred) {
+                                                         int normalize, float* __restrict__ cos_sum, uint16_t* __restrict__ dpred,
+                                                         float* __restrict__ row_out) {
     const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -400,7 +406,10 @@ __global__ __launch_bounds__(NT) void cosine_loss_kernel(const uint16_t* __restr
     tt = wave_sum(tt); uu = wave_sum(uu); tu = wave_sum(tu);
     const float nt = fmaxf(sqrtf(tt), 1e-8f), nu = fmaxf(sqrtf(uu), 1e-8f);
     const float c = tu / (nt * nu);
-    if (lane == 0) atomicAdd(cos_sum, c);
+    if (lane == 0) {
+        if (row_out) row_out[row] = c;
+        else atomicAdd(cos_sum, c);
+    }
     if (!dpred) return;
     // w = d cos / d u = (t/nt - c * u/nu) / nu ;  d u / d p = (I - phat phat^T) / pn
     const float inv_r = -1.0f / (float)R;
@@ -727,20 +736,32 @@ extern "C" int mm355_layernorm_bwd(const mm355_bf16* dy, const mm355_bf16* x, co
     return mm_launch_status();
 }
 
-extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V, float grad_scale,
-                             float* loss_sum, void* stream) {
+extern "C" int mm355_sum_rows_f32(const float* values, int64_t n, float scale, float* out, int accumulate, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
-    if (!logits || !targets || !loss_sum || R <= 0 || V <= 0 || ld < V || (ld & 7) || R > 0x7fffffff || !mm_aligned16(logits)) return MM355_EINVAL;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(CE_NT), 0, (hipStream_t)stream, logits, ld, targets, (int)V, grad_scale, loss_sum);
+    if (!values || !out || n <= 0) return MM355_EINVAL;
+    hipLaunchKernelGGL(mm_sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, values, n, scale, out, accumulate);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_ce_rows(mm355_bf16* logits, int64_t ld, const int32_t* targets, int64_t R, int64_t V, float grad_scale,
+                             float* loss_sum, float* row_ws, void* stream) {
+    (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
+    if (!logits || !targets || (!loss_sum && !row_ws) || R <= 0 || V <= 0 || ld < V || (ld & 7) || R > 0x7fffffff || !mm_aligned16(logits))
+        return MM355_EINVAL;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(CE_NT), 0, (hipStream_t)stream, logits, ld, targets, (int)V, grad_scale, loss_sum,
+                       row_ws);
+    if (row_ws && loss_sum) hipLaunchKernelGGL(mm_sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)row_ws, R, 1.0f, loss_sum, 1);
     return mm_launch_status();
 }
 
 extern "C" int mm355_cosine_loss(const mm355_bf16* pred_raw, const mm355_bf16* target, int64_t R, int64_t C, int normalize,
-                                 float* cos_sum, mm355_bf16* dpred, void* stream) {
+                                 float* cos_sum, mm355_bf16* dpred, float* row_ws, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!pred_raw || !target || !cos_sum || R <= 0 || C <= 0 || (C & 7)) return MM355_EINVAL;
     const unsigned grid = (unsigned)((R + NT / 64 - 1) / (NT / 64));
-    hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize, cos_sum, dpred);
+    hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred_raw, target, (int)R, (int)C, normalize, cos_sum, dpred,
+                       row_ws);
+    if (row_ws) hipLaunchKernelGGL(mm_sum_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)row_ws, R, 1.0f, cos_sum, 1);
     return mm_launch_status();
 }
 

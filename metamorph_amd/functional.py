@@ -1199,50 +1199,21 @@ CE_CHUNK = 8192
 
 
 class LinearCrossEntropyFn(Function):
-    """loss = mean over rows with a target of CE(hidden_r @ W^T, target_r).
+    """loss = mean over rows with a target of CE(hidden_r @ W^T, target_r) -- ONE library call (mm355_linear_ce, include/mm355.h).
 
     Rows without a target were already dropped by the host plan (`ce_rows`), so no flop is spent on
-    ignored positions.  Per chunk of rows: logits GEMM (bf16) -> fp32 softmax / NLL kernel that overwrites
-    the logits with d loss / d logits -> the two gradient GEMMs.  The [M,V] fp32 logits tensor of the
-    reference (metamorph_llama.py:398-399) never exists.
+    ignored positions.  Inside the library, per chunk of 8192 rows: logits GEMM (bf16) -> fp32 softmax / NLL kernel that overwrites
+    the logits with d loss / d logits -> the two gradient GEMMs; the per-row NLL values are summed in a fixed order (bit-reproducible
+    loss).  The [M,V] fp32 logits tensor of the reference (metamorph_llama.py:398-399) never exists.
     """
 
     @staticmethod
     def forward(ctx, hidden, weight, head_module, plan_dev, n_valid):
-        dev = hidden.device
-        V, h = weight.shape
-        Vp = (V + 127) // 128 * 128                        # whole pairs of 64-wide K tiles for the dX GEMM (ping-pong kernel)
-        rows = plan_dev["ce_rows"]                          # int32 [n_valid]
-        tgt = plan_dev["ce_targets"]                        # int32 [n_valid]
-        need_dh = hidden.requires_grad
-        need_dw = weight.requires_grad
-        loss_sum = torch.zeros(1, device=dev, dtype=torch.float32)
-        hc = ops.rows_gather(hidden, rows)                  # compact [n_valid, h]
-        dhc = torch.empty_like(hc) if need_dh else None
-        wt = None
-        if need_dh:
-            wt = torch.empty((h, Vp), device=dev, dtype=BF16)
-            if Vp != V:
-                wt[:, V:].zero_()                             # only the padding columns (K tail of the dX GEMM)
-            ops.transpose(weight, out=wt[:, :V])
-        # chunks accumulate in fp32 (a bf16 running sum would lose the small chunks once n_valid >> CE_CHUNK); rounded once in backward
-        dw = torch.empty((V, h), device=dev, dtype=BF16 if n_valid <= CE_CHUNK else torch.float32) if need_dw else None
-        inv = 1.0 / max(n_valid, 1)
-        first = True
-        for r0 in range(0, n_valid, CE_CHUNK):
-            r1 = min(n_valid, r0 + CE_CHUNK)
-            logits = torch.empty((r1 - r0, Vp), device=dev, dtype=BF16)
-            ops.gemm(hc[r0:r1], weight, out=logits, n=V)
-            ops.ce_rows_(logits, tgt[r0:r1], V, inv, loss_sum)   # logits <- d loss / d logits (padding cols 0)
-            if need_dh:
-                ops.gemm(logits, wt, out=dhc[r0:r1])
-            if need_dw:
-                weight_grad_gemm(logits[:, :V], hc[r0:r1], dw, not first)
-            first = False
-            del logits
+        loss, dhc, dw = ops.linear_ce(hidden, plan_dev["ce_rows"], plan_dev["ce_targets"], weight, need_dh=hidden.requires_grad,
+                                      need_dw=weight.requires_grad, dw_f32=n_valid > CE_CHUNK)
         ctx.head_module, ctx.plan, ctx.hidden_shape = head_module, plan_dev, hidden.shape
         ctx.save_for_backward(dhc, dw)
-        return (loss_sum * inv).reshape(())
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):

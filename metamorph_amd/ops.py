@@ -620,11 +620,40 @@ def axpy_(y, x, s_dev=None, s_host=1.0, accumulate=True):
 
 # ------------------------------------------------------------------------------------------------ losses
 
-def ce_rows_(logits2d, targets_i32, V, grad_scale, loss_sum_f32):
+def linear_ce(hidden, rows, targets, weight, need_dh=True, need_dw=True, dw_f32=None):
+    """mm355_linear_ce: mean NLL of softmax(hidden[rows] @ weight^T) at `targets`, plus d loss / d hidden[rows] (compact [n, h] bf16) and
+    d loss / d weight ([V, h]; fp32 when more than one 8192-row chunk accumulates into it, else bf16) -> (loss f32 [1], d_hidden | None,
+    dW | None).  hidden [M, h] bf16 (row-strided view allowed); rows / targets int32 [n] on the device (rows None: the first n rows)."""
+    _chk_dev(hidden, rows, targets, weight)
+    ph, M, h, ldh = _rows2d(hidden)
+    pw, V, hw, ldw = _rows2d(weight)
+    n = int(targets.numel())
+    assert hw == h and hidden.dtype == BF16 and weight.dtype == BF16 and targets.dtype == torch.int32 and n > 0
+    assert rows is None or (rows.dtype == torch.int32 and rows.numel() == n)
+    dev = hidden.device
+    if dw_f32 is None:
+        dw_f32 = n > 8192
+    loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    dh = torch.empty((n, h), device=dev, dtype=BF16) if need_dh else None
+    dw = torch.empty((V, h), device=dev, dtype=torch.float32 if dw_f32 else BF16) if need_dw else None
+    nbytes = int(_L().mm355_linear_ce_ws_bytes(n, V, h, int(rows is not None), int(need_dh), int(need_dw)))
+    ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    _lib.check(_L().mm355_linear_ce(ph, ldh, _p(rows), targets.data_ptr(), n, pw, ldw, V, h, loss.data_ptr(), _p(dh), _p(dw), int(bool(dw_f32)),
+                                    ws.data_ptr(), nbytes, _stream()), f"mm355_linear_ce n={n} V={V} h={h}")
+    return loss, dh, dw
+
+
+def _row_ws(R, device, deterministic=True):
+    """R floats for the per-row loss values (summed in a fixed order -> bit-reproducible loss scalars); None = atomics (tests only)."""
+    return torch.empty((R,), device=device, dtype=torch.float32) if deterministic else None
+
+
+def ce_rows_(logits2d, targets_i32, V, grad_scale, loss_sum_f32, deterministic=True):
     _chk_dev(logits2d, targets_i32, loss_sum_f32)
     p, R, _, ld = _rows2d(logits2d)
     assert targets_i32.dtype == torch.int32 and targets_i32.numel() >= R
-    _lib.check(_L().mm355_ce_rows(p, ld, targets_i32.data_ptr(), R, V, grad_scale, loss_sum_f32.data_ptr(), _stream()), "mm355_ce_rows")
+    ws = _row_ws(R, logits2d.device, deterministic)
+    _lib.check(_L().mm355_ce_rows(p, ld, targets_i32.data_ptr(), R, V, grad_scale, loss_sum_f32.data_ptr(), _p(ws), _stream()), "mm355_ce_rows")
 
 
 def cosine_loss(pred_raw, target, normalize, want_grad=True):
@@ -633,8 +662,8 @@ def cosine_loss(pred_raw, target, normalize, want_grad=True):
     R, C = pred_raw.shape
     cos_sum = torch.zeros((1,), device=pred_raw.device, dtype=torch.float32)
     dpred = torch.empty_like(pred_raw) if want_grad else None
-    _lib.check(_L().mm355_cosine_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(normalize), cos_sum.data_ptr(), _p(dpred), _stream()),
-               "mm355_cosine_loss")
+    _lib.check(_L().mm355_cosine_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(normalize), cos_sum.data_ptr(), _p(dpred),
+                                      _p(_row_ws(R, pred_raw.device)), _stream()), "mm355_cosine_loss")
     return cos_sum, dpred
 
 
@@ -645,7 +674,8 @@ def mean_abs_loss(pred, target, want_grad=True):
     R, C = pred.shape
     abs_sum = torch.zeros((1,), device=pred.device, dtype=torch.float32)
     dpred = torch.empty_like(pred) if want_grad else None
-    _lib.check(_L().mm355_mean_abs_loss(pred.data_ptr(), target.data_ptr(), R, C, abs_sum.data_ptr(), _p(dpred), _stream()), "mm355_mean_abs_loss")
+    _lib.check(_L().mm355_mean_abs_loss(pred.data_ptr(), target.data_ptr(), R, C, abs_sum.data_ptr(), _p(dpred), _p(_row_ws(R, pred.device)),
+                                        _stream()), "mm355_mean_abs_loss")
     return abs_sum, dpred
 
 
@@ -658,7 +688,7 @@ def soft_ce_loss(pred_raw, target, normalize, temperature=0.07, want_grad=True):
     loss_sum = torch.zeros((1,), device=pred_raw.device, dtype=torch.float32)
     dpred = torch.empty_like(pred_raw) if want_grad else None
     _lib.check(_L().mm355_soft_ce_loss(pred_raw.data_ptr(), target.data_ptr(), R, C, int(bool(normalize)), float(temperature),
-                                       loss_sum.data_ptr(), _p(dpred), _stream()), "mm355_soft_ce_loss")
+                                       loss_sum.data_ptr(), _p(dpred), _p(_row_ws(R, pred_raw.device)), _stream()), "mm355_soft_ce_loss")
     return loss_sum, dpred
 
 

@@ -47,9 +47,37 @@ def _layer_weights(fetch, i, requires_grad=False):
     return w
 
 
+def _to_cpu(o):
+    if isinstance(o, torch.Tensor):
+        return o.detach().cpu()
+    if isinstance(o, dict):
+        return {k: _to_cpu(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_cpu(v) for v in o)
+    return o
+
+
 def full_depth(fetch, cfg: RM.OracleConfig, input_ids, attention_mask, labels, images, probe_layers=(), grad_layers=(),
-               head_grads=True, backward=True, log=None, embed_grad=False):
+               head_grads=True, backward=True, log=None, embed_grad=False, device=None):
     """fp32 forward (and backward) of the whole model, layer-streamed.  Right padding only.
+
+    device: None = where the inputs live (the host: the oracle's home, and the only place its bf16 run means "the reference stack's bf16
+    arithmetic").  "cuda": the SAME functions evaluated with stock torch fp32 ops on the GPU (weights moved as they are fetched; every
+    result returned on the host) -- the full-width fp32 runs of the GPU parity tests take seconds instead of minutes of host GEMMs; the
+    device evaluation is itself pinned to the reference's recorded fp32 run and to the host evaluation (tests/test_model_gpu.py
+    test_streamed_oracle_on_device_*)."""
+    if device is not None:
+        dev = torch.device(device)
+        mv = lambda t: None if t is None else t.to(dev)
+        with torch.device(dev):
+            out = _full_depth(lambda k: fetch(k).to(dev), cfg, mv(input_ids), mv(attention_mask), mv(labels), mv(images), probe_layers,
+                              grad_layers, head_grads, backward, log, embed_grad)
+        return _to_cpu(out)
+    return _full_depth(fetch, cfg, input_ids, attention_mask, labels, images, probe_layers, grad_layers, head_grads, backward, log, embed_grad)
+
+
+def _full_depth(fetch, cfg, input_ids, attention_mask, labels, images, probe_layers, grad_layers, head_grads, backward, log, embed_grad):
+    """(the body of full_depth: every tensor is created next to the inputs)
 
     Returns a dict: raw_hidden [N, P, hv] (tower, hidden_states[-1]), features, projected, labels / attention_mask /
     image_positions (spliced, as `ref_model.forward`), probes {n: [B, L, h] hidden rows after n decoder layers (zeros on padding)},

@@ -758,6 +758,89 @@ def test_ce_rows(ops):
     assert float(dev[5].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", [dict(n=300, M=420, V=1003, h=256, gather=True), dict(n=64, M=64, V=128258, h=256, gather=False),
+                                  dict(n=9001, M=9500, V=520, h=128, gather=True)])
+def test_linear_ce_entry_point_through_ctypes_only(case):
+    """mm355_linear_ce (SURVEY 8(b) `linear_ce`; reference metamorph_llama.py:393-413) driven with NOTHING but ctypes + raw device pointers
+    (torch only owns the memory) against oracle.ref_ops: mean NLL, d hidden, d W.  n = 9001: two 8192-row chunks accumulating into an
+    fp32 dW, ragged second chunk.  Two identical calls return bit-identical loss / gradients (fixed-order row sum, no atomics)."""
+    import ctypes
+    from metamorph_amd import lib as mmlib
+    L = mmlib.load()
+    n, M, V, h = case["n"], case["M"], case["V"], case["h"]
+    g = torch.Generator().manual_seed(n)
+    hid = (torch.randn(M, h, generator=g) * 1.0).bfloat16()
+    W = (torch.randn(V, h, generator=g) * 0.08).bfloat16()
+    rows = torch.randperm(M, generator=g)[:n].sort().values.to(torch.int32) if case["gather"] else None
+    tgt = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
+    tgt[0], tgt[-1] = V - 1, 0
+    # oracle: the reference's arithmetic -- bf16 linear, .float(), mean CE (fp32) -- and autograd for the gradients
+    x = (hid[rows.long()] if rows is not None else hid[:n]).float().requires_grad_(True)
+    Wf = W.float().requires_grad_(True)
+    logits = (x @ Wf.t()).bfloat16().float()
+    logits_g = (x @ Wf.t())
+    logits_g.data = logits                                          # straight-through the bf16 rounding of the logits
+    loss_ref = torch.nn.functional.cross_entropy(logits_g, tgt.long())
+    loss_ref.backward()
+    dw_f32 = n > 8192
+    d = lambda t: t.to(DEV)
+    hid_d, W_d, tgt_d = d(hid), d(W), d(tgt)
+    rows_d = d(rows) if rows is not None else None
+    nbytes = L.mm355_linear_ce_ws_bytes(n, V, h, int(rows is not None), 1, 1)
+    assert nbytes > 0
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
+        loss = torch.full((1,), float("nan"), device=DEV)
+        dh = torch.full((n, h), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dw = torch.full((V, h), float("nan"), device=DEV, dtype=torch.float32 if dw_f32 else torch.bfloat16)
+        rc = L.mm355_linear_ce(hid_d.data_ptr(), h, rows_d.data_ptr() if rows_d is not None else None, tgt_d.data_ptr(), n, W_d.data_ptr(), h, V, h,
+                               loss.data_ptr(), dh.data_ptr(), dw.data_ptr(), int(dw_f32), ws.data_ptr(), nbytes, stream)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return loss, dh, dw
+
+    loss, dh, dw = run()
+    close(loss[0], loss_ref.detach(), 1e-3, 1e-4, "linear_ce loss")
+    close(dh, x.grad, 2e-2, 2e-2 * float(x.grad.abs().max()), "linear_ce d hidden")
+    close(dw, Wf.grad, 2e-2, 2e-2 * float(Wf.grad.abs().max()), "linear_ce d W")
+    loss2, dh2, dw2 = run()
+    assert torch.equal(loss, loss2) and torch.equal(dh, dh2) and torch.equal(dw, dw2)          # bit-reproducible
+    # loss only (evaluation): no gradient buffers, a smaller workspace
+    nb0 = L.mm355_linear_ce_ws_bytes(n, V, h, int(rows is not None), 0, 0)
+    assert 0 < nb0 < nbytes
+    ws0, l0 = torch.empty(nb0, device=DEV, dtype=torch.uint8), torch.zeros(1, device=DEV)
+    assert L.mm355_linear_ce(hid_d.data_ptr(), h, rows_d.data_ptr() if rows_d is not None else None, tgt_d.data_ptr(), n, W_d.data_ptr(), h, V, h,
+                             l0.data_ptr(), None, None, 0, ws0.data_ptr(), nb0, stream) == 0
+    assert torch.equal(l0, loss)
+    assert L.mm355_linear_ce(hid_d.data_ptr(), h, None, tgt_d.data_ptr(), n, W_d.data_ptr(), h, V, h, l0.data_ptr(), None, None, 0, ws0.data_ptr(),
+                             nb0 // 2, stream) == -1                                               # workspace too small: MM355_EINVAL
+
+
+def test_loss_scalars_are_bit_reproducible(ops):
+    """CE / cosine / soft-CE / mean-abs sums go through per-row values + ONE fixed-order reduction (row_ws), not one fp32 atomicAdd per row:
+    five calls on the same inputs return the same bits (DESIGN section 8 carried "loss scalar not bit-reproducible" since round 2)."""
+    Rr, C, V = 4099, 1152, 2048
+    p, t = rnd(Rr, C, seed=11).to(DEV), rnd(Rr, C, seed=12).to(DEV)
+    lg = rnd(Rr, V, seed=13, scale=3.0).to(DEV)
+    tg = torch.randint(0, V, (Rr,), generator=torch.Generator().manual_seed(14), dtype=torch.int32).to(DEV)
+
+    def once():
+        ls = torch.zeros(1, device=DEV)
+        ops.ce_rows_(lg.clone(), tg, V, 1.0, ls)
+        return (ls.clone(), ops.cosine_loss(p, t, 1)[0].clone(), ops.soft_ce_loss(p, ops.softmax_rows(t), True)[0].clone(),
+                ops.mean_abs_loss(p, t)[0].clone())
+
+    first = once()
+    for _ in range(4):
+        assert all(torch.equal(a, b) for a, b in zip(first, once()))
+    # the atomics form (row_ws = NULL, kept in the ABI) sums the same values: equal up to summation order
+    ls_a = torch.zeros(1, device=DEV)
+    ops.ce_rows_(lg.clone(), tg, V, 1.0, ls_a, deterministic=False)
+    close(ls_a, first[0], 1e-5, 0, "atomics vs fixed order")
+
+
 def test_cosine_loss(ops):
     Rr, C = 21, 1152
     p, t = rnd(Rr, C, seed=1), R.l2_normalize(rnd(Rr, C, seed=2).float()).bfloat16()

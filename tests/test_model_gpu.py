@@ -24,6 +24,46 @@ from oracle.ref_model import OracleConfig, forward as oracle_forward, init_state
 
 DEV = "cuda"
 
+# ---- the full-width / full-depth tests (GPUTEST budget: the whole -m gpu suite must fit the driver's step limit)
+# (1) their fp32 oracle is evaluated with stock torch fp32 ops ON THE GPU by default (oracle/ref_stream.full_depth(device=...): same
+#     functions, seconds instead of minutes of host GEMMs; pinned to the reference's recorded fp32 run and to the host evaluation by
+#     test_streamed_oracle_on_device_*).  MM355_ORACLE_FP32_DEVICE=cpu restores the host evaluation.
+# (2) their bf16 YARDSTICK -- the oracle run in bf16 on the host, i.e. the reference stack's own bf16 arithmetic, whose distance from the
+#     fp32 truth bounds what "within bf16 tolerance" means at that depth -- is a deterministic function of the seeded weights and inputs:
+#     it is recorded once (MM355_RECORD_YARDSTICK=1 pytest ... -> gpurun_out/r6_bf16_yardstick.json) and committed as
+#     tests/golden/r6_bf16_yardstick.json together with the fp32 oracle's loss on the same inputs, which every run re-checks (a changed
+#     seed / batch / weight generator fails loudly instead of silently using a stale yardstick).  No entry for a key: the yardstick is
+#     computed on the spot, as before.
+ORACLE_FP32_DEVICE = os.environ.get("MM355_ORACLE_FP32_DEVICE", "cuda")
+RECORD_YARDSTICK = os.environ.get("MM355_RECORD_YARDSTICK") == "1"
+YARDSTICK_PATH = os.path.join(GOLDEN, "r6_bf16_yardstick.json")
+
+
+def load_yardstick(key):
+    if RECORD_YARDSTICK or not os.path.exists(YARDSTICK_PATH):
+        return None
+    with open(YARDSTICK_PATH) as f:
+        return json.load(f).get(key)
+
+
+def record_yardstick(key, rec):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "r6_bf16_yardstick.json")
+    allr = json.load(open(path)) if os.path.exists(path) else {}
+    allr[key] = rec
+    with open(path, "w") as f:
+        json.dump(allr, f, indent=1, sort_keys=True)
+
+
+def oracle_fp32(fetch_host, fetch_dev, cfg, ids, mask, labels, images_f32, **kw):
+    """The layer-streamed fp32 oracle on ORACLE_FP32_DEVICE (results always on the host).  fetch_host(k) -> fp32 host tensor,
+    fetch_dev(k) -> fp32 device tensor of the same values."""
+    from oracle.ref_stream import full_depth
+    if ORACLE_FP32_DEVICE == "cpu" or RECORD_YARDSTICK:
+        return full_depth(fetch_host, cfg, ids, mask, labels, images_f32, **kw)
+    return full_depth(fetch_dev, cfg, ids, mask, labels, images_f32, device=ORACLE_FP32_DEVICE, **kw)
+
 
 def T(a):
     return torch.from_numpy(np.asarray(a))
@@ -1114,47 +1154,73 @@ def test_configs0_tinyllama_real_widths_against_oracle():
     assert n >= 20
 
 
-# ------------------------------------------------------------------ BASELINE configs[2] shape: L = 4096, 8 interleaved frames
-def test_configs2_shape_8_frames_seq4096_against_oracle():
-    """BASELINE configs[2] (VideoQA): LLaMA-3-8B widths (h 4096, 32/8 heads of 128, I 14336, V 128258), spliced length exactly 4096
-    with EIGHT prompt-side frames of 256 tokens each (SO400M/14-384 tower geometry, 729 -> 256 interpolation), two decoder and two
-    tower layers so the fp32 oracle finishes in well under a minute on the host cores.  A second, shorter sample carries an
-    answer-side frame after two prompt frames (ragged lengths + the regression head at full width)."""
-    cfg = OracleConfig(num_hidden_layers=2, v_layers=2, num_image_tokens=256, tokenizer_model_max_length=4096)
-    g = torch.Generator().manual_seed(4321)
-    L, T_img = 4096, 256
-    n_ids = L - 8 * (T_img - 1)
-    ids = torch.full((2, n_ids), 128001, dtype=torch.long)
-    row = torch.randint(0, 127999, (n_ids,), generator=g)
-    row[0] = row[1] = 128000
-    for f in range(8):
-        p = 22 + 3 * f
-        row[p], row[p + 1], row[p + 2] = 128256, -200, 128257
-    ids[0] = row
-    lab0 = torch.full((n_ids,), -100, dtype=torch.long)
-    lab0[-512:] = row[-512:]
-    short = 604                                                  # sample 1: 2 prompt frames, text, an answer-side frame, eot; then padding
-    r1 = torch.randint(0, 127999, (short,), generator=g)
-    r1[0] = r1[1] = 128000
-    for p in (10, 13):
-        r1[p], r1[p + 1], r1[p + 2] = 128256, -200, 128257
-    r1[600], r1[601], r1[602], r1[603] = 128256, -200, 128257, 128009
-    ids[1, :short] = r1
-    lab1 = torch.full((n_ids,), -100, dtype=torch.long)
-    lab1[300:604] = r1[300:604]
-    lab1[601] = -200
-    labels = torch.stack([lab0, lab1])
-    mask = ids.ne(128001)
-    n_img = 8 + 3
-    images = torch.randn(n_img, 3, 384, 384, generator=g)
-    # measured (round 3): hidden 8.5e-3, worst gradient 2.1e-2 (layers.1.q_proj) -> 1.5 x
-    n = _fullwidth_check(cfg, ids, labels, mask, images, seed=77, grad_tol=3.2e-2, hidden_tol=1.3e-2, what="configs[2] shape (8 frames, L=4096)",
-                         check_embed_grad=False)
-    assert n >= 20
+# (BASELINE configs[2] -- L = 4096, eight interleaved frames at LLaMA-3-8B widths -- is test_configs2_shape_8_frames_seq4096_eight_layers_*
+#  below: eight decoder layers on the same shape.  Its two-layer twin on the plain oracle, 52 s of host GEMMs for a strict subset of that
+#  coverage, was retired in round 6 to keep the -m gpu suite inside the driver's step limit.)
+
+
+# ------------------------------------------------------------------ the fp32 oracle evaluated on the device (round 6)
+def test_streamed_oracle_on_device_against_reference_recorded_8_layer_run():
+    """oracle/ref_stream.full_depth(device="cuda") -- the evaluation the full-width tests below use for their fp32 truth -- DIRECTLY against
+    the reference: tests/golden/e2e_multi_frame_T4_ar1_deep8_f32.npz is the reference's own fp32 forward + backward of an 8-layer decoder +
+    4-layer tower (the host evaluation passes the same check in tests/test_oracle_stream.py)."""
+    from oracle.ref_stream import full_depth
+    g = np.load(os.path.join(GOLDEN, "e2e_multi_frame_T4_ar1_deep8_f32.npz"))
+    cfg = tiny_cfg(num_image_tokens=4, **json.loads(str(g["cfg_json"])))
+    assert cfg.num_hidden_layers == 8 and cfg.v_layers == 4
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    got = full_depth(lambda k: sd[k].detach().clone(), cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]),
+                     grad_layers=(0, 7), device=DEV)
+    assert all(not v.is_cuda for v in got["grads"].values()) and not got["hidden_states"].is_cuda       # results come back on the host
+    assert abs(got["loss"] - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(got["loss_language"] - float(g["loss_language"])) <= 2e-5 * abs(float(g["loss_language"]))
+    assert abs(got["loss_image_ar"] - float(g["loss_image_ar"])) <= 2e-5
+    valid = got["attention_mask"]
+    torch.testing.assert_close(got["hidden_states"][valid], T(g["hidden"])[valid], rtol=2e-4, atol=2e-5)
+    checked = 0
+    for name, grad in got["grads"].items():
+        torch.testing.assert_close(grad_summary(grad), T(g["grad::" + name]), rtol=5e-4, atol=2e-6)
+        checked += 1
+    assert checked == 18 + 2 + 4 + 4
+
+
+def test_streamed_oracle_on_device_equals_host_evaluation():
+    """The same fp32 oracle run on the host and on the device at a width where GEMM blocking differs (h 1024, 4 layers, 16 / 4 heads of 64,
+    600 + 300 rows, 27 x 27 -> 16 tower tokens): loss to 2e-6, hidden rows to 1e-5, every gradient to 2e-4 -- accumulation-order noise of
+    fp32, three orders of magnitude below anything the bf16 comparisons measure."""
+    from oracle.ref_stream import full_depth
+    cfg = OracleConfig(hidden_size=1024, intermediate_size=2048, num_hidden_layers=4, num_attention_heads=16, num_key_value_heads=4,
+                       vocab_size=32002, v_layers=2, v_intermediate=288, v_image=378, num_image_tokens=16, tokenizer_model_max_length=1024,
+                       image_start_id=32000)
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, 31999, (2, 588), generator=g)
+    ids[:, 0] = 1
+    ids[:, 21], ids[:, 22], ids[:, 23] = 32000, -200, 32001
+    ids[1, 300:] = 0
+    labels = torch.full_like(ids, -100)
+    labels[0, 200:] = ids[0, 200:]
+    labels[1, 18:300] = ids[1, 18:300]
+    labels[1, 22] = -200
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    mask[1, 300:] = False
+    images = torch.randn(2, 3, 378, 378, generator=g)
+    sd = init_state_dict(cfg, seed=12, fast_big=True)
+    kw = dict(probe_layers=(2,), grad_layers=(0, 3), embed_grad=True)
+    host = full_depth(lambda k: sd[k].clone(), cfg, ids, mask, labels, images, **kw)
+    dev = full_depth(lambda k: sd[k].clone(), cfg, ids, mask, labels, images, device=DEV, **kw)
+    assert torch.equal(host["labels"], dev["labels"]) and torch.equal(host["image_positions"], dev["image_positions"]) and host["n_rows"] == dev["n_rows"]
+    assert abs(host["loss"] - dev["loss"]) <= 2e-6 * abs(host["loss"]) and abs(host["loss_image_ar"] - dev["loss_image_ar"]) <= 2e-6
+    va = host["attention_mask"]
+    assert rel(dev["hidden_states"][va], host["hidden_states"][va]) < 1e-5 and rel(dev["probes"][2][va], host["probes"][2][va]) < 1e-5
+    assert rel(dev["raw_hidden"], host["raw_hidden"]) < 1e-5
+    worst = max((rel(dev["grads"][k], v), k) for k, v in host["grads"].items())
+    print(f"\n   device vs host evaluation of the fp32 oracle: worst gradient rel diff {worst[0]:.2e} ({worst[1]}), "
+          f"host {host['seconds']['total']:.1f}s device {dev['seconds']['total']:.1f}s")
+    assert set(dev["grads"]) == set(host["grads"]) and len(host["grads"]) == 18 + 2 + 4 + 4 + 1 and worst[0] < 2e-4
 
 
 # ------------------------------------------------------------------ depth beyond two layers for configs[0] and configs[2] (round 4)
-def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidden_factor=1.15):
+def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidden_factor=1.15, key=None):
     """HIP model (bf16) vs the LAYER-STREAMED fp32 oracle (oracle/ref_stream.py, pinned to the plain oracle by tests/test_oracle_stream.py)
     on the same bf16-rounded weights, with the SAME streamed oracle run in bf16 -- the reference stack's own arithmetic -- as the yardstick
     for what depth does to bf16: loss at 1e-3 (north_star), final hidden rows no farther from the fp32 truth than 1.15 x the bf16
@@ -1173,28 +1239,41 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidde
     NL = cfg.num_hidden_layers
     img16 = images.bfloat16()
     t0 = time.time()
-    ref = full_depth(lambda k: sd16[k].float(), cfg, ids, mask, labels, img16.float(), grad_layers=(0, NL - 1))
+    ref = oracle_fp32(lambda k: sd16[k].float(), lambda k: sd16[k].to(DEV).float(), cfg, ids, mask, labels, img16.float(), grad_layers=(0, NL - 1))
     t1 = time.time()
-    ref16 = full_depth(lambda k: sd16[k], cfg, ids, mask, labels, img16, grad_layers=(0, NL - 1), backward=True)
-    print(f"\n   {what}: streamed oracle fp32 {t1 - t0:.0f}s, bf16 {time.time() - t1:.0f}s; rows per sample {ref['n_rows']}")
+    yard = load_yardstick(key) if key else None
+    if yard is None:
+        ref16 = full_depth(lambda k: sd16[k], cfg, ids, mask, labels, img16, grad_layers=(0, NL - 1), backward=True)
+        va = ref["attention_mask"]
+        yard = dict(oracle_fp32_loss=ref["loss"], loss=ref16["loss"], hidden_final=rel(ref16["hidden_states"].float()[va], ref["hidden_states"][va]),
+                    grads={k: rel(ref16["grads"][k].float(), g) for k, g in ref["grads"].items()}, rows=ref["n_rows"])
+        if RECORD_YARDSTICK and key:
+            record_yardstick(key, yard)
+    else:
+        # the recorded yardstick belongs to THESE weights and inputs: the fp32 oracle must reproduce the loss it was recorded beside
+        assert abs(ref["loss"] - yard["oracle_fp32_loss"]) <= 2e-5 * abs(ref["loss"]) and ref["n_rows"] == yard["rows"], (
+            f"{key}: the fp32 oracle gives loss {ref['loss']} on rows {ref['n_rows']}, the recorded yardstick was taken beside "
+            f"{yard['oracle_fp32_loss']} / {yard['rows']} -- re-record with MM355_RECORD_YARDSTICK=1")
+    print(f"\n   {what}: streamed oracle fp32 ({'host' if ORACLE_FP32_DEVICE == 'cpu' or RECORD_YARDSTICK else ORACLE_FP32_DEVICE}) {t1 - t0:.0f}s, "
+          f"bf16 yardstick {'recorded fixture' if time.time() - t1 < 1 else f'{time.time() - t1:.0f}s on the host'}; rows per sample {ref['n_rows']}")
     assert torch.equal(plan[5].cpu(), ref["labels"]) and torch.equal(plan[6].cpu(), ref["image_positions"])
     assert torch.equal(plan[2].cpu().bool(), ref["attention_mask"])
     got, want = float(out.loss.detach()), ref["loss"]
-    print(f"   loss hip={got:.5f} oracle-fp32={want:.5f} oracle-bf16={ref16['loss']:.5f}  lang {model.loss_language:.5f}/{ref['loss_language']:.5f}  "
+    print(f"   loss hip={got:.5f} oracle-fp32={want:.5f} oracle-bf16={yard['loss']:.5f}  lang {model.loss_language:.5f}/{ref['loss_language']:.5f}  "
           f"img {model.loss_image_ar:.5f}/{ref['loss_image_ar']:.5f}")
     assert abs(got - want) <= 1e-3 * abs(want), (got, want)
     assert abs(model.loss_language - ref["loss_language"]) <= 1e-3 * abs(want)
     assert abs(model.loss_image_ar - ref["loss_image_ar"]) <= 1e-3
     valid = ref["attention_mask"]
     e_h = rel(out.hidden_states.float().cpu()[valid], ref["hidden_states"][valid])
-    e_16 = rel(ref16["hidden_states"].float()[valid], ref["hidden_states"][valid])
+    e_16 = yard["hidden_final"]
     print(f"   final hidden rows after {NL} layers vs fp32: hip {e_h:.3e}  oracle-bf16 {e_16:.3e}")
     assert e_h <= max(hidden_factor * e_16, 8e-3), (e_h, e_16)
     params = dict(model.named_parameters())
     n, worst = 0, (0.0, "", 0.0)
     for k, g in ref["grads"].items():
         assert params[k].grad is not None, k
-        e, e16 = rel(params[k].grad, g), rel(ref16["grads"][k].float(), g)
+        e, e16 = rel(params[k].grad, g), yard["grads"][k]
         worst = max(worst, (e, k, e16))
         assert e <= max(1.5 * e16, 3.3e-2), (k, e, e16)
         n += 1
@@ -1244,7 +1323,8 @@ def test_sharp_attention_logits_of_30_against_streamed_oracle():
     assert float(s0.abs().max()) >= 30.0
     # (sharp softmaxes amplify every bf16 rounding upstream of them: the bf16 oracle itself sits 5 % (hidden) / 5 - 20 % (gradients) from fp32
     # here -- measured on the CPU -- and two equally good roundings differ by chance, hence 1.3 x instead of the depth tests' 1.15 x)
-    assert _depth_check(cfg, ids, labels, mask, images, seed=5, what="sharp attention (logits x 40)", sd_hook=sharpen, hidden_factor=1.3) >= 20
+    assert _depth_check(cfg, ids, labels, mask, images, seed=5, what="sharp attention (logits x 40)", sd_hook=sharpen, hidden_factor=1.3,
+                        key="sharp_attention_logits_30") >= 20
 
 
 def test_configs0_tinyllama_full_depth_22_layers_against_streamed_oracle():
@@ -1264,7 +1344,7 @@ def test_configs0_tinyllama_full_depth_22_layers_against_streamed_oracle():
     labels[1, 22] = -200
     mask = torch.ones_like(ids, dtype=torch.bool)
     images = torch.randn(2, 3, 384, 384, generator=g)
-    assert _depth_check(cfg, ids, labels, mask, images, seed=33, what="configs[0] TinyLlama-1.1B, 22 + 27 layers") == 28
+    assert _depth_check(cfg, ids, labels, mask, images, seed=33, what="configs[0] TinyLlama-1.1B, 22 + 27 layers", key="configs0_22_layers") == 28
 
 
 def test_configs2_shape_8_frames_seq4096_eight_layers_against_streamed_oracle():
@@ -1296,7 +1376,7 @@ def test_configs2_shape_8_frames_seq4096_eight_layers_against_streamed_oracle():
     labels = torch.stack([lab0, lab1])
     mask = ids.ne(128001)
     images = torch.randn(8 + 3, 3, 384, 384, generator=g)
-    assert _depth_check(cfg, ids, labels, mask, images, seed=78, what="configs[2] shape (8 frames, L = 4096), 8 layers") == 28
+    assert _depth_check(cfg, ids, labels, mask, images, seed=78, what="configs[2] shape (8 frames, L = 4096), 8 layers", key="configs2_8_layers") == 28
 
 
 # ------------------------------------------------------------------ BASELINE configs[3]: generation-mode finetune (all samples regress an image)
@@ -1384,7 +1464,8 @@ def test_configs4_shape_70b_widths_zero3_recompute_against_oracle():
         opt.synchronize()
         opt._drain_grad_slots()
         # the oracle, fp32, on the same bf16-rounded weights
-        ref = full_depth(lambda k: sd16[k].float(), cfg, ids, mask, labels, images.bfloat16().float(), grad_layers=(0, 1), embed_grad=True)
+        ref = oracle_fp32(lambda k: sd16[k].float(), lambda k: sd16[k].to(DEV).float(), cfg, ids, mask, labels, images.bfloat16().float(),
+                          grad_layers=(0, 1), embed_grad=True)
         got, want = float(out.loss.detach()), ref["loss"]
         print(f"\n   configs[4] shape (L = {L}, rows {ref['n_rows']}): loss hip={got:.5f} oracle-fp32={want:.5f} img={model.loss_image_ar:.5f}/"
               f"{ref['loss_image_ar']:.5f}  oracle {ref['seconds']['total']:.0f}s")

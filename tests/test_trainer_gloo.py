@@ -96,6 +96,25 @@ def _train(out_dir, per_device_bs, accum, steps):
     return torch.cat([p.data.reshape(-1) for p in model.parameters()])
 
 
+def test_trainer_dataloader_keeps_batches_on_the_host_until_prepare_inputs(tmp_path):
+    """accelerate's prepared DataLoader must NOT place batches on the device itself (device_placement=False), or `_prepare_inputs`
+    never sees a host original to register as a mirror and every step pays the `.cpu()` synchronisation.  Checked on the prepared loader
+    HF's own `get_train_dataloader` returns; the device half (STATS['sync'] stays 0 over a Trainer run) is tests/test_trainer_gpu.py."""
+    from transformers import TrainingArguments
+    from metamorph_amd.trainer import MetaMorphTrainer
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, max_steps=1, use_cpu=True, report_to=[], save_strategy="no",
+                             remove_unused_columns=False, dataloader_num_workers=0, dataloader_pin_memory=False)
+    tr = MetaMorphTrainer(model=Toy(), args=args, train_dataset=_DS(8), zero2_kwargs=dict(
+        shard_update=_oracle_update, sumsq=_oracle_sumsq, clip_coef=_oracle_clip))
+    dl = tr.get_train_dataloader()
+    assert hasattr(dl, "device") and dl.device is None, getattr(dl, "device", "no attribute")     # accelerate: device None <=> no placement
+    batch = next(iter(dl))
+    assert all(v.device.type == "cpu" for v in batch.values())
+    from accelerate import Accelerator
+    plain = Accelerator(cpu=True).prepare(torch.utils.data.DataLoader(_DS(8), batch_size=2))
+    assert plain.device is not None                               # what the loader looks like without the override (placement on)
+
+
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       ACCELERATE_USE_CPU="true")
