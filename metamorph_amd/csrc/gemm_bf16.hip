@@ -696,12 +696,17 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(GemmArgs a) {
 // LDS image per tile as in the other LDS-DMA variants: [256 rows][64 k] for A then B, 128-B rows, 16-B chunk ^ (row & 7).
 // ------------------------------------------------------------------------------------------------
 template <int N> MM_DEV void wait_vmcnt() {
+#if defined(MM355_SWB_ABL) && MM355_SWB_ABL == 3
+    static_assert(N >= 0 && N <= 10, "unsupported count");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#else
     static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8, "unsupported count");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // body of one 256x256 output tile; `bid` = index of the workgroup within ITS problem (the pair kernel below runs two problems
@@ -869,6 +874,42 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             }
         }
     };
+#if defined(MM355_SWB_ABL) && MM355_SWB_ABL == 3
+    // TIMING-ONLY (tools/build_swb_abl.sh 3): the epilogue's HBM traffic of ONE tile -- 32 16-B loads of gate / up rows, 80 16-B stores of
+    // dgu / act^T / dgu^T per thread, at the epilogue's own addresses -- issued INSIDE the K loop, spread evenly over its 256 phases: what a
+    // perfectly overlapped (persistent) kernel would put on the memory system while its matrix pipe runs.  Results are garbage by construction.
+    u32x4 swb_sink = u32x4{0u, 0u, 0u, 0u};
+    auto swb_extra = [&](int pidx) -> int {                  // returns the number of vector-memory ops it issued (0, 1 or 2)
+        int n = 0;
+        const int row_l = lane >> 2, k4 = lane & 3;
+        const int c_wave = n0 + wn * 64;
+        if ((pidx & 7) == 0) {                               // load li = pidx / 8 of 32: (i-block, 8-channel half, gate | up)
+            const int li = pidx >> 3, i = li >> 2, j8 = (li >> 1) & 1, gsel = li & 1;
+            const int grow = min(m0 + wm * 128 + row_l + i * 16, M - 1);
+            const uint16_t* pa = a.res + (int64_t)grow * a.ldr + min(c_wave, a.N - 64) + k4 * 16 + j8 * 8 + gsel * a.N;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(swb_sink) : "v"(pa) : "memory");
+            ++n;
+        }
+        const int s_now = (pidx * 5) >> 4, s_prev = pidx ? ((pidx - 1) * 5) >> 4 : -1;
+        if (s_now != s_prev) {                               // store si of 80: 32 row-major dgu vectors, then 48 transposed 16-B runs
+            const int si = s_now;
+            uint16_t* pa;
+            if (si < 32) {
+                const int i = si >> 2, j8 = (si >> 1) & 1, gsel = si & 1;
+                const int grow = min(m0 + wm * 128 + row_l + i * 16, M - 1);
+                pa = (uint16_t*)a.C + (int64_t)grow * a.ldc + min(c_wave, a.N - 64) + k4 * 16 + j8 * 8 + gsel * a.N;
+            } else {
+                const int t = si - 32, q = t >> 4, it = (t >> 2) & 3, ib = t & 3;
+                const int ch = min(c_wave, a.N - 64) + it * 16 + fq * 4 + (fr & 3);
+                const int r8 = min(m0 + wm * 128 + ib * 32 + 8 * (fr >> 2), M - 8);
+                pa = (q == 0 ? a.aux0 : a.aux1) + (int64_t)(q == 2 ? a.N + ch : ch) * a.ld_aux + r8;
+            }
+            asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(pa), "v"(swb_sink) : "memory");
+            ++n;
+        }
+        return n;
+    };
+#endif
     // one phase; P = phase of the K tile, VM = vmcnt to keep in flight, ISSUE: stage quarter (P + 2) & 3 of tile st,
     // NEXTA: tile + 1 exists (read its A rows block 0 in phase 3)
     auto phase = [&](auto p_c, auto vm_c, auto issue_c, auto nexta_c, int tile, int st) {
@@ -882,6 +923,16 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
             if constexpr (P == 3 && NEXTA) rdA(0, tile + 1);
         }
         if constexpr (ISSUE && ABL != 1) issue((P + 2) & 3, st);
+#if defined(MM355_SWB_ABL) && MM355_SWB_ABL == 3
+        if constexpr (SWB) {
+            // the extra ops sit BEHIND this phase's DMA pieces in the in-order counter: they may stay in flight (VM + n), the pieces older
+            // than them are waited for exactly as before
+            const int nx = swb_extra(tile * 4 + P);
+            if (nx == 0) wait_vmcnt<VM>();
+            else if (nx == 1) wait_vmcnt<VM + 1>();
+            else wait_vmcnt<VM + 2>();
+        } else
+#endif
         if constexpr (ABL != 1) wait_vmcnt<VM>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -906,6 +957,13 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     using I8 = std::integral_constant<int, 8>;
     using T = std::true_type; using F = std::false_type;
 
+#if defined(MM355_SWB_ABL) && MM355_SWB_ABL == 2
+    if constexpr (SWB) {                                     // TIMING-ONLY: no K loop at all -- the epilogue's 896 KB per tile alone
+        __syncthreads();
+        gemm_epilogue_swiglu_bwd(acc, a, smem, m0, n0, wm, wn, wave, lane);
+        return;
+    }
+#endif
     // prologue: quarters 0..5 (tile 0 complete, tile 1 first half) in flight; quarters 0, 1 landed; A rows block 0 of tile 0
 #pragma unroll
     for (int kd = 0; kd < 4; ++kd) issue(kd, 0);
@@ -938,6 +996,17 @@ MM_DEV void gemm_pp_tile(const GemmArgs& a, const int bid, unsigned char* smem) 
     phase(I3{}, I0{}, F{}, F{}, t + 1, 0);
     if (wm == 0) __builtin_amdgcn_s_barrier();               // the first group catches the barrier count up
     __syncthreads();
+#if defined(MM355_SWB_ABL) && (MM355_SWB_ABL == 1 || MM355_SWB_ABL == 3)
+    if constexpr (SWB) {                                     // TIMING-ONLY: the K loop alone (1) / with the epilogue's traffic inside it (3); the
+        float keep = 0.f;                                    // accumulators are consumed so that the MFMAs stay
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 1.2345e-30f) ((float*)a.C)[tid] = keep;
+        return;
+    }
+#endif
     if constexpr (SWI) gemm_epilogue_swiglu(acc, a, smem, m0, tn, wm, wn, wave, lane);
     else if constexpr (SWB) gemm_epilogue_swiglu_bwd(acc, a, smem, m0, n0, wm, wn, wave, lane);
     else if constexpr (ROPE) gemm_epilogue_rope(acc, a, smem, m0, n0, wm, wn, wave, lane);

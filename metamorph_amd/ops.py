@@ -621,7 +621,7 @@ def axpy_(y, x, s_dev=None, s_host=1.0, accumulate=True):
 # ------------------------------------------------------------------------------------------------ losses
 
 def linear_ce(hidden, rows, targets, weight, need_dh=True, need_dw=True, dw_f32=None):
-    """mm355_linear_ce: mean NLL of softmax(hidden[rows] @ weight^T) at `targets`, plus d loss / d hidden[rows] (compact [n, h] bf16) and
+    """mm355_linear_ce: mean NLL of softmax(hidden[rows] . weight^T) at `targets`, plus d loss / d hidden[rows] (compact [n, h] bf16) and
     d loss / d weight ([V, h]; fp32 when more than one 8192-row chunk accumulates into it, else bf16) -> (loss f32 [1], d_hidden | None,
     dW | None).  hidden [M, h] bf16 (row-strided view allowed); rows / targets int32 [n] on the device (rows None: the first n rows)."""
     _chk_dev(hidden, rows, targets, weight)

@@ -275,3 +275,58 @@ def flash_bf16_backward(q, k, v, do, seqlens, causal, scale):
             dk[b, :n, hk] += (ds.t() @ Q) * scale
             dv[b, :n, hk] += pb.t() @ dO
     return o, dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------ the backward streams' own arithmetic
+
+def attn4_backward_model(q, k, v, o, do, lse, seqlens, causal, scale):
+    """CPU model of the ARITHMETIC of the d == 128 backward streams (metamorph_amd/csrc/attn4_bwd.hip, tools/gen_attn4_bwd.py; round 6:
+    the hostile backward cases now assert "at most two bf16 steps from this model" instead of absolute floors around a yardstick).
+
+    What the two kernels compute, and in which precision (not how they schedule it):
+      * delta_i = sum_d bf16(dO) * bf16(O)  in fp32  (mm355_attn_bwd_prep; O = the forward kernel's bf16 output)
+      * the score chains start from fp32 C operands: X = -lse_i * fp32(1 / scale) + q_i . k_j and Y = -delta_i + dO_i . v_j -- fp32 sums of
+        exact bf16 x bf16 products on q, k, v, dO AS STORED (nstat_kernel / the dQ kernel's constant tuples; `lse` = the forward kernel's)
+      * P = exp2(c * X), c = fp32(scale) * fp32(log2 e) (v_mul_f32 + v_exp_f32); masked scores (causal, keys >= the sample's length) are -inf;
+        dS = P * Y in fp32
+      * bf16(P) feeds dV^T += dO^T P, bf16(dS) feeds dK^T += Q^T dS and dQ^T += K^T dS^T (fp32 accumulation; the GQA group sum happens in
+        the dK / dV accumulators); the softmax scale is applied ONCE to the finished dK / dQ accumulators, then one rounding to bf16
+      * query rows >= the sample's length produce dq = 0 (`keep`), key rows >= it dk = dv = 0
+    Both kernels recompute the SAME fp32 X, so one P / dS serves all three gradients here.  Differences between model and kernel:
+    accumulation order inside the MFMAs and v_exp_f32's last bit.
+
+    q [B, L, Hq, 128], k / v [B, L, Hkv, 128], o / do [B, L, Hq, 128] bf16, lse [B, Hq, L] fp32 (CPU) -> dq, dk, dv bf16 in the same layouts."""
+    B, L, Hq, d = q.shape
+    assert d == D
+    Hkv = k.shape[2]
+    rep = Hq // Hkv
+    c = sl2_of(scale)
+    inv_scale = f32(1.0) / f32(scale)
+    bf = torch.bfloat16
+    dq = torch.zeros(B, L, Hq, d, dtype=bf)
+    dk = torch.zeros(B, L, Hkv, d, dtype=bf)
+    dv = torch.zeros(B, L, Hkv, d, dtype=bf)
+    for b in range(B):
+        n = L if seqlens is None else min(int(seqlens[b]), L)
+        if n == 0:
+            continue
+        for hk in range(Hkv):
+            K, V = k[b, :n, hk].float(), v[b, :n, hk].float()
+            dk_acc = torch.zeros(n, d)
+            dv_acc = torch.zeros(n, d)
+            for hq in range(hk * rep, (hk + 1) * rep):
+                Q, dO, O = q[b, :n, hq].float(), do[b, :n, hq].float(), o[b, :n, hq].float()
+                delta = (dO * O).sum(-1)
+                X = (-lse[b, hq, :n] * inv_scale)[:, None] + Q @ K.t()
+                Y = -delta[:, None] + dO @ V.t()
+                P = torch.exp2(c * X)
+                if causal:
+                    P = P.masked_fill(~torch.ones(n, n, dtype=torch.bool).tril(), 0.0)
+                dS = P * Y
+                Pb, dSb = P.to(bf).float(), dS.to(bf).float()
+                dv_acc += Pb.t() @ dO
+                dk_acc += dSb.t() @ Q
+                dq[b, :n, hq] = ((dSb @ K) * f32(scale)).to(bf)
+            dk[b, :n, hk] = (dk_acc * f32(scale)).to(bf)
+            dv[b, :n, hk] = dv_acc.to(bf)
+    return dq, dk, dv

@@ -55,3 +55,38 @@ def test_rounds_1_to_4_arithmetic_is_worse_at_large_scores():
     rms = lambda x: float((x.float() - ref).pow(2).mean().sqrt())
     assert rms(new) <= 1.2 * rms(fl)
     assert rms(old) >= 2.0 * rms(new), (rms(old), rms(new), rms(fl))
+
+
+@pytest.mark.parametrize("kind,B,L,Hq,Hkv,seqlens", [("benign", 2, 300, 2, 1, [300, 77]), ("wide", 1, 513, 4, 1, None), ("sink", 1, 400, 2, 2, None),
+                                                      ("cliff", 2, 320, 2, 1, [320, 0])])
+def test_backward_model_against_fp32_autograd_and_the_flash_yardstick(kind, B, L, Hq, Hkv, seqlens):
+    """The model of the backward streams' arithmetic (attn4_backward_model: what tests/test_attn_hostile_gpu.py holds the kernels to, two
+    bf16 steps) is itself a sane backward: on benign scores within the bf16 flash yardstick's distance of the fp32 autograd truth (x 1.5);
+    on hostile scores it shows the arithmetic's known price (P ~ 1 rounded to bf16 after the lse subtraction: dv under a dominant sink) --
+    bounded relative to the gradient's magnitude; zero rows beyond a sample's length; the GQA group sum in dk / dv."""
+    q, k, v = M.hostile_inputs(kind, B, L, Hq, Hkv, seed=2)
+    g = torch.Generator().manual_seed(9)
+    do = (torch.randn(B, L, Hq, M.D, generator=g) * 0.5).to(torch.bfloat16)
+    valid = None
+    if seqlens is not None:
+        valid = torch.arange(L)[None] < torch.tensor(seqlens)[:, None]
+        do = do * valid[:, :, None, None]
+    o, lse, _ = M.attn4_forward_model(q, k, v, seqlens, True, SCALE)
+    dq, dk, dv = M.attn4_backward_model(q, k, v, o, do, lse, seqlens, True, SCALE)
+    qf, kf, vf = (t.transpose(1, 2).float().requires_grad_(True) for t in (q, k, v))
+    ref = R.attention(qf, kf, vf, valid, causal=True)
+    ref = torch.nan_to_num(ref)                                   # (a sample of length 0: fully masked rows)
+    (ref * do.transpose(1, 2).float()).sum().backward()
+    _, fq, fk, fv = M.flash_bf16_backward(q, k, v, do, seqlens, True, SCALE)
+    for name, m, y, t in (("dq", dq, fq, qf.grad.transpose(1, 2)), ("dk", dk, fk, kf.grad.transpose(1, 2)), ("dv", dv, fv, vf.grad.transpose(1, 2))):
+        t = torch.nan_to_num(t)
+        if seqlens is not None:
+            for b in range(B):
+                if seqlens[b] < L:
+                    assert float(m[b, seqlens[b]:].float().abs().max()) == 0, (name, b)
+        nrm = float(t.norm().clamp_min(1e-20))
+        e_m, e_f = float((m.float() - t).norm()) / nrm, float((y - t).norm()) / nrm
+        if kind == "benign":
+            assert e_m <= 1.5 * e_f + 1e-3, (name, e_m, e_f)
+        else:
+            assert e_m <= 3.0 * e_f + 2e-2, (kind, name, e_m, e_f)

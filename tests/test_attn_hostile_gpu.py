@@ -204,7 +204,19 @@ def test_attn4_backward_on_hostile_scores(ops, case):
     _, fq, fk, fv = M.flash_bf16_backward(q, k, v, do, seqlens, True, SCALE)
     got = res[4].cpu().float()
     gq, gk, gv = got[:, :nq].view(B, L, Hq, D), got[:, nq:nq + nk].view(B, L, Hkv, D), got[:, nq + nk:].view(B, L, Hkv, D)
-    line = [f"\n   {kind:9s} B={B} L={L} {Hq}/{Hkv}"]
+    # the streams' OWN arithmetic (tests/attn4_model.attn4_backward_model: fp32 chains from -lse / scale and -delta, P and dS rounded to bf16
+    # before the gradient products, scale applied once to the finished accumulators) on the forward kernel's own o / lse: the kernel may
+    # differ from it by accumulation order and v_exp_f32's last bit only -- at most two bf16 steps at the tensor's magnitude, whatever the
+    # scores look like.  (The looser comparisons with the fp32 truth further down say how good that ARITHMETIC is, not whether the kernel
+    # implements it: in `sink` / `cliff` dv sits 10^3 x farther from fp32 than the flash yardstick because P ~ 1 is rounded to bf16 after the
+    # lse subtraction -- and exactly as far as this model.)
+    mq, mk, mv = M.attn4_backward_model(q, k, v, o.view(B, L, Hq, D).cpu(), do, lse.cpu(), seqlens, True, SCALE)
+    for name, x, m in (("dq", gq, mq), ("dk", gk, mk), ("dv", gv, mv)):
+        mmax = float(m.float().abs().max())
+        e_m = float((x - m.float()).abs().max())
+        assert e_m <= 2.0 ** -6 * max(mmax, 1e-30), (name, "more than two bf16 steps from the model of its own arithmetic", e_m, mmax)
+    line = [f"\n   {kind:9s} B={B} L={L} {Hq}/{Hkv} (vs own-arithmetic model: dq {float((gq - mq.float()).abs().max()):.1e} dk {float((gk - mk.float()).abs().max()):.1e} "
+            f"dv {float((gv - mv.float()).abs().max()):.1e})"]
     for name, x, y, t in (("dq", gq, fq, qf.grad.transpose(1, 2)), ("dk", gk, fk, kf.grad.transpose(1, 2)), ("dv", gv, fv, vf.grad.transpose(1, 2))):
         if seqlens is not None:                                  # rows beyond a sample's length: exact zeros
             for b in range(B):

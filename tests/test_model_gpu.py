@@ -1242,6 +1242,7 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidde
     ref = oracle_fp32(lambda k: sd16[k].float(), lambda k: sd16[k].to(DEV).float(), cfg, ids, mask, labels, img16.float(), grad_layers=(0, NL - 1))
     t1 = time.time()
     yard = load_yardstick(key) if key else None
+    from_fixture = yard is not None
     if yard is None:
         ref16 = full_depth(lambda k: sd16[k], cfg, ids, mask, labels, img16, grad_layers=(0, NL - 1), backward=True)
         va = ref["attention_mask"]
@@ -1255,7 +1256,7 @@ def _depth_check(cfg, ids, labels, mask, images, seed, what, sd_hook=None, hidde
             f"{key}: the fp32 oracle gives loss {ref['loss']} on rows {ref['n_rows']}, the recorded yardstick was taken beside "
             f"{yard['oracle_fp32_loss']} / {yard['rows']} -- re-record with MM355_RECORD_YARDSTICK=1")
     print(f"\n   {what}: streamed oracle fp32 ({'host' if ORACLE_FP32_DEVICE == 'cpu' or RECORD_YARDSTICK else ORACLE_FP32_DEVICE}) {t1 - t0:.0f}s, "
-          f"bf16 yardstick {'recorded fixture' if time.time() - t1 < 1 else f'{time.time() - t1:.0f}s on the host'}; rows per sample {ref['n_rows']}")
+          f"bf16 yardstick {'from the recorded fixture' if from_fixture else f'{time.time() - t1:.0f}s on the host'}; rows per sample {ref['n_rows']}")
     assert torch.equal(plan[5].cpu(), ref["labels"]) and torch.equal(plan[6].cpu(), ref["image_positions"])
     assert torch.equal(plan[2].cpu().bool(), ref["attention_mask"])
     got, want = float(out.loss.detach()), ref["loss"]

@@ -1,12 +1,12 @@
 #!/bin/bash
 # The round-6 evidence run: everything profiles/r6_* is copied from.  Usage on the GPU box, from the repo root:
-#   bash tools/gpu_round6_profiles.sh [tests] [bench] [pmc] [modes] [decode] [attn] [vendor]     (no argument: all)
+#   bash tools/gpu_round6_profiles.sh [tests] [bench] [pmc] [modes] [decode] [attn] [swbabl] [vendor]     (no argument: all)
 # Output: gpurun_out/r6p/*.  rocprofv3 runs from /tmp (TMPDIR=/tmp).  Counter passes are SEPARATE runs with --kernel-trace only
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots"; gpurun refuses --pmc with other trace domains).
 set -u
 OUT=gpurun_out/r6p; mkdir -p $OUT
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-WHAT="${*:-tests bench pmc modes decode attn vendor}"
+WHAT="${*:-tests bench pmc modes decode attn swbabl vendor}"
 R=$(pwd)
 PMC_CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 for w in $WHAT; do case $w in
@@ -35,6 +35,10 @@ decode)
 attn)
   timeout 300 python tools/bench_attn4.py > $OUT/attn4_fwd_bench.log 2>&1
   timeout 300 python tools/bench_attn4_bwd.py > $OUT/attn4_bwd_bench.log 2>&1 ;;
+swbabl)
+  # the experiment that bounds a persistent / overlapped gemm_pp_swiglu_bwd_kernel: K loop alone, epilogue alone, and the
+  # K loop with one tile's epilogue traffic issued inside it (timing-only builds of tools/build_swb_abl.sh, made in the build container)
+  { for rep in 1 2; do python tools/bench_swb_abl.py; for m in 1 2 3; do MM355_LIB_PATH=$R/build/swb_abl$m/libmm355.so python tools/bench_swb_abl.py; done; done; } > $OUT/swiglu_bwd_overlap_bound.log 2>&1 ;;
 vendor)
   timeout 900 python tools/bench_vendor_step.py > $OUT/vendor_step.json 2> $OUT/vendor_step.err ;;
 esac; done
