@@ -58,12 +58,16 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct seeded batches rotated through the steps (the loss is then a training loss, not a memorised batch)")
     ap.add_argument("--llama31-rope", action="store_true", help="LLaMA-3.1's rope_scaling (rope_type llama3) instead of the plain theta = 5e5 RoPE of "
                     "BASELINE's LLaMA-3-8B: only the cos / sin TABLES differ, every kernel is the same; said in config.workload")
+    ap.add_argument("--ragged", type=float, default=0.0, metavar="SHARE", help="ragged batches with this mean padding share (sample lengths uniform in "
+                    "[1 - 2 SHARE, 1] x seq, right-padded to the longest): `value` then counts VALID tokens/s; NOT the headline config")
+    ap.add_argument("--compact-rows", default="auto", choices=("auto", "on", "off"), help="padding-free decoder rows (model.config.mm355_compact_rows): "
+                    "auto = from 8 %% padding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
 
-def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
+def make_batch(B, L, T, device, seed, frames=1, all_generation=False, ragged=0.0):
     """[BOS,BOS, 20 text, frames x (<image_start>, <image>, <image_end>), text ...] padded so the SPLICED length is exactly L.
     Samples 1..B-1 are image-QA (prompt-side images, labels -100 on the prompt); sample 0 is a generation sample (its LAST
     image is answer-side: the label at its <image_start> is live) so the vision-head / cosine path runs and the combined loss is
@@ -86,6 +90,14 @@ def make_batch(B, L, T, device, seed, frames=1, all_generation=False):
     labels[gen, last - 3:] = ids[gen, last - 3:]             # generation sample: supervise from just before the last <image_start>
     labels[gen, last] = -200
     mask = torch.ones(B, n_ids, dtype=torch.bool)
+    if ragged > 0:
+        # --ragged SHARE: an ImageQA-like length distribution -- sample lengths uniform in [1 - 2 SHARE, 1] x the full length (mean padding share
+        # SHARE), right-padded to the longest as the reference's collator does (train.py:1258-1284); one sample per batch keeps the full length
+        u = 1.0 - 2.0 * ragged * torch.rand(B, generator=g)
+        u[B - 1] = 1.0
+        for b in range(B):
+            nb = max(prompt_end + 8, int(round(float(u[b]) * n_ids)))
+            ids[b, nb:], labels[b, nb:], mask[b, nb:] = 128001, -100, False
     images = torch.randn(B * frames, 3, 384, 384, generator=g)
     if device is None:                                       # --host-inputs: what a DataLoader with pin_memory hands the Trainer
         return tuple(t.pin_memory() for t in (ids, labels, mask, images))
@@ -605,7 +617,11 @@ def main():
     # a pool of distinct seeded batches, all resident before the timed region, rotated through the steps
     n_pool = max(1, args.pool)
     pool = [make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank + 1000 * j,
-                       frames=args.frames, all_generation=args.all_generation) for j in range(n_pool)]
+                       frames=args.frames, all_generation=args.all_generation, ragged=args.ragged) for j in range(n_pool)]
+    model.config.mm355_compact_rows = {"auto": "auto", "on": True, "off": False}[args.compact_rows]
+    # valid spliced rows of every pool batch (mask rows + the image rows the splice inserts): what `value` counts under --ragged
+    pool_valid = [int(b_[2].sum()) + args.batch * args.frames * (args.image_tokens - 1) for b_ in pool]
+    valid_timed = [0]
     host_bytes = sum(t.numel() * t.element_size() for t in pool[0]) if args.host_inputs else 0
     timer = GemmTimer()
     hbm_timer = HbmTimer()
@@ -617,6 +633,7 @@ def main():
 
     def step():
         ids, labels, mask, images = pool[step_no[0] % n_pool]
+        valid_timed[0] += pool_valid[step_no[0] % n_pool]
         step_no[0] += 1
         if args.host_inputs:                                 # host -> HBM inside the step (HF Trainer._prepare_inputs), pixels cast on the device
             ids, labels, mask = (hostmirror.to_device(t, dev, non_blocking=True) for t in (ids, labels, mask))
@@ -638,6 +655,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = hbm_timer.enabled = True
+    valid_timed[0] = 0
     dist_run = world > 1 or force_dist
     if dist_run and hasattr(opt, "comm_timing"):
         opt.comm_timing = True                                   # HIP events around the parts of step() that wait for RCCL
@@ -697,6 +715,8 @@ def main():
             opt.set_async_update(False)
     tokens_per_rank = args.batch * args.seq
     value = world * tokens_per_rank * args.steps / dt
+    if args.ragged > 0:                                          # valid tokens only (this rank's count x ranks: every rank draws the same distribution)
+        value = world * valid_timed[0] / dt
 
     n_all, t_all_g, fl_all = timer.summary() if not args.no_kernel_timing else (0, 0.0, 0.0)
     n_gemm, t_gemm, fl_gemm, bytes_gemm = timer.summary(plain_only=True) if not args.no_kernel_timing else (0, 0.0, 0.0, 0.0)
@@ -756,7 +776,8 @@ def main():
     # whole-step model flops: 3 x (32 x (436.2 MFLOP + 2 L h) + 2 h V) per token + 666.5 GFLOP per image
     h, V, L = 4096, 128258, args.seq
     per_tok = 3.0 * (args.layers * (436.2076e6 + 2.0 * L * h) + 2.0 * h * V)
-    step_flops = per_tok * tokens_per_rank + args.batch * args.frames * 666.5e9 * (args.vit_layers / 27.0) * (3.0 if args.train_vision else 1.0)
+    flop_tokens = valid_timed[0] / max(args.steps, 1) if args.ragged > 0 else tokens_per_rank       # model flops are those of the VALID tokens
+    step_flops = per_tok * flop_tokens + args.batch * args.frames * 666.5e9 * (args.vit_layers / 27.0) * (3.0 if args.train_vision else 1.0)
     mfu = step_flops * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
 
     if rank == 0:
@@ -769,7 +790,9 @@ def main():
             "tokens_per_sec_per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE configs[1]: LLaMA-3-8B + SigLIP-SO400M/14-384, spliced seq 2048 with one 256-token image per sample, "
                                    "bf16 full fine-tune (tower " + ("trainable" if args.train_vision else "frozen") + "), AdamW + ZeRO-2" + (
-                                       "; LLaMA-3.1 rope_scaling (rope_type llama3) instead of BASELINE's plain RoPE" if args.llama31_rope else ""),
+                                       "; LLaMA-3.1 rope_scaling (rope_type llama3) instead of BASELINE's plain RoPE" if args.llama31_rope else "") + (
+                                       f"; RAGGED batches, mean padding share {args.ragged:.2f} (value = VALID tokens/s: {valid_timed[0] / max(args.steps, 1) / (args.batch * args.seq):.3f} "
+                                       f"of the padded rows; decoder rows {getattr(model, '_decoder_rows', None)}; compact rows {args.compact_rows}) -- NOT the headline" if args.ragged > 0 else ""),
                        "global_batch": world * args.batch, "per_gpu_batch": args.batch, "seq_len": args.seq, "image_tokens": args.image_tokens, "frames_per_sample": args.frames,
                        "decoder_layers": args.layers, "tower_layers": args.vit_layers, "trainable_params": n_params,
                        **({"variants": sorted(args.set_variant)} if args.set_variant else {}),

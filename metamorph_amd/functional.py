@@ -295,10 +295,15 @@ def input_grad_gemm(dy2d, w, out=None, residual=None):
 class LayerMeta:
     """Geometry shared by all decoder layers of one forward pass."""
 
-    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens, recompute=False, pos_offset=None):
+    def __init__(self, B, L, Hq, Hkv, d, I, eps, cos, sin, seqlens, recompute=False, pos_offset=None, c2p=None, p2c=None):
         self.B, self.L, self.Hq, self.Hkv, self.d, self.I, self.eps = B, L, Hq, Hkv, d, I, eps
         self.cos, self.sin, self.seqlens = cos, sin, seqlens
         self.pos_offset = pos_offset        # int32 [B] or None: RoPE position of row (b, l) = l + pos_offset[b] (left-padded batches)
+        # padding-free rows (ragged batches): the decoder's row-wise work (norms, GEMMs, SwiGLU, residuals) runs on the COMPACT layout --
+        # the sum(len) valid rows back to back, rounded up to 256 with zero rows -- and only q|k|v -> attention -> o visits the padded
+        # [B, L] layout the attention kernels address (per-sample lengths from row b * L).  c2p int32 [rows]: padded row of every compact
+        # row (-1: a zero row of the tail); p2c int32 [B * L]: compact row of every padded row (-1: padding).  None: x IS the padded layout.
+        self.c2p, self.p2c = c2p, p2c
         self.scale = d ** -0.5
         # gradient checkpointing (reference train.py:1443-1449 + `--gradient_checkpointing True` in every launch script): keep only
         # the layer input, re-run the layer's forward kernels at the start of its backward
@@ -312,15 +317,19 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
     wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
     n1, rstd1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, m.eps, want_rstd=True)
-    if VARIANTS["fuse_rope"] and ops.gemm_rope_supported(n1, wqkv, m.Hq, m.Hkv, m.d, m.cos):
+    if m.p2c is None and VARIANTS["fuse_rope"] and ops.gemm_rope_supported(n1, wqkv, m.Hq, m.Hkv, m.d, m.cos):
         qkv = ops.gemm_rope(n1, wqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)     # rotation in the GEMM epilogue: same bits
         del n1
     else:
         qkv = ops.gemm(n1, wqkv)
         del n1
+        if m.p2c is not None:                                  # compact rows -> the padded layout attention addresses (padding rows: zeros)
+            qkv = ops.rows_gather(qkv, m.p2c)
         ops.rope_qk_(qkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)
     nq, nk = m.Hq * m.d, m.Hkv * m.d
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
+    if m.c2p is not None:
+        o = ops.rows_gather(o, m.c2p)                          # back to compact rows for o_proj and everything after it
     x2 = ops.gemm(o, att.o_proj.weight, residual=x)
     n2, rstd2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps, want_rstd=True)
     if VARIANTS["fuse_swiglu"] and ops.gemm_swiglu_supported(n2, wgu, m.I):
@@ -455,12 +464,17 @@ class DecoderLayerFn(Function):
             do = input_grad_gemm(dx2, att.o_proj.weight)                        # [M, Hq*d]
         dqkv = torch.empty_like(qkv)
         fuse_rope = VARIANTS["fuse_rope"] and ops.attn_bwd_rope_supported(m.d)      # inverse RoPE of dq / dk in the attention kernels' epilogues
-        ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
+        o_att = o
+        if m.p2c is not None:                                  # padding-free rows: o / d o to the padded layout (qkv was saved in it)
+            o_att, do = ops.rows_gather(o, m.p2c), ops.rows_gather(do, m.p2c)
+        ops.attn_bwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], o_att, do, lse, m.B, m.L, m.Hq, m.Hkv, m.d,
                      m.scale, True, m.seqlens, dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:],
                      rope=(m.cos, m.sin, m.pos_offset) if fuse_rope else None)
-        del do
+        del do, o_att
         if not fuse_rope:
             ops.rope_qk_(dqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, inverse=True, pos_offset=m.pos_offset)
+        if m.c2p is not None:
+            dqkv = ops.rows_gather(dqkv, m.c2p)                # gradients of the compact q|k|v rows (tail rows: zeros)
         wqkv = fused_weight(qkv_params)
         if VARIANTS["dw_tn"] and ops.gemm_nn_supported(dqkv, wqkv):
             dn1 = ops.gemm_nn(dqkv, wqkv)

@@ -55,6 +55,24 @@ def _left_pad_maps(seqlens, B, L):
     return to_right, to_left, off
 
 
+def compact_row_maps(seqlens, B, L, granule=256):
+    """Row maps between the right-padded layout (row b * L + l, valid for l < n_b) and the compact one (the valid rows back to back, rounded
+    up to `granule` rows -- whole GEMM tiles and whole 64-row transposed vectors): (c2p int32 [rows]: padded row of every compact row, -1 in
+    the tail; p2c int32 [B * L]: compact row of every padded row, -1 for padding)."""
+    n = np.asarray(seqlens, dtype=np.int64)
+    total = int(n.sum())
+    rows = max(granule, (total + granule - 1) // granule * granule)
+    c2p = np.full(rows, -1, dtype=np.int32)
+    p2c = np.full(B * L, -1, dtype=np.int32)
+    at = 0
+    for b in range(B):
+        k = int(n[b])
+        c2p[at:at + k] = b * L + np.arange(k, dtype=np.int32)
+        p2c[b * L:b * L + k] = at + np.arange(k, dtype=np.int32)
+        at += k
+    return c2p, p2c
+
+
 class _Attention(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -372,14 +390,29 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
             moved = torch.from_numpy(np.concatenate([to_right, to_left, off])).to(dev)
             to_right_d, to_left_d, pos_off = moved[:B * L], moved[B * L:2 * B * L], moved[2 * B * L:]
         cos, sin = self.model.rope_tables(2 * L if shift else L, dev)
+        # Padding-free rows (reference: batches are right-padded to their longest sample, train.py:1258-1284, and the intended attention is
+        # varlen, llama_flash_attn_monkey_patch.py:95-104; tokens/s counts VALID tokens): when enough of the B x L rows are
+        # padding, the decoder runs on the sum(len) valid rows only (LayerMeta.c2p / p2c) -- norms, GEMMs and SwiGLU never touch a padding
+        # row; q|k|v -> attention -> o visits the padded layout through row gathers.  `mm355_compact_rows`: True / False / "auto" (default:
+        # on from 8 % padding, where the saved GEMM rows outweigh the five gathers + one RoPE pass per layer, ~3 % of a layer).
+        c2p_d = p2c_d = None
+        mode = getattr(cfg, "mm355_compact_rows", "auto")
+        n_valid_rows = int(plan.seqlens.sum())
+        if mode is True or (mode == "auto" and B * L - n_valid_rows >= 0.08 * B * L and n_valid_rows > 0):
+            c2p, p2c = compact_row_maps(plan.seqlens, B, L)
+            both = torch.from_numpy(np.concatenate([c2p, p2c])).to(dev)
+            c2p_d, p2c_d = both[:c2p.shape[0]], both[c2p.shape[0]:]
+        self._decoder_rows = (int(c2p_d.shape[0]) if c2p_d is not None else B * L, B * L)     # (rows the decoder ran on, padded rows): introspection
         meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],
-                           recompute=bool(self.model.gradient_checkpointing) and self.training, pos_offset=pos_off)
+                           recompute=bool(self.model.gradient_checkpointing) and self.training, pos_offset=pos_off, c2p=c2p_d, p2c=p2c_d)
 
         x = inputs_embeds.reshape(B * L, h)
         if not x.is_contiguous():
             x = x.contiguous()
         if shift:
             x = F.RowsPermuteFn.apply(x, to_right_d, to_left_d)
+        if c2p_d is not None:
+            x = F.RowsPermuteFn.apply(x, c2p_d, p2c_d)                  # [rows_compact, h]; backward gathers with p2c (padding rows: zero)
         tap = self.model.layer_output_hook
         n_ck = self.model.checkpoint_layers
         meta_keep = meta
@@ -389,7 +422,9 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         for li, layer in enumerate(self.model.layers):
             x = F.decoder_layer(x, layer, meta if (n_ck is None or li < int(n_ck)) else meta_keep)
             if tap is not None:                                         # the reference's output_hidden_states tuple, one entry at a time
-                tap(li, x)
+                tap(li, x if p2c_d is None else ops.rows_gather(x.detach(), p2c_d))
+        if c2p_d is not None:
+            x = F.RowsPermuteFn.apply(x, p2c_d, c2p_d)                  # back to [B * L, h] (padding rows: zeros, as the padded path leaves them
         if shift:
             x = F.RowsPermuteFn.apply(x, to_left_d, to_right_d)
         hid = self.model.norm(x)                                       # [B*L, h]

@@ -277,6 +277,23 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
     assert m2.config.num_image_tokens == 4 and m2.config.model_type == "metamorph_llama"
 
 
+def test_compact_row_maps_are_inverse_and_tile_aligned():
+    """Padding-free rows: c2p / p2c of metamorph_llama.compact_row_maps are inverse on the valid rows, list samples back to back in order, mark
+    padding / tail rows -1, and the compact row count is a whole number of 256-row GEMM tiles (>= one tile, also for an all-empty batch)."""
+    from metamorph_amd.model.language_model.metamorph_llama import compact_row_maps
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        B, L = int(rng.integers(1, 9)), int(rng.integers(1, 900))
+        n = rng.integers(0, L + 1, size=B)
+        c2p, p2c = compact_row_maps(n, B, L)
+        total = int(n.sum())
+        assert c2p.shape[0] % 256 == 0 and c2p.shape[0] >= max(total, 256) and c2p.shape[0] - total < 256 + (total == 0) * 256
+        assert (c2p[total:] == -1).all() and (c2p[:total] >= 0).all() and (np.diff(c2p[:total]) > 0).all()
+        assert p2c.shape == (B * L,) and (p2c[c2p[:total]] == np.arange(total)).all()
+        valid = (np.arange(L)[None] < n[:, None]).reshape(-1)
+        assert ((p2c >= 0) == valid).all()
+
+
 def test_llama31_checkpoint_config_round_trips_and_unsupported_fields_are_refused_by_name(tmp_path):
     """A LLaMA-3.1-shaped config.json (rope_scaling rope_type "llama3" -- the reference README's base model, README.md:178,187 -- plus tied
     embeddings and an explicit head_dim) constructs, saves and loads back: same RoPE frequencies, lm_head still tied, q_proj sized by head_dim.

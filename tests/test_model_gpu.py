@@ -1159,6 +1159,59 @@ def test_configs0_tinyllama_real_widths_against_oracle():
 #  coverage, was retired in round 6 to keep the -m gpu suite inside the driver's step limit.)
 
 
+# ------------------------------------------------------------------ padding-free rows (round 6)
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_padding_free_rows_equal_the_padded_path(side):
+    """Ragged batch (lengths 700 / 333 / 90 of L = 700: 47 % padding): the decoder on COMPACT rows (mm355_compact_rows, the default from 8 %
+    padding) against the same model on the padded layout (mm355_compact_rows = False).  Every row-wise kernel computes a row from that row
+    alone, and attention sees the same padded q|k|v either way: loss, loss_language / loss_image_ar, logits-free hidden rows and the input
+    gradient are compared BIT FOR BIT on the valid rows; weight gradients contract over rows (zero rows removed = another fp32 summation
+    order inside the MFMAs) and are held to 2e-3 of their norm.  Both padding sides; 1 536 instead of 2 100 decoder rows."""
+    cfg = OracleConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                       vocab_size=32002, v_layers=1, v_intermediate=144, v_image=56, num_image_tokens=16, tokenizer_model_max_length=1024,
+                       image_start_id=32000, tokenizer_padding_side=side)
+    g = torch.Generator().manual_seed(21)
+    lens = [685, 318, 75]                                         # ids per sample; + 15 image rows each = 700 / 333 / 90 spliced rows
+    n_ids = max(lens)
+    ids = torch.zeros((3, n_ids), dtype=torch.long)
+    labels = torch.full((3, n_ids), -100, dtype=torch.long)
+    mask = torch.zeros((3, n_ids), dtype=torch.bool)
+    for b, n in enumerate(lens):
+        row = torch.randint(3, 31999, (n,), generator=g)
+        row[0] = 1
+        p = 20 if b != 2 else n - 4                               # samples 0, 1: prompt-side image; sample 2: answer-side image at its end
+        row[p], row[p + 1], row[p + 2] = 32000, -200, 32001
+        lab = torch.full((n,), -100, dtype=torch.long)
+        lab[n // 2:] = row[n // 2:]
+        sl = slice(n_ids - n, n_ids) if side == "left" else slice(0, n)
+        ids[b, sl], labels[b, sl], mask[b, sl] = row, lab, True
+    images = torch.randn(3, 3, 56, 56, generator=g)
+    sd = init_state_dict(cfg, seed=19, dtype=torch.bfloat16)
+    res = {}
+    for compact in (False, "auto"):
+        model = hip_model(cfg, sd)
+        model.train()
+        model.config.mm355_compact_rows = compact
+        out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), images=images.to(DEV).bfloat16())
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res[compact] = dict(loss=out.loss.detach().clone(), lang=model.loss_language, img=model.loss_image_ar, hid=out.hidden_states.detach().clone(),
+                            rows=model._decoder_rows, grads={n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        del model
+    a, b = res[False], res["auto"]
+    assert a["rows"] == (2100, 2100) and b["rows"] == (1280, 2100), (a["rows"], b["rows"])       # 700 + 333 + 90 = 1123 -> 1280 (whole 256-row tiles)
+    assert torch.equal(a["loss"], b["loss"]) and a["lang"] == b["lang"] and a["img"] == b["img"], (float(a["loss"]), float(b["loss"]))
+    assert torch.equal(a["hid"], b["hid"])                        # every row, padding included (zeros on both paths)
+    worst = (0.0, "")
+    for n, ga in a["grads"].items():
+        e = float((b["grads"][n] - ga).norm() / ga.norm().clamp_min(1e-30))
+        worst = max(worst, (e, n))
+        assert e <= 2e-3, (n, e)
+    same = sum(int(torch.equal(a["grads"][n], b["grads"][n])) for n in a["grads"])
+    print(f"\n   padding-free vs padded ({side} padding): loss / hidden rows bit-identical; {same} of {len(a['grads'])} gradient tensors bit-identical, "
+          f"worst rel diff {worst[0]:.2e} ({worst[1]})")
+
+
 # ------------------------------------------------------------------ the fp32 oracle evaluated on the device (round 6)
 def test_streamed_oracle_on_device_against_reference_recorded_8_layer_run():
     """oracle/ref_stream.full_depth(device="cuda") -- the evaluation the full-width tests below use for their fp32 truth -- DIRECTLY against

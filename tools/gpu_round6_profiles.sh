@@ -6,7 +6,7 @@
 set -u
 OUT=gpurun_out/r6p; mkdir -p $OUT
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-WHAT="${*:-tests bench pmc modes decode attn swbabl vendor}"
+WHAT="${*:-tests bench pmc modes decode attn swbabl ragged vendor}"
 R=$(pwd)
 PMC_CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 for w in $WHAT; do case $w in
@@ -39,6 +39,10 @@ swbabl)
   # the experiment that bounds a persistent / overlapped gemm_pp_swiglu_bwd_kernel: K loop alone, epilogue alone, and the
   # K loop with one tile's epilogue traffic issued inside it (timing-only builds of tools/build_swb_abl.sh, made in the build container)
   { for rep in 1 2; do python tools/bench_swb_abl.py; for m in 1 2 3; do MM355_LIB_PATH=$R/build/swb_abl$m/libmm355.so python tools/bench_swb_abl.py; done; done; } > $OUT/swiglu_bwd_overlap_bound.log 2>&1 ;;
+ragged)
+  # padding-free decoder rows on ragged batches (mean padding share 0.4): compact rows on / off, and the dense batch on the same box
+  for cr in on off; do timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --ragged 0.4 --compact-rows $cr > $OUT/bench_ragged40_compact_$cr.json 2>> $OUT/bench_ragged.err; done
+  timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_dense_same_box.json 2>> $OUT/bench_ragged.err ;;
 vendor)
   timeout 900 python tools/bench_vendor_step.py > $OUT/vendor_step.json 2> $OUT/vendor_step.err ;;
 esac; done
