@@ -17,6 +17,7 @@ import torch
 
 _MIRRORS: dict = {}                                          # id(device tensor) -> (weakref to it, its version, host array); the weakref's
                                                              # callback drops the entry (a WeakKeyDictionary would compare tensors with ==)
+_WARNED = False
 STATS = {"mirror": 0, "cpu": 0, "sync": 0}                   # how host_array was served (tests / bench assert on `sync`)
 
 
@@ -52,4 +53,12 @@ def host_array(t: torch.Tensor | None) -> np.ndarray | None:
         STATS["mirror"] += 1
         return hit[2]
     STATS["sync"] += 1
+    global _WARNED
+    if not _WARNED:
+        _WARNED = True
+        import warnings
+        warnings.warn("metamorph_amd: a batch tensor reached the model without a host mirror -- its values are copied back from the device "
+                      "(one synchronisation per step, ~4 ms at 8B).  Move batches with metamorph_amd.hostmirror.to_device(t, device), or "
+                      "use metamorph_amd.trainer.MetaMorphTrainer, which registers the collator's host tensors itself.  (Shown once.)",
+                      RuntimeWarning, stacklevel=3)
     return t.detach().cpu().numpy()

@@ -28,6 +28,31 @@ for use_cache in (() if os.environ.get("NO_GREEDY") else (True,) if os.environ.g
         per = (dt2 - dt) / max(out2.numel() - out.numel(), 1)
         print(f"   decode step alone: {per*1e3:.3f} ms/token = {wbytes/per/1e12:.2f} TB/s of weights; prompt pass + first token ~ {(dt - per*out.numel())*1e3:.1f} ms", flush=True)
 
+# ---- the prompt pass alone (round 6): decoder_prefill over L0 rows through the training-path kernels, KV rows kept; floor = the later of
+#      streaming the weights once (15.1 GB at the ~6.3 TB/s achievable) and the GEMM + attention flops at the 1.45 PF the big GEMMs sustain
+if not os.environ.get("NO_PREFILL"):
+    import metamorph_amd.functional as F
+    wbytes = sum(p.numel() for n_, p in model.named_parameters() if "vision_tower" not in n_ and "embed_tokens" not in n_ and "lm_head" not in n_) * 2
+    with torch.no_grad():
+        for Lp in [int(x) for x in os.environ.get("PROMPTS", "128,512,2048").split(",")]:
+            _, meta = model._decode_meta(Lp)
+            cos, sin = model.model.rope_tables(Lp + 8, dev)
+            meta.cos, meta.sin = cos, sin
+            kv = F.KVCache(len(model.model.layers), Lp + 8, meta.Hkv * meta.d, dev, Hq=meta.Hq, d=meta.d)
+            x = (torch.randn(Lp, h, device=dev) * 0.02).bfloat16()
+            for _ in range(2):
+                kv.set_lengths([0]); F.decoder_prefill(x, model.model.layers, meta, kv)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                kv.set_lengths([0]); F.decoder_prefill(x, model.model.layers, meta, kv)
+            torch.cuda.synchronize(); per = (time.perf_counter() - t0) / reps
+            flops = layers * (436.2076e6 + 2.0 * Lp * h) * Lp
+            floor = max(wbytes / 6.3e12, flops / 1.45e15)
+            print(f"prompt pass {Lp:5d} rows: {per*1e3:7.2f} ms  ({flops/per/1e12:6.0f} TFLOP/s, weights at {wbytes/per/1e12:.2f} TB/s; floor {floor*1e3:.2f} ms = "
+                  f"{'weights' if wbytes / 6.3e12 > flops / 1.45e15 else 'flops'}; x {per/floor:.2f})", flush=True)
+            del kv
+
 # ---- the batched cached step (round 5: all rows of a batch / all beams in ONE pass over the weights): ms per step by batch size
 if not os.environ.get("NO_BATCH"):
     import metamorph_amd.functional as F
