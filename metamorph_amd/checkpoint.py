@@ -137,3 +137,114 @@ def load_consolidated_optimizer_state(opt, model, ckpt):
     if opt.master.is_cuda:                                   # parameters changed behind torch's version counters
         from . import functional as F
         F.bump_param_generation()
+
+
+# ------------------------------------------------------------------------------------------------ DeepSpeed's own ZeRO-2 shards
+# The reference trains under DeepSpeed (scripts/zero2.json); an HF Trainer checkpoint of such a run holds, next to the consolidated
+# weights, DeepSpeed's per-rank resume files (HF `Trainer._save_checkpoint` -> `deepspeed_engine.save_checkpoint`, reached from the
+# reference at train.py:210-213 / through `trainer.train(resume_from_checkpoint=True)`, train.py:1592-1599):
+#
+#   checkpoint-N/latest                                              text: "global_stepN"
+#   checkpoint-N/global_stepN/mp_rank_00_model_states.pt             {"module": 16-bit state dict, "param_shapes": [OrderedDict name -> shape per
+#                                                                     parameter group], "ds_version", ...}
+#   checkpoint-N/global_stepN/[bf16_]zero_pp_rank_{r}_mp_rank_00_optim_states.pt
+#                                                                    {"optimizer_state_dict": {"zero_stage": 2, "partition_count": W,
+#                                                                     "single_partition_of_fp32_groups": [flat fp32 slice per group],
+#                                                                     "base_optimizer_state": {"state": {g: {"exp_avg", "exp_avg_sq", "step"}},
+#                                                                                              "param_groups": [...]}}}
+#
+# A group's fp32 master vector is the concatenation of the ranks' slices: its parameters back to back in `param_shapes[g]` order, padded
+# to a multiple of 2 x world size (DeepSpeed's `zero_to_fp32.py`, pinned 0.15.1 in the reference's pyproject.toml:16: `zero2_align`); the
+# Adam moments are partitioned the same way.  DeepSpeed is NOT installed in this image, so no file of its making could be recorded: the
+# layout above is restated from that script -- **parity unpinned** (tests/test_host_logic.py round-trips it through a writer of the same
+# layout; a real checkpoint has not been read).
+
+def _ds_step_dir(checkpoint_dir: str) -> str:
+    latest = os.path.join(checkpoint_dir, "latest")
+    if os.path.isfile(latest):
+        return os.path.join(checkpoint_dir, open(latest).read().strip())
+    steps = sorted(d for d in os.listdir(checkpoint_dir) if d.startswith("global_step"))
+    if not steps:
+        raise FileNotFoundError(f"{checkpoint_dir}: no `latest` file and no global_step* directory (not a DeepSpeed checkpoint)")
+    return os.path.join(checkpoint_dir, steps[-1])
+
+
+def read_deepspeed_zero2_checkpoint(checkpoint_dir: str):
+    """DeepSpeed ZeRO-2 per-rank shards -> the world-size-independent form `load_consolidated_optimizer_state` takes:
+    {"step", "param_groups", "state": {name: {"master", "exp_avg", "exp_avg_sq"}}} (fp32 CPU tensors in each parameter's shape)."""
+    import re
+    step_dir = _ds_step_dir(checkpoint_dir)
+    model_states = torch.load(os.path.join(step_dir, "mp_rank_00_model_states.pt"), map_location="cpu", weights_only=False)
+    shapes = model_states["param_shapes"]
+    files = {}
+    for f in os.listdir(step_dir):
+        m = re.fullmatch(r"(?:bf16_)?zero_pp_rank_(\d+)_mp_rank_00_optim_states\.pt", f)
+        if m:
+            files[int(m.group(1))] = os.path.join(step_dir, f)
+    if not files or sorted(files) != list(range(len(files))):
+        raise FileNotFoundError(f"{step_dir}: optimizer shards of ranks {sorted(files)} found; need 0 .. W-1")
+    osd = [torch.load(files[r], map_location="cpu", weights_only=False)["optimizer_state_dict"] for r in range(len(files))]
+    stage = osd[0].get("zero_stage", 2)
+    if int(stage) > 2:
+        raise NotImplementedError(f"zero_stage {stage}: ZeRO-3 shards partition every parameter separately (use the gathered 16-bit weights instead)")
+    world = osd[0]["partition_count"]
+    world = int(max(world) if isinstance(world, (list, tuple)) else world)
+    if world != len(files):
+        raise ValueError(f"partition_count {world} but {len(files)} shard files")
+    state, step = {}, 0
+    for g, group_shapes in enumerate(shapes):
+        def merged(pick):
+            return torch.cat([pick(osd[r]).reshape(-1).float() for r in range(world)])
+        vec = {"master": merged(lambda o: o["single_partition_of_fp32_groups"][g]),
+               "exp_avg": merged(lambda o: o["base_optimizer_state"]["state"][g]["exp_avg"]),
+               "exp_avg_sq": merged(lambda o: o["base_optimizer_state"]["state"][g]["exp_avg_sq"])}
+        st = osd[0]["base_optimizer_state"]["state"][g].get("step", 0)
+        step = max(step, int(st.item() if isinstance(st, torch.Tensor) else st))
+        off = 0
+        for name, shape in group_shapes.items():
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if off + n > vec["master"].numel():
+                raise ValueError(f"group {g}: parameter {name} ends at {off + n}, the merged partitions hold {vec['master'].numel()} values")
+            state[name] = {k: v[off:off + n].view(tuple(shape)).clone() for k, v in vec.items()}
+            off += n
+        align = 2 * world
+        if (off + align - 1) // align * align != vec["master"].numel():
+            raise ValueError(f"group {g}: {off} parameter values aligned to {align} != {vec['master'].numel()} values in the merged partitions")
+    groups = [{k: v for k, v in pg.items() if k != "params"} for pg in osd[0]["base_optimizer_state"]["param_groups"]]
+    return {"step": step, "state": state, "param_groups": groups, "module": model_states.get("module")}
+
+
+def write_deepspeed_zero2_layout(consolidated, group_names, checkpoint_dir: str, world: int, tag: str = "global_step1", bf16: bool = True,
+                                 module=None):
+    """The inverse of `read_deepspeed_zero2_checkpoint` (used by its test and for handing a run BACK to a DeepSpeed stack): the consolidated
+    state as W per-rank shard files + the model-states file.  group_names: one list of parameter names per optimizer parameter group."""
+    from collections import OrderedDict
+    step_dir = os.path.join(checkpoint_dir, tag)
+    os.makedirs(step_dir, exist_ok=True)
+    align = 2 * world
+    flats, shapes = [], []
+    for names in group_names:
+        shapes.append(OrderedDict((n, torch.Size(consolidated["state"][n]["master"].shape)) for n in names))
+        flat = {}
+        for k in ("master", "exp_avg", "exp_avg_sq"):
+            v = torch.cat([consolidated["state"][n][k].reshape(-1).float() for n in names])
+            pad = (v.numel() + align - 1) // align * align - v.numel()
+            flat[k] = torch.cat([v, v.new_zeros(pad)])
+        flats.append(flat)
+    torch.save({"module": module or {}, "param_shapes": shapes, "buffer_names": [], "shared_params": {}, "ds_version": "0.15.1"},
+               os.path.join(step_dir, "mp_rank_00_model_states.pt"))
+    for r in range(world):
+        part = lambda v: v.view(world, -1)[r].clone()
+        osd = {"zero_stage": 2, "partition_count": world, "loss_scaler": None, "dynamic_loss_scale": False, "overflow": False, "clip_grad": 1.0,
+               "single_partition_of_fp32_groups": [part(f["master"]) for f in flats],
+               "base_optimizer_state": {"state": {g: {"exp_avg": part(f["exp_avg"]), "exp_avg_sq": part(f["exp_avg_sq"]), "step": consolidated["step"]}
+                                                  for g, f in enumerate(flats)},
+                                        "param_groups": [dict(pg, params=[g]) for g, pg in enumerate(consolidated["param_groups"])]},
+               "ds_version": "0.15.1"}
+        torch.save({"optimizer_state_dict": osd, "ds_version": "0.15.1"},
+                   os.path.join(step_dir, f"{'bf16_' if bf16 else ''}zero_pp_rank_{r}_mp_rank_00_optim_states.pt"))
+    with open(os.path.join(checkpoint_dir, "latest"), "w") as f:
+        f.write(tag)
+    return step_dir

@@ -196,6 +196,14 @@ class MetaMorphTrainer(Trainer):
             return super()._load_optimizer_and_scheduler(checkpoint)
         path = os.path.join(checkpoint, self._OPT)
         if not os.path.isfile(path):
+            # a checkpoint written by the reference's own stack: DeepSpeed's per-rank ZeRO-2 shards (global_step*/[bf16_]zero_pp_rank_*): merged into
+            # the world-size-independent form and scattered into this optimizer (checkpoint.read_deepspeed_zero2_checkpoint; layout unpinned)
+            if not isinstance(z, Zero3AdamW) and (os.path.isfile(os.path.join(checkpoint, "latest")) or any(
+                    d.startswith("global_step") for d in os.listdir(checkpoint))):
+                from .checkpoint import read_deepspeed_zero2_checkpoint
+                ds = read_deepspeed_zero2_checkpoint(checkpoint)
+                ds["param_groups"] = ds["param_groups"][:len(z.param_groups)] if len(ds["param_groups"]) >= len(z.param_groups) else [{}] * len(z.param_groups)
+                load_consolidated_optimizer_state(z, self.model, ds)
             return
         if isinstance(z, Zero3AdamW):
             shard = os.path.join(checkpoint, f"zero3_rank{z.rank}-of-{z.world}-{self._OPT}")

@@ -277,6 +277,33 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
     assert m2.config.num_image_tokens == 4 and m2.config.model_type == "metamorph_llama"
 
 
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_deepspeed_zero2_shard_layout_round_trip(tmp_path, world):
+    """`checkpoint.read_deepspeed_zero2_checkpoint`: DeepSpeed's per-rank ZeRO-2 resume files (reference train.py:210-213 / 1592-1599; layout
+    restated from DeepSpeed 0.15.1's zero_to_fp32.py -- PARITY UNPINNED: DeepSpeed is not in this image, no real file could be recorded) -> the
+    world-size-independent optimizer state.  Round trip through a writer of the same layout at world 1 / 2 / 8: two parameter groups, sizes that
+    do not divide 2 x world (alignment padding), bf16_ and plain file names; a missing rank and a ZeRO-3 stage are refused."""
+    from metamorph_amd.checkpoint import read_deepspeed_zero2_checkpoint, write_deepspeed_zero2_layout
+    g = torch.Generator().manual_seed(world)
+    shapes = {"model.embed_tokens.weight": (37, 8), "model.layers.0.mlp.gate_proj.weight": (5, 8), "model.norm.weight": (8,), "lm_head.bias": (3,)}
+    cons = {"step": 7, "param_groups": [{"lr": 2e-5, "weight_decay": 0.0, "betas": (0.9, 0.999), "eps": 1e-8}, {"lr": 2e-6, "weight_decay": 0.1, "betas": (0.9, 0.999), "eps": 1e-8}],
+            "state": {n: {k: torch.randn(*shp, generator=g) for k in ("master", "exp_avg", "exp_avg_sq")} for n, shp in shapes.items()}}
+    groups = [["model.embed_tokens.weight", "model.layers.0.mlp.gate_proj.weight"], ["model.norm.weight", "lm_head.bias"]]
+    d = str(tmp_path / "checkpoint-7")
+    step_dir = write_deepspeed_zero2_layout(cons, groups, d, world, tag="global_step7", bf16=world != 2)
+    assert sorted(os.listdir(step_dir)) == sorted(["mp_rank_00_model_states.pt"] + [f"{'bf16_' if world != 2 else ''}zero_pp_rank_{r}_mp_rank_00_optim_states.pt" for r in range(world)])
+    back = read_deepspeed_zero2_checkpoint(d)
+    assert back["step"] == 7 and set(back["state"]) == set(shapes)
+    for n in shapes:
+        for k in ("master", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(back["state"][n][k], cons["state"][n][k]), (n, k)
+    assert [pg["lr"] for pg in back["param_groups"]] == [2e-5, 2e-6]
+    if world > 1:
+        os.remove(os.path.join(step_dir, f"{'bf16_' if world != 2 else ''}zero_pp_rank_{world - 1}_mp_rank_00_optim_states.pt"))
+        with pytest.raises((FileNotFoundError, ValueError)):
+            read_deepspeed_zero2_checkpoint(d)
+
+
 def test_compact_row_maps_are_inverse_and_tile_aligned():
     """Padding-free rows: c2p / p2c of metamorph_llama.compact_row_maps are inverse on the valid rows, list samples back to back in order, mark
     padding / tail rows -1, and the compact row count is a whole number of 256-row GEMM tiles (>= one tile, also for an all-empty batch)."""
