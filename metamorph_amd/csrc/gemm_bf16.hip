@@ -1425,14 +1425,20 @@ extern "C" int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf1
         // auto: LDS-DMA staging whenever K is a whole number of 64-wide tiles; the 256x256 ping-pong kernel once it
         // still yields at least one full wave of workgroups over the 256 CUs.
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (dma_ok) variant = (t256 >= 200) ? 11 : 2;         // 11 falls back to 7 when K is not a whole number of tile pairs
-        else variant = 1;
+        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+        if (dma_ok) {
+            variant = (t256 >= 200) ? 11 : 2;                // 11 falls back to 7 when K is not a whole number of tile pairs
+            // prompt-pass shapes (a few hundred rows against N = 4096 .. 6144): 128 x 128 tiles leave half of the 256 CUs without a
+            // workgroup (M = 512, N = 4096: 128 tiles); 64-row tiles double the count.  Same K order per output element: same bits.
+            if (variant == 2 && t128 < 224 && M > 64 && t128 * 2 >= 64) variant = 9;
+        } else variant = 1;
     }
     if (!dma_ok && (variant == 2 || variant == 4 || variant >= 6)) return MM355_EUNSUPPORTED;
     switch (variant) {
         case 1: return launch_gemm<128, 128, 2, 2, false>(a, s);
         case 2: return launch_gemm<128, 128, 2, 2, true>(a, s);
         case 7: return launch_gemm<256, 256, 2, 4, true, 1>(a, s);
+        case 9: return launch_gemm<64, 128, 1, 4, true>(a, s);    // 64 x 128 tiles, four waves side by side (small-M / prompt-pass shapes)
         case 11: return launch_gemm_pp(a, s);
 #ifdef MM355_LEGACY_VARIANTS                                 // tools build: kernels no product path selects, kept for A/B timing
         case 3: return launch_gemm<256, 128, 4, 2, false>(a, s);

@@ -59,11 +59,11 @@ GEMM_SHAPES = [(128, 128, 64), (256, 256, 128), (300, 200, 192), (512, 384, 1152
                (200, 1152, 592), (1024, 1024, 4096)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 7, 11] + ([3, 4, 5, 6, 8, 10] if LEGACY else []))
+@pytest.mark.parametrize("variant", [0, 1, 2, 7, 9, 11] + ([3, 4, 5, 6, 8, 10] if LEGACY else []))
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_plain(ops, variant, shape):
     M, N, K = shape
-    if K % 64 and variant in (2, 4, 6, 7, 8, 10, 11):
+    if K % 64 and variant in (2, 4, 6, 7, 8, 9, 10, 11):
         pytest.skip("LDS-DMA variants need K % 64 == 0")
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     ref = a.float() @ b.float().t()
@@ -839,6 +839,25 @@ def test_loss_scalars_are_bit_reproducible(ops):
     ls_a = torch.zeros(1, device=DEV)
     ops.ce_rows_(lg.clone(), tg, V, 1.0, ls_a, deterministic=False)
     close(ls_a, first[0], 1e-5, 0, "atomics vs fixed order")
+
+
+def test_gemm_small_m_tiles_are_bit_identical_and_selected_for_prompt_shapes(ops):
+    """Round 6: 64 x 128 tiles (variant 9) for prompt-pass shapes -- a few hundred rows against N = 4096 .. 6144, where 128 x 128 tiles leave
+    half of the CUs without a workgroup.  Same K order per output element as every other tiling: bit-identical to variants 2 and 11, with
+    every epilogue flag; and the auto dispatch (variant 0) returns those same bits on such shapes."""
+    for (M, N, K) in [(512, 4096, 4096), (520, 6144, 4096), (300, 4096, 14336), (729, 1152, 1152), (96, 1024, 256)]:
+        a, b = rnd(M, K, seed=M).to(DEV), rnd(N, K, seed=N, scale=0.05).to(DEV)
+        ref = ops.gemm(a, b, variant=2)
+        assert torch.equal(ops.gemm(a, b, variant=9), ref) and torch.equal(ops.gemm(a, b, variant=0), ref), (M, N, K)
+        if K % 128 == 0:
+            assert torch.equal(ops.gemm(a, b, variant=11), ref)
+        bias, res = rnd(N, seed=3).to(DEV), rnd(M, N, seed=4).to(DEV)
+        for kw in (dict(bias=bias, gelu="tanh"), dict(residual=res), dict(out_f32=True), dict(bias=bias, residual=res, gelu="erf")):
+            assert torch.equal(ops.gemm(a, b, variant=9, **kw), ops.gemm(a, b, variant=2, **kw)), (M, N, K, sorted(kw))
+        acc9, acc2 = res.clone(), res.clone()
+        ops.gemm(a, b, out=acc9, accumulate=True, variant=9)
+        ops.gemm(a, b, out=acc2, accumulate=True, variant=2)
+        assert torch.equal(acc9, acc2)
 
 
 def test_cosine_loss(ops):
