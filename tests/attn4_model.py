@@ -279,7 +279,7 @@ def flash_bf16_backward(q, k, v, do, seqlens, causal, scale):
 
 # ------------------------------------------------------------------------------------------------ the backward streams' own arithmetic
 
-def attn4_backward_model(q, k, v, o, do, lse, seqlens, causal, scale):
+def attn4_backward_model(q, k, v, o, do, lse, seqlens, causal, scale, noise=None):
     """CPU model of the ARITHMETIC of the d == 128 backward streams (metamorph_amd/csrc/attn4_bwd.hip, tools/gen_attn4_bwd.py; round 6:
     the hostile backward cases now assert "at most two bf16 steps from this model" instead of absolute floors around a yardstick).
 
@@ -295,7 +295,18 @@ def attn4_backward_model(q, k, v, o, do, lse, seqlens, causal, scale):
     Both kernels recompute the SAME fp32 X, so one P / dS serves all three gradients here.  Differences between model and kernel:
     accumulation order inside the MFMAs and v_exp_f32's last bit.
 
+    noise = a seed: every fp32 ADDEND of the two score chains (the C operand and the 128-term dot product) carries independent relative
+    noise of 2^-21 -- the size of the rounding differences between two fp32 summation orders of the same chain (the MFMAs accumulate 8
+    k-steps onto C; this model adds one torch matmul to C).  Where the chains cancel (dP - delta under a dominant sink; X = s - lse at
+    |s| ~ 10^2-10^3 raw units feeding exp2) that noise is amplified into dS and through the key sum into dq / dk: the spread between noisy
+    runs and the plain run is the CONDITIONING of each output, which the GPU test adds to its two-bf16-step bar.
+
     q [B, L, Hq, 128], k / v [B, L, Hkv, 128], o / do [B, L, Hq, 128] bf16, lse [B, Hq, L] fp32 (CPU) -> dq, dk, dv bf16 in the same layouts."""
+    gen = None if noise is None else torch.Generator().manual_seed(int(noise))
+
+    def jitter(t):
+        return t if gen is None else t * (1.0 + (torch.rand(t.shape, generator=gen) * 2.0 - 1.0) * 2.0 ** -21)
+
     B, L, Hq, d = q.shape
     assert d == D
     Hkv = k.shape[2]
@@ -317,8 +328,8 @@ def attn4_backward_model(q, k, v, o, do, lse, seqlens, causal, scale):
             for hq in range(hk * rep, (hk + 1) * rep):
                 Q, dO, O = q[b, :n, hq].float(), do[b, :n, hq].float(), o[b, :n, hq].float()
                 delta = (dO * O).sum(-1)
-                X = (-lse[b, hq, :n] * inv_scale)[:, None] + Q @ K.t()
-                Y = -delta[:, None] + dO @ V.t()
+                X = jitter((-lse[b, hq, :n] * inv_scale)[:, None].expand(n, n)) + jitter(Q @ K.t())
+                Y = jitter(-delta[:, None].expand(n, n)) + jitter(dO @ V.t())
                 P = torch.exp2(c * X)
                 if causal:
                     P = P.masked_fill(~torch.ones(n, n, dtype=torch.bool).tril(), 0.0)
