@@ -67,6 +67,17 @@ int mm355_gemm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64
                     uint32_t flags, int variant, void* stream);
 int mm355_gemm_num_variants(void);
 
+/* Split-K form for PROMPT-PASS shapes (reference: the same nn.Linear calls, reached with a few hundred rows when `generate` runs the prompt,
+ * metamorph_llama.py:665-717): C[M][N] = bf16(A . B^T (+ residual)) with K cut into slices that run as separate workgroups of ONE launch (64 x
+ * 128 tiles x slices; fp32 partials in `workspace`, summed in slice order by a second launch).  At M <= ~1000 against N = 4096 .. 6144 the plain
+ * kernels are a latency chain of one LDS-DMA round trip per K tile (down_proj, K = 14336: 184 us at any such M); the slices run side by side.
+ * Not bit-identical to mm355_gemm_bf16 (another fp32 summation order).  workspace: mm355_gemm_splitk_ws_floats(M, N, K) floats (0: the shape
+ * is not split -- the call then forwards to mm355_gemm_bf16 and needs none).  K % 64 == 0, N % 8 == 0, leading dimensions % 8 == 0. */
+int64_t mm355_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t K);
+int mm355_gemm_splitk_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr, float* workspace,
+                           int64_t workspace_floats, void* stream);
+
 /* Fused gate|up projection + SwiGLU of the LLaMA MLP (reference: HF LlamaMLP `down_proj(act_fn(gate_proj(x)) * up_proj(x))`, reached at
  * metamorph_llama.py:349-359):  gu[M][2 I] = X[M][K] . Wgu[2 I][K]^T  (gate columns 0..I-1, up columns I..2I-1, exactly what
  * mm355_gemm_bf16 writes) AND act[M][I] = bf16(silu(gate)) * up from the bf16-rounded gu values (exactly what mm355_swiglu_fwd writes), in

@@ -308,7 +308,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
-    const int M = a.M, N = a.N, K = a.K;
+    // split-K: slice blockIdx.y of K (prompt-pass shapes: a few hundred rows against one weight -- the K loop is a latency chain of one
+    // LDS-DMA round trip per 64-wide tile; S slices run as S times as many workgroups side by side); C = fp32 partials [slice][M][ldc]
+    const int sl = a.kslice ? (int)blockIdx.y : 0;
+    const uint16_t* Ab = a.A + (TNL ? (int64_t)sl * a.kslice * a.lda : (int64_t)sl * a.kslice);
+    const uint16_t* Bb = a.B + (TNL ? (int64_t)sl * a.kslice * a.ldb : (int64_t)sl * a.kslice);
+    const int M = a.M, N = a.N, K = a.kslice ? min(a.kslice, a.K - sl * a.kslice) : a.K;
     const int nk = (K + 63) >> 6;
 
     f32x4 acc[FM][FN];
@@ -330,13 +335,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         for (int i = 0; i < AV; ++i) {
             const int v = tid + i * NT, row = v >> 3, c = v & 7;
             const int gr = min(m0 + row, M - 1), k = k0 + c * 8;
-            ra[i] = (k < K) ? *(const u32x4*)(a.A + (int64_t)gr * a.lda + k) : u32x4{0u, 0u, 0u, 0u};
+            ra[i] = (k < K) ? *(const u32x4*)(Ab + (int64_t)gr * a.lda + k) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < BV; ++i) {
             const int v = tid + i * NT, row = v >> 3, c = v & 7;
             const int gr = min(n0 + row, N - 1), k = k0 + c * 8;
-            rb[i] = (k < K) ? *(const u32x4*)(a.B + (int64_t)gr * a.ldb + k) : u32x4{0u, 0u, 0u, 0u};
+            rb[i] = (k < K) ? *(const u32x4*)(Bb + (int64_t)gr * a.ldb + k) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto lstore = [&](int buf) {
@@ -362,10 +367,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         const int c = (lane & 7) ^ rin;                      // source chunk that belongs in LDS slot (lane & 7)
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            srcA[i] = a.A + (int64_t)min(m0 + (i * NW + wave_s) * 8 + rin, M - 1) * a.lda + c * 8;
+            srcA[i] = Ab + (int64_t)min(m0 + (i * NW + wave_s) * 8 + rin, M - 1) * a.lda + c * 8;
 #pragma unroll
         for (int i = 0; i < BI; ++i)
-            srcB[i] = a.B + (int64_t)min(n0 + (i * NW + wave_s) * 8 + rin, N - 1) * a.ldb + c * 8;
+            srcB[i] = Bb + (int64_t)min(n0 + (i * NW + wave_s) * 8 + rin, N - 1) * a.ldb + c * 8;
     } else {
         // [64 k][256 cols] tiles, 512-B rows: a 1-KiB piece is 2 k-rows; physical 16-B chunk = logical ^ f(row) with
         // f(row) = 2*(row & 3) + 8*((row >> 3) & 1) so that the 8 rows x 2 chunks of one tr-read half-wave hit 16 distinct slots
@@ -375,13 +380,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
         for (int i = 0; i < AI; ++i) {
             const int row = (i * NW + wave_s) * 2 + rinT;
             const int c = pcT ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
-            srcA[i] = a.A + (int64_t)row * a.lda + min(m0 + c * 8, M - 8);
+            srcA[i] = Ab + (int64_t)row * a.lda + min(m0 + c * 8, M - 8);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int row = (i * NW + wave_s) * 2 + rinT;
             const int c = pcT ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
-            srcB[i] = a.B + (int64_t)row * a.ldb + min(n0 + c * 8, N - 8);
+            srcB[i] = Bb + (int64_t)row * a.ldb + min(n0 + c * 8, N - 8);
         }
     }
     auto gdma = [&](int kt, int buf) {
@@ -532,6 +537,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs a) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if (a.kslice) {                                          // this slice's partial tile, plain fp32 (the host set OUT_F32 and no other flag)
+        GemmArgs e = a;
+        e.C = (float*)a.C + (int64_t)sl * a.M * a.ldc;
+        gemm_epilogue<TM, TN, FM, FN>(acc, e, smem, m0, n0, wm, wn, wave, lane);
+        return;
+    }
     gemm_epilogue<TM, TN, FM, FN>(acc, a, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -1393,6 +1404,80 @@ __global__ __launch_bounds__(1024) void colsum8_kernel(const uint16_t* __restric
 }
 
 }  // namespace
+
+namespace {
+// out[m][n] = bf16(sum_s part[s][m][n] (+ residual[m][n])), slices added in order s = 0 .. S-1 (fixed order: reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, const uint16_t* __restrict__ res,
+                                                            int64_t ldr, uint16_t* __restrict__ out, int64_t ldc) {
+    const int nv = N >> 3;
+    const int64_t total = (int64_t)M * nv, plane = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nv), c = (int)(i % nv) * 8;
+        float v[8];
+        const float* p = part + (int64_t)m * N + c;
+        const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        for (int s = 1; s < S; ++s) {
+            const f32x4 b0 = *(const f32x4*)(p + s * plane), b1 = *(const f32x4*)(p + s * plane + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (res) {
+            float r[8];
+            unpack8(*(const u32x4*)(res + (int64_t)m * ldr + c), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        *(u32x4*)(out + (int64_t)m * ldc + c) = pack8(v);
+    }
+}
+
+// slices for a prompt-pass problem: enough workgroups (64 x 128 tiles x slices) to put ~3 on every CU, at least 8 K tiles per slice
+int splitk_slices(int64_t M, int64_t N, int64_t K) {
+    if (K % 64 || N % 8 || M > 4096) return 1;
+    const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128), nk = K / 64;
+    int S = (int)std::min<int64_t>(8, (768 + tiles - 1) / tiles);
+    while (S > 1 && nk / S < 8) --S;
+    return S;
+}
+}  // namespace
+
+extern "C" int64_t mm355_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int S = splitk_slices(M, N, K);
+    return S > 1 ? (int64_t)S * M * N : 0;
+}
+
+extern "C" int mm355_gemm_splitk_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr, float* workspace,
+                                      int64_t workspace_floats, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
+    const int S = splitk_slices(M, N, K);
+    if (S <= 1)                                              // nothing to split: the plain kernel (same call a caller would have made)
+        return mm355_gemm_bf16(A, lda, B, ldb, C, ldc, M, N, K, nullptr, residual, ldr, 0, residual ? MM355_GEMM_RESIDUAL : 0u, 0, stream);
+    if ((lda & 7) || (ldb & 7) || (ldc & 7) || (residual && (ldr & 7)) || !mm_aligned16(A) || !mm_aligned16(B) || !mm_aligned16(C) ||
+        (residual && !mm_aligned16(residual)) || !workspace || !mm_aligned16(workspace) || workspace_floats < (int64_t)S * M * N)
+        return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.C = workspace; a.lda = lda; a.ldb = ldb; a.ldc = N;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = MM355_GEMM_OUT_F32;
+    const int64_t nk = K / 64;
+    a.kslice = (int)((nk + S - 1) / S) * 64;
+    constexpr int BM = 64, BN = 128;
+    auto kern = gemm_nt_kernel<BM, BN, 1, 4, true, 0, false>;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (mm_ensure_dynamic_lds((const void*)kern, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+    a.ntm = (int)((M + BM - 1) / BM);
+    a.ntn = (int)((N + BN - 1) / BN);
+    const int slices = (int)((K + a.kslice - 1) / a.kslice);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn), (unsigned)slices), dim3(256), LDS, (hipStream_t)stream, a);
+    const int64_t vecs = M * (N / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((vecs + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, slices, (int)M, (int)N, (const uint16_t*)residual, ldr, (uint16_t*)C, ldc);
+    return mm_launch_status();
+}
 
 extern "C" int mm355_gemm_num_variants(void) { return 14; }
 

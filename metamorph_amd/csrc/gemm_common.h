@@ -19,7 +19,8 @@ struct GemmArgs {
     uint16_t* aux0;                                          // fused SwiGLU-backward epilogue: actT [I][ld_aux]
     uint16_t* aux1;                                          //                                 dguT [2 I][ld_aux]
     int64_t ld_aux;
-};
+    int kslice;                                              // split-K (gemm_nt_kernel only): K elements per blockIdx.y slice, 0 = off; C is then the
+};                                                           // fp32 partial buffer [slices][M][ldc]
 
 // ragged-edge epilogue (N tail or unaligned leading dimensions): one element at a time, kept out of line
 // so the unrolled fast path stays small.

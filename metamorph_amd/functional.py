@@ -35,7 +35,10 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             "decode_fold_rows": 4,                           # decode step: fold the RMSNorms into the GEMVs' operand reads up to this many rows
             # one launch for an input-gradient GEMM and the weight-gradient GEMM that reads the same dy: (dn2, dW_gate_up) and (dX_o, dW_o)
             # -- the mechanism of dw_pair (mm355_gemm_pair_bf16: same kernel body, same bits), saving one ramp and tail per pair
-            "dx_pair": True}
+            "dx_pair": True,
+            # prompt pass of a cached decode: q|k|v, o and down projections through the split-K GEMM (a few hundred rows: the plain kernels are a
+            # latency chain over K there)
+            "prefill_splitk": True}
 
 
 def set_variant(name, value):
@@ -304,6 +307,9 @@ class LayerMeta:
         # [B, L] layout the attention kernels address (per-sample lengths from row b * L).  c2p int32 [rows]: padded row of every compact
         # row (-1: a zero row of the tail); p2c int32 [B * L]: compact row of every padded row (-1: padding).  None: x IS the padded layout.
         self.c2p, self.p2c = c2p, p2c
+        # prompt pass of a cached decode (decoder_prefill sets it): a few hundred rows -- the q|k|v, o and down projections take the split-K
+        # GEMM (ops.gemm_splitk); inference only
+        self.prompt_pass = False
         self.scale = d ** -0.5
         # gradient checkpointing (reference train.py:1443-1449 + `--gradient_checkpointing True` in every launch script): keep only
         # the layer input, re-run the layer's forward kernels at the start of its backward
@@ -321,7 +327,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
         qkv = ops.gemm_rope(n1, wqkv, m.B, m.L, m.Hq, m.Hkv, m.d, m.cos, m.sin, pos_offset=m.pos_offset)     # rotation in the GEMM epilogue: same bits
         del n1
     else:
-        qkv = ops.gemm(n1, wqkv)
+        qkv = ops.gemm_splitk(n1, wqkv) if m.prompt_pass else ops.gemm(n1, wqkv)
         del n1
         if m.p2c is not None:                                  # compact rows -> the padded layout attention addresses (padding rows: zeros)
             qkv = ops.rows_gather(qkv, m.p2c)
@@ -330,7 +336,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
     o, lse = ops.attn_fwd(qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:], m.B, m.L, m.Hq, m.Hkv, m.d, m.scale, True, m.seqlens)
     if m.c2p is not None:
         o = ops.rows_gather(o, m.c2p)                          # back to compact rows for o_proj and everything after it
-    x2 = ops.gemm(o, att.o_proj.weight, residual=x)
+    x2 = ops.gemm_splitk(o, att.o_proj.weight, residual=x) if m.prompt_pass else ops.gemm(o, att.o_proj.weight, residual=x)
     n2, rstd2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, m.eps, want_rstd=True)
     if VARIANTS["fuse_swiglu"] and ops.gemm_swiglu_supported(n2, wgu, m.I):
         gu, act = ops.gemm_swiglu(n2, wgu, m.I)                # SiLU(gate) * up formed in the GEMM epilogue: same bits, one pass less
@@ -339,7 +345,7 @@ def decoder_layer_forward(x, layer, m: LayerMeta):
         gu = ops.gemm(n2, wgu)
         del n2
         act = ops.swiglu_fwd(gu, m.I)
-    y = ops.gemm(act, mlp.down_proj.weight, residual=x2)
+    y = ops.gemm_splitk(act, mlp.down_proj.weight, residual=x2) if m.prompt_pass else ops.gemm(act, mlp.down_proj.weight, residual=x2)
     # rstd1 / rstd2 (fp32 [M] each): the backward pass rebuilds the TRANSPOSED norm outputs from them in one pass (rmsnorm_apply_t)
     return y, (qkv, o, lse, x2, gu, rstd1, rstd2)
 
@@ -802,6 +808,7 @@ def decoder_prefill(x, layers, meta, cache, row=0):
     B = meta.B
     L = x.shape[0] // B
     assert B == 1 or (B == cache.batch and row == 0)
+    meta.prompt_pass = VARIANTS["prefill_splitk"] and not torch.is_grad_enabled() and x.shape[0] <= 4096
     for i, layer in enumerate(layers):
         params_ready(layer)
         x, saved = decoder_layer_forward(x, layer, meta)

@@ -86,6 +86,29 @@ def gemm(a, b, out=None, *, bias=None, residual=None, res_row_mod=0, gelu=None, 
     return out
 
 
+def gemm_splitk(a, b, residual=None, out=None):
+    """out[M, N] = a[M, K] . b[N, K]^T (+ residual), K cut into slices that run side by side (mm355_gemm_splitk_bf16): the prompt-pass form --
+    a few hundred rows against one weight, where the plain kernels are a latency chain over K.  Shapes it would not split go to the plain
+    kernel inside the library.  Another fp32 summation order than ops.gemm: equal to accumulation accuracy, not bit for bit."""
+    _chk_dev(a, b, residual, out)
+    assert a.dtype == BF16 and b.dtype == BF16
+    pa, M, K, lda = _rows2d(a)
+    pb, N, Kb, ldb = _rows2d(b)
+    assert K == Kb
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+    po, _, _, ldc = _rows2d(out)
+    pr, ldr = 0, 0
+    if residual is not None:
+        pr, Mr, Nr, ldr = _rows2d(residual)
+        assert (Mr, Nr) == (M, N)
+    n_ws = int(_L().mm355_gemm_splitk_ws_floats(M, N, K))
+    ws = torch.empty((max(n_ws, 4),), device=a.device, dtype=torch.float32)
+    _lib.check(_L().mm355_gemm_splitk_bf16(pa, lda, pb, ldb, po, ldc, M, N, K, pr, ldr, ws.data_ptr(), n_ws, _stream()),
+               f"mm355_gemm_splitk_bf16 M={M} N={N} K={K}")
+    return out
+
+
 def gemm_pair_supported(a0, b0, a1, b1):
     """Both problems fit mm355_gemm_pair_bf16 (plain NT operands, whole pairs of K tiles, 31-bit operand offsets)."""
     return (a0.shape[1] == b0.shape[1] and a1.shape[1] == b1.shape[1]

@@ -860,6 +860,34 @@ def test_gemm_small_m_tiles_are_bit_identical_and_selected_for_prompt_shapes(ops
         assert torch.equal(acc9, acc2)
 
 
+@pytest.mark.parametrize("shape", [(512, 4096, 14336), (128, 6144, 4096), (520, 4096, 4096), (1000, 1152, 4352), (64, 1024, 512), (2048, 28672, 4096)])
+def test_gemm_splitk_against_the_plain_kernel_and_fp64(ops, shape):
+    """mm355_gemm_splitk_bf16 (the prompt-pass form: K slices as separate workgroups of one launch, fp32 partials summed in slice order):
+    against an fp64 product within one bf16 rounding + the fp32 accumulation bound, against mm355_gemm_bf16 within one bf16 step (another
+    summation order), with and without the residual; shapes it does not split ((64, 1024, 512): K too short; (2048, 28672, 4096): enough
+    tiles) forward to the plain kernel and ARE bit-identical; two runs of the split form are bit-identical (fixed slice order)."""
+    from metamorph_amd import lib as mmlib
+    M, N, K = shape
+    a, b, res = rnd(M, K, seed=M), rnd(N, K, seed=N, scale=0.05), rnd(M, N, seed=7)
+    ad, bd, rd = a.to(DEV), b.to(DEV), res.to(DEV)
+    split = int(mmlib.load().mm355_gemm_splitk_ws_floats(M, N, K)) > 0
+    assert split == (shape not in ((64, 1024, 512), (2048, 28672, 4096)))
+    ref = a.double() @ b.double().t()
+    bound = 4.0 * K * 2.0 ** -24 * (a.double().abs() @ b.double().abs().t())
+    for r, rr in ((None, 0.0), (rd, res.double())):
+        got = ops.gemm_splitk(ad, bd, residual=r)
+        plain = ops.gemm(ad, bd, residual=r)
+        want = ref + rr
+        err = (got.double().cpu() - want).abs()
+        assert bool((err <= 2.0 ** -8 * want.abs() + bound).all()), (shape, r is not None, float(err.max()))
+        if split:
+            d = (got.float() - plain.float()).abs()
+            assert bool((d <= 2.0 ** -7 * plain.float().abs() + 1e-6).all()), (shape, float(d.max()))
+            assert torch.equal(got, ops.gemm_splitk(ad, bd, residual=r))
+        else:
+            assert torch.equal(got, plain)
+
+
 def test_cosine_loss(ops):
     Rr, C = 21, 1152
     p, t = rnd(Rr, C, seed=1), R.l2_normalize(rnd(Rr, C, seed=2).float()).bfloat16()

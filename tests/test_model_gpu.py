@@ -544,6 +544,36 @@ def test_cached_decode_matches_full_forward():
         assert cache.length == L
 
 
+def test_prompt_pass_split_k_equals_the_plain_projections():
+    """The prompt pass of a cached decode sends q|k|v, o and down through the split-K GEMM (functional.VARIANTS["prefill_splitk"]; h = 1024,
+    300 rows: two K slices): hidden rows and the cached K / V rows against the same pass on the plain kernels -- one bf16 step (another fp32
+    summation order), and the continuation of the decode reads the same argmax."""
+    from metamorph_amd import functional as F
+    cfg = tiny_cfg(hidden_size=1024, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=2, num_hidden_layers=3)
+    model = hip_model(cfg, init_state_dict(cfg, seed=23, dtype=torch.bfloat16)).eval()
+    L0 = 300
+    g = torch.Generator().manual_seed(8)
+    emb = (torch.randn(L0, cfg.hidden_size, generator=g) * 0.5).bfloat16().to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for on in (True, False):
+            old = F.set_variant("prefill_splitk", on)
+            try:
+                _, meta = model._decode_meta(L0)
+                cos, sin = model.model.rope_tables(L0 + 4, DEV)
+                meta.cos, meta.sin = cos, sin
+                cache = F.KVCache(cfg.num_hidden_layers, L0 + 4, meta.Hkv * meta.d, DEV)
+                x = F.decoder_prefill(emb.clone(), model.model.layers, meta, cache)
+                assert meta.prompt_pass is on
+                outs[on] = (x.float().clone(), cache.k[:, 0, :L0].float().clone(), cache.v[:, 0, :L0].float().clone(), model._head_row(x[-1:].contiguous(), False)[0].clone())
+            finally:
+                F.set_variant("prefill_splitk", old)
+    for a, b, what in zip(outs[True][:3], outs[False][:3], ("hidden rows", "cached k", "cached v")):
+        assert rel(a, b) < 6e-3, (what, rel(a, b))
+        assert not torch.equal(a, b) or what != "hidden rows"      # the split form really ran (another summation order)
+    assert int(outs[True][3].argmax()) == int(outs[False][3].argmax())
+
+
 def test_cached_image_mode_head_matches_reference_loop_step():
     """Image mode: vision_head -> L2 norm -> mm_projector on the last row; cached head == llm_forward(decoding=True)."""
     cfg, model = _decode_model()
