@@ -882,7 +882,8 @@ def test_gemm_splitk_against_the_plain_kernel_and_fp64(ops, shape):
         assert bool((err <= 2.0 ** -8 * want.abs() + bound).all()), (shape, r is not None, float(err.max()))
         if split:
             d = (got.float() - plain.float()).abs()
-            assert bool((d <= 2.0 ** -7 * plain.float().abs() + 1e-6).all()), (shape, float(d.max()))
+            # one bf16 step; near-zero outputs (a cancellation of K terms of size ~3: |value| ~ 1e-5) carry the fp32 summation noise itself
+            assert bool((d <= 2.0 ** -7 * torch.maximum(plain.float().abs(), got.float().abs()) + 2e-4).all()), (shape, float(d.max()))
             assert torch.equal(got, ops.gemm_splitk(ad, bd, residual=r))
         else:
             assert torch.equal(got, plain)
