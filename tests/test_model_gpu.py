@@ -1242,6 +1242,40 @@ def test_padding_free_rows_equal_the_padded_path(side):
           f"worst rel diff {worst[0]:.2e} ({worst[1]})")
 
 
+def test_padding_free_rows_under_gradient_checkpointing_are_bit_identical():
+    """Per-layer recompute (`gradient_checkpointing_enable()`, every reference launch script) re-runs a layer's forward kernels on the same
+    compact rows: loss and every gradient equal the non-recomputing compact run bit for bit."""
+    cfg = OracleConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       vocab_size=32002, v_layers=1, v_intermediate=144, v_image=56, num_image_tokens=16, tokenizer_model_max_length=512,
+                       image_start_id=32000)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.zeros((2, 300), dtype=torch.long)
+    labels = torch.full((2, 300), -100, dtype=torch.long)
+    mask = torch.zeros((2, 300), dtype=torch.bool)
+    for b, n in enumerate((300, 120)):
+        row = torch.randint(3, 31999, (n,), generator=g)
+        row[0] = 1
+        row[n - 4], row[n - 3], row[n - 2] = 32000, -200, 32001
+        ids[b, :n], mask[b, :n] = row, True
+        labels[b, n // 2:n] = row[n // 2:]
+        labels[b, n - 3] = -200
+    images = torch.randn(2, 3, 56, 56, generator=g)
+    sd = init_state_dict(cfg, seed=29, dtype=torch.bfloat16)
+    res = []
+    for ckpt in (False, True):
+        model = hip_model(cfg, sd)
+        model.train()
+        if ckpt:
+            model.gradient_checkpointing_enable()
+        out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), images=images.to(DEV).bfloat16())
+        out.loss.backward()
+        assert model._decoder_rows[0] < model._decoder_rows[1]             # compact rows were on (28 % padding)
+        res.append((out.loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        del model
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1].keys() == res[1][1].keys()
+    assert all(torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
+
+
 # ------------------------------------------------------------------ the fp32 oracle evaluated on the device (round 6)
 def test_streamed_oracle_on_device_against_reference_recorded_8_layer_run():
     """oracle/ref_stream.full_depth(device="cuda") -- the evaluation the full-width tests below use for their fp32 truth -- DIRECTLY against
