@@ -38,7 +38,9 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             "dx_pair": True,
             # prompt pass of a cached decode: q|k|v, o and down projections through the split-K GEMM (a few hundred rows: the plain kernels are a
             # latency chain over K there)
-            "prefill_splitk": True}
+            "prefill_splitk": True,
+            # decode step of MORE than 16 sequences: one pass over the weights through the split-K GEMM instead of one GEMV pass per 16 rows
+            "decode_wide_gemm": True}
 
 
 def set_variant(name, value):
@@ -772,7 +774,7 @@ class KVCache:
         self.len_dev = torch.ones(batch, device=device, dtype=torch.int32)       # = pos + 1: rows visible to that token
         self.ws = None
         if Hq is not None:                                                       # (rows are stepped at most 16 at a time: the GEMV kernels' limit)
-            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(min(batch, 16), Hq, d, max_len)), device=device,
+            self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(batch, Hq, d, max_len)), device=device,
                                   dtype=torch.float32)                           # arrival counters start at 0
 
     @property
@@ -864,6 +866,28 @@ def _decode_rows16(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bou
     return x
 
 
+def _decode_rows_gemm(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_bound):
+    """17 new rows and more (one per sequence) through every decoder layer in ONE pass over the weights (round 6; rounds 5: chunks of 16 rows,
+    i.e. the 15 GB read once per chunk).  The GEMV kernels hold one 16-row MFMA operand; beyond it the projections take the split-K GEMM of
+    the prompt pass (mm355_gemm_splitk_bf16: 64 x 128 tiles x K slices -- at 32 rows a weight-streaming problem with ~3 workgroups per CU),
+    RoPE + cache append, attention per row at its own length, SwiGLU as their own launches: nine launches per layer for any number of rows."""
+    nq = meta.Hq * meta.d
+    for i, layer in enumerate(layers):
+        params_ready(layer)
+        att, mlp = layer.self_attn, layer.mlp
+        wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
+        wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
+        n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
+        qkv = ops.gemm_splitk(n1, wqkv)
+        ops.rope_kv_append_(qkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i])
+        o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, kv_bound, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
+        x2 = ops.gemm_splitk(o, att.o_proj.weight, residual=x)
+        n2 = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, meta.eps)
+        act = ops.swiglu_fwd(ops.gemm_splitk(n2, wgu), meta.I)
+        x = ops.gemm_splitk(act, mlp.down_proj.weight, residual=x2)
+    return x
+
+
 SHORT_KV = 1024                                              # mm355_attn_decode: a bound of <= 1024 rows is one key group (no merge, more workgroups)
 
 
@@ -892,7 +916,9 @@ def decoder_decode_row(x, layers, meta, cache, cos, sin, kv_bound=None):
         raise ValueError(f"decode bound {bound} is below the longest sequence + 1 ({cache.length + 1}); lengths change only through set_lengths")
     if B <= 16:
         y = _decode_rows16(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, bound)
-    else:
+    elif VARIANTS["decode_wide_gemm"]:
+        y = _decode_rows_gemm(x, layers, meta, cos, sin, cache.k, cache.v, cache.pos_dev, cache.len_dev, cache.ws, bound)
+    else:                                                    # (rounds 5: one pass over the weights per chunk of 16 rows)
         y = torch.cat([_decode_rows16(x[c:c + 16], layers, meta, cos, sin, cache.k[:, c:c + 16], cache.v[:, c:c + 16], cache.pos_dev[c:c + 16],
                                       cache.len_dev[c:c + 16], cache.ws, bound) for c in range(0, B, 16)], 0)
     cache.pos_dev.add_(1)

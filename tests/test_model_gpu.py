@@ -780,12 +780,12 @@ def test_config_fields_of_real_checkpoints_are_supported_or_refused_by_name():
             MetaMorphLlamaForCausalLM(MetaMorphConfig(**base, **{field: True}))
 
 
-@pytest.mark.parametrize("B", [3, 8, 11, 19])
+@pytest.mark.parametrize("B", [3, 8, 11, 19, 35])
 def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypatch):
     """The cached step of a batch (reference: the whole batch goes to ONE forward per step, metamorph_llama.py:711-717) takes all B rows
     through every decoder layer in one pass -- 5 launches per layer (7 from five rows on: the norms run on their own) for B <= 16 (the GEMV
-    kernels' M), ceil(B / 16) x that beyond -- not
-    B passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
+    kernels' M); beyond 16 rows (round 6) still ONE pass: the projections take the split-K GEMM, attention one launch per layer -- not
+    B passes, and not ceil(B / 16) passes; and every sequence gets what it gets alone: prompts of B different lengths (left-padded batch), eight greedy steps, per-step
     logits of every row against the same prompt decoded on its own (accumulation-order accuracy; argmax ids equal wherever the top two
     logits are further apart than that accuracy)."""
     import metamorph_amd.functional as F
@@ -812,6 +812,8 @@ def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypat
     n_dec = len(launches)
     print(f"\n   B={B}: {n_dec} decode-shape launches over {steps} cached steps (+ prompt pass)")
     assert n_dec <= (steps + 1) * per_step + 2 * B, (n_dec, steps, per_step)      # one pass per step for the batch, not one per row
+    if B > 16:                                                   # one attention launch per layer and step: the batch was not chunked
+        assert launches.count("attn_decode") == steps * cfg.num_hidden_layers, (launches.count("attn_decode"), steps)
     monkeypatch.undo()
     for b in range(B):
         alone = model.generate(inputs=ids[b:b + 1, n - lens[b]:].to(DEV), **kw)
