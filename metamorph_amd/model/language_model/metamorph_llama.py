@@ -29,7 +29,7 @@ from transformers.modeling_outputs import CausalLMOutputWithPast
 from ... import functional as F
 from ... import ops
 from ...constants import DEFAULT_IMAGE_END_ID, DEFAULT_IMAGE_START_ID, IGNORE_INDEX
-from ...splice_plan import SplicePlan
+from ...splice_plan import SplicePlan, compact_row_maps
 from ...hostmirror import host_array
 from ...rope import head_dim as _head_dim, rope_params
 from ..metamorph_arch import MetaMorphMetaForCausalLM, MetaMorphMetaModel, upload_plan
@@ -53,24 +53,6 @@ def _left_pad_maps(seqlens, B, L):
         to_right[b * L:b * L + n] = b * L + off[b] + np.arange(n, dtype=np.int32)
         to_left[b * L + off[b]:(b + 1) * L] = b * L + np.arange(n, dtype=np.int32)
     return to_right, to_left, off
-
-
-def compact_row_maps(seqlens, B, L, granule=256):
-    """Row maps between the right-padded layout (row b * L + l, valid for l < n_b) and the compact one (the valid rows back to back, rounded
-    up to `granule` rows -- whole GEMM tiles and whole 64-row transposed vectors): (c2p int32 [rows]: padded row of every compact row, -1 in
-    the tail; p2c int32 [B * L]: compact row of every padded row, -1 for padding)."""
-    n = np.asarray(seqlens, dtype=np.int64)
-    total = int(n.sum())
-    rows = max(granule, (total + granule - 1) // granule * granule)
-    c2p = np.full(rows, -1, dtype=np.int32)
-    p2c = np.full(B * L, -1, dtype=np.int32)
-    at = 0
-    for b in range(B):
-        k = int(n[b])
-        c2p[at:at + k] = b * L + np.arange(k, dtype=np.int32)
-        p2c[b * L:b * L + k] = at + np.arange(k, dtype=np.int32)
-        at += k
-    return c2p, p2c
 
 
 class _Attention(nn.Module):
@@ -399,9 +381,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         mode = getattr(cfg, "mm355_compact_rows", "auto")
         n_valid_rows = int(plan.seqlens.sum())
         if mode is True or (mode == "auto" and B * L - n_valid_rows >= 0.08 * B * L and n_valid_rows > 0):
-            c2p, p2c = compact_row_maps(plan.seqlens, B, L)
-            both = torch.from_numpy(np.concatenate([c2p, p2c])).to(dev)
-            c2p_d, p2c_d = both[:c2p.shape[0]], both[c2p.shape[0]:]
+            c2p_d, p2c_d = pd["c2p"], pd["p2c"]                        # uploaded with the rest of the plan (one pinned, asynchronous copy)
         self._decoder_rows = (int(c2p_d.shape[0]) if c2p_d is not None else B * L, B * L)     # (rows the decoder ran on, padded rows): introspection
         meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],
                            recompute=bool(self.model.gradient_checkpointing) and self.training, pos_offset=pos_off, c2p=c2p_d, p2c=p2c_d)

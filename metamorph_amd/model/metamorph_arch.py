@@ -16,7 +16,7 @@ from .. import functional as F
 from .. import ops
 from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_IMAGE_START_ID
 from ..hostmirror import host_array
-from ..splice_plan import SplicePlan, build_splice_plan
+from ..splice_plan import SplicePlan, build_splice_plan, compact_row_maps
 from .modules import HipLinear
 from .multimodal_encoder.builder import build_vision_tower
 from .multimodal_projector.builder import build_vision_projector
@@ -113,6 +113,8 @@ def upload_plan(plan: SplicePlan, device, extra=None) -> PlanOnDevice:
         inv = np.full(M, -1, dtype=np.int32)
         inv[plan.ce_rows] = np.arange(plan.ce_rows.shape[0], dtype=np.int32)
         arrays["ce_inv"] = inv
+    # padding-free decoder rows (ragged batches): compact <-> padded row maps over the right-padded layout the decoder runs in
+    arrays["c2p"], arrays["p2c"] = compact_row_maps(plan.seqlens, plan.B, plan.L)
     for k, v in (extra or {}).items():
         if v is not None:
             arrays["x_" + k] = np.ascontiguousarray(v)

@@ -191,3 +191,21 @@ def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_p
                       target_keep=target_keep, feat_row=feat_row, pred_rows=pred_rows, shift_targets=shift_targets,
                       ce_rows=ce_rows, n_valid=n_valid, emb_tok=emb_tok, emb_seg=emb_seg, emb_pos=emb_pos,
                       images_consumed=img, padding_side=padding_side)
+
+
+def compact_row_maps(seqlens, B, L, granule=256):
+    """Row maps between the right-padded layout (row b * L + l, valid for l < n_b) and the compact one (the valid rows back to back, rounded
+    up to `granule` rows -- whole GEMM tiles and whole 64-row transposed vectors): (c2p int32 [rows]: padded row of every compact row, -1 in
+    the tail; p2c int32 [B * L]: compact row of every padded row, -1 for padding)."""
+    n = np.asarray(seqlens, dtype=np.int64)
+    total = int(n.sum())
+    rows = max(granule, (total + granule - 1) // granule * granule)
+    c2p = np.full(rows, -1, dtype=np.int32)
+    p2c = np.full(B * L, -1, dtype=np.int32)
+    at = 0
+    for b in range(B):
+        k = int(n[b])
+        c2p[at:at + k] = b * L + np.arange(k, dtype=np.int32)
+        p2c[b * L:b * L + k] = at + np.arange(k, dtype=np.int32)
+        at += k
+    return c2p, p2c
