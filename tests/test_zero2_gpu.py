@@ -59,6 +59,59 @@ def test_model_training_steps_reduce_loss():
     assert all(torch.isfinite(p.float()).all() for p in model.parameters())
 
 
+def test_tied_embeddings_train_as_one_parameter_under_zero2():
+    """`tie_word_embeddings` (LLaMA-3.2 1B / 3B bases; round 6) under the sharded optimizer: lm_head.weight IS embed_tokens.weight -- one
+    Parameter, one slice of the flat buffers, one gradient that receives the fused CE's dW and the splice's embedding-row sums.  Four steps
+    against the oracle trained the same way (autograd through ONE shared tensor + the oracle's AdamW): loss per step to 1 %, the tie survives
+    every step (both modules read the re-pointed flat storage)."""
+    import os
+    from conftest import GOLDEN
+    from test_model_gpu import T, hip_model, tiny_cfg
+    from oracle.ref_model import forward as oracle_forward, init_state_dict
+    from metamorph_amd.zero2 import Zero2AdamW
+    g = np.load(os.path.join(GOLDEN, "e2e_mixed_T4_ar1_tied_bf16.npz"))
+    cfg = tiny_cfg(num_image_tokens=4, tie_word_embeddings=True)
+    sd = init_state_dict(cfg, seed=int(g["seed"]))
+    model = hip_model(cfg, {k: v.bfloat16() for k, v in sd.items()})
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert model.lm_head.weight is model.model.embed_tokens.weight and sum(p is model.lm_head.weight for p in params) == 1
+    opt = Zero2AdamW(params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    args = dict(input_ids=T(g["input_ids"]).cuda(), attention_mask=T(g["attention_mask"]).cuda(), labels=T(g["labels"]).cuda(),
+                images=T(g["images"]).cuda().bfloat16())
+    # the oracle: fp32 weights rounded through bf16 once (what the model holds), the tied tensor shared by both names
+    ref = {k: v.bfloat16().float() for k, v in sd.items()}
+    ref["lm_head.weight"] = ref["model.embed_tokens.weight"]
+    train = {k: v for k, v in ref.items() if "vision_tower" not in k and "vision_proj" not in k and k != "lm_head.weight"}
+    for v in train.values():
+        v.requires_grad_(True)
+    m_ = {k: torch.zeros_like(v) for k, v in train.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in train.items()}
+    hip, ora = [], []
+    for step in range(1, 5):
+        opt.zero_grad()
+        out = model(**args)
+        out.loss.backward()
+        opt.step()
+        hip.append(float(out.loss.detach()))
+        assert model.lm_head.weight is model.model.embed_tokens.weight
+        assert model.lm_head.weight.data_ptr() == model.model.embed_tokens.weight.data_ptr()
+        o = oracle_forward(ref, cfg, T(g["input_ids"]), T(g["attention_mask"]), T(g["labels"]), T(g["images"]), return_logits=False)
+        for v in train.values():
+            v.grad = None
+        o["loss"].backward()
+        ora.append(float(o["loss"].detach()))
+        gn = torch.sqrt(sum((v.grad.float() ** 2).sum() for v in train.values()))
+        coef = min(1.0, 1.0 / (float(gn) + 1e-6))
+        with torch.no_grad():
+            for k, v in train.items():
+                R.adamw_step(v.data.view(-1), v.grad.reshape(-1), m_[k].view(-1), v_[k].view(-1), step, 2e-3, 0.9, 0.999, 1e-8, 0.0, grad_scale=coef)
+    print(f"\n   tied embeddings under Zero2AdamW: loss hip {[round(x, 4) for x in hip]} oracle {[round(x, 4) for x in ora]}")
+    assert hip[-1] < hip[0] - 0.3
+    for a, b in zip(hip, ora):
+        assert abs(a - b) <= 1e-2 * abs(b), (hip, ora)
+
+
 def test_loss_curve_matches_oracle_training():
     """north_star: "loss curves matching reference within tolerance".  Six optimizer steps of the tiny model on one mixed
     batch (text CE + answer-image cosine loss): the HIP run (bf16 activations and weights, fp32 master, Zero2AdamW with
