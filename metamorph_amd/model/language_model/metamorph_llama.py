@@ -234,6 +234,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         self._loss_language_t = None
         self._loss_image_ar_t = None
         self._mm_plan = None
+        self._compact_hwm = {}                      # (B, L) -> compact decoder rows in use (constant across steps: llm_forward)
         self.post_init()
 
     # ------------------------------------------------------------------ HF plumbing
@@ -376,12 +377,23 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
         # varlen, llama_flash_attn_monkey_patch.py:95-104; tokens/s counts VALID tokens): when enough of the B x L rows are
         # padding, the decoder runs on the sum(len) valid rows only (LayerMeta.c2p / p2c) -- norms, GEMMs and SwiGLU never touch a padding
         # row; q|k|v -> attention -> o visits the padded layout through row gathers.  `mm355_compact_rows`: True / False / "auto" (default:
-        # on from 8 % padding, where the saved GEMM rows outweigh the five gathers + one RoPE pass per layer, ~3 % of a layer).
+        # on when at least an eighth of the rows is saved; the gathers + one RoPE pass per layer cost ~2 % of a layer).
         c2p_d = p2c_d = None
         mode = getattr(cfg, "mm355_compact_rows", "auto")
         n_valid_rows = int(plan.seqlens.sum())
-        if mode is True or (mode == "auto" and B * L - n_valid_rows >= 0.08 * B * L and n_valid_rows > 0):
-            c2p_d, p2c_d = pd["c2p"], pd["p2c"]                        # uploaded with the rest of the plan (one pinned, asynchronous copy)
+        if mode is not False and n_valid_rows > 0:
+            # The compact row count is kept CONSTANT across steps of one (B, L) shape: a high-water mark of what the batches seen so far needed,
+            # in steps of 1/16 of B x L.  Tensor sizes that change from step to step defeat the caching allocator at the occupancy a
+            # training run has (222 of 288 GB at B = 16): every new maximum costs a flush of the cache, and PyTorch-ROCm has no expandable
+            # segments -- measured (profiles/r6_ragged_compact_rows.log): per-batch row counts at 5 - 20 % padding ran 1.4 x SLOWER than the
+            # padded layout.  With a constant count the shapes are as static as the padded path's and the saving is that of the fullest batch.
+            step_rows = max(256, (B * L // 16 + 255) // 256 * 256)
+            need = (n_valid_rows + step_rows - 1) // step_rows * step_rows
+            hwm = self._compact_hwm.get((B, L), 0)
+            rows = min(max(need, hwm), (B * L + 255) // 256 * 256)
+            if mode is True or rows <= 0.875 * B * L:                # "auto": at least an eighth of the rows saved
+                self._compact_hwm[(B, L)] = rows
+                c2p_d, p2c_d = pd["c2p"][:rows], pd["p2c"]            # uploaded with the rest of the plan (one pinned, asynchronous copy)
         self._decoder_rows = (int(c2p_d.shape[0]) if c2p_d is not None else B * L, B * L)     # (rows the decoder ran on, padded rows): introspection
         meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],
                            recompute=bool(self.model.gradient_checkpointing) and self.training, pos_offset=pos_off, c2p=c2p_d, p2c=p2c_d)

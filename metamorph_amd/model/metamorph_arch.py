@@ -114,7 +114,7 @@ def upload_plan(plan: SplicePlan, device, extra=None) -> PlanOnDevice:
         inv[plan.ce_rows] = np.arange(plan.ce_rows.shape[0], dtype=np.int32)
         arrays["ce_inv"] = inv
     # padding-free decoder rows (ragged batches): compact <-> padded row maps over the right-padded layout the decoder runs in
-    arrays["c2p"], arrays["p2c"] = compact_row_maps(plan.seqlens, plan.B, plan.L)
+    arrays["c2p"], arrays["p2c"] = compact_row_maps(plan.seqlens, plan.B, plan.L, full=True)
     for k, v in (extra or {}).items():
         if v is not None:
             arrays["x_" + k] = np.ascontiguousarray(v)

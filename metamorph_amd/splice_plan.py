@@ -193,14 +193,16 @@ def build_splice_plan(input_ids, labels, attention_mask, num_images: int, rows_p
                       images_consumed=img, padding_side=padding_side)
 
 
-def compact_row_maps(seqlens, B, L, granule=256):
+def compact_row_maps(seqlens, B, L, granule=256, full=False):
     """Row maps between the right-padded layout (row b * L + l, valid for l < n_b) and the compact one (the valid rows back to back, rounded
     up to `granule` rows -- whole GEMM tiles and whole 64-row transposed vectors): (c2p int32 [rows]: padded row of every compact row, -1 in
-    the tail; p2c int32 [B * L]: compact row of every padded row, -1 for padding)."""
+    the tail; p2c int32 [B * L]: compact row of every padded row, -1 for padding).  full=True: c2p has B * L entries (-1 beyond the valid
+    rows): any prefix of at least `rows` entries is a valid map -- the caller picks the row count (LlamaForCausalLM keeps it constant across
+    steps)."""
     n = np.asarray(seqlens, dtype=np.int64)
     total = int(n.sum())
     rows = max(granule, (total + granule - 1) // granule * granule)
-    c2p = np.full(rows, -1, dtype=np.int32)
+    c2p = np.full(max(rows, (B * L + granule - 1) // granule * granule) if full else rows, -1, dtype=np.int32)
     p2c = np.full(B * L, -1, dtype=np.int32)
     at = 0
     for b in range(B):

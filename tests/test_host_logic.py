@@ -307,7 +307,7 @@ def test_deepspeed_zero2_shard_layout_round_trip(tmp_path, world):
 def test_compact_row_maps_are_inverse_and_tile_aligned():
     """Padding-free rows: c2p / p2c of metamorph_llama.compact_row_maps are inverse on the valid rows, list samples back to back in order, mark
     padding / tail rows -1, and the compact row count is a whole number of 256-row GEMM tiles (>= one tile, also for an all-empty batch)."""
-    from metamorph_amd.model.language_model.metamorph_llama import compact_row_maps
+    from metamorph_amd.splice_plan import compact_row_maps
     rng = np.random.default_rng(5)
     for _ in range(50):
         B, L = int(rng.integers(1, 9)), int(rng.integers(1, 900))
@@ -319,6 +319,10 @@ def test_compact_row_maps_are_inverse_and_tile_aligned():
         assert p2c.shape == (B * L,) and (p2c[c2p[:total]] == np.arange(total)).all()
         valid = (np.arange(L)[None] < n[:, None]).reshape(-1)
         assert ((p2c >= 0) == valid).all()
+        # full = True (what the plan upload carries): one array whose every prefix of >= `rows` entries is a valid map, up to whole tiles of B x L
+        cf, pf = compact_row_maps(n, B, L, full=True)
+        assert cf.shape[0] == max(c2p.shape[0], (B * L + 255) // 256 * 256) and (cf[:c2p.shape[0]] == c2p).all() and (cf[c2p.shape[0]:] == -1).all()
+        assert (pf == p2c).all()
 
 
 def test_llama31_checkpoint_config_round_trips_and_unsupported_fields_are_refused_by_name(tmp_path):
