@@ -773,7 +773,7 @@ class KVCache:
         self.pos_dev = torch.zeros(batch, device=device, dtype=torch.int32)      # row the next token of sequence b is written to
         self.len_dev = torch.ones(batch, device=device, dtype=torch.int32)       # = pos + 1: rows visible to that token
         self.ws = None
-        if Hq is not None:                                                       # (rows are stepped at most 16 at a time: the GEMV kernels' limit)
+        if Hq is not None:                                                       # (sized for the whole batch: beyond 16 rows one attention launch serves all of them)
             self.ws = torch.zeros(int(ops._L().mm355_attn_decode_ws_floats(batch, Hq, d, max_len)), device=device,
                                   dtype=torch.float32)                           # arrival counters start at 0
 
