@@ -811,13 +811,16 @@ def decoder_prefill(x, layers, meta, cache, row=0):
     L = x.shape[0] // B
     assert B == 1 or (B == cache.batch and row == 0)
     meta.prompt_pass = VARIANTS["prefill_splitk"] and not torch.is_grad_enabled() and x.shape[0] <= 4096
+    ident = torch.arange(L, device=x.device, dtype=torch.int32) if B == 1 else None
     for i, layer in enumerate(layers):
         params_ready(layer)
         x, saved = decoder_layer_forward(x, layer, meta)
         qkv = saved[0]
         if B == 1:
-            cache.k[i, row, :L].copy_(qkv[:, nq:nq + nk])
-            cache.v[i, row, :L].copy_(qkv[:, nq + nk:])
+            # the k / v column blocks of the fused activation -> cache rows: a strided row copy with 16-byte vectors (mm355_rows_gather with the
+            # identity map: ~3 us; ATen's strided bf16 copy took 28 us per call, 1.3 of the 10.8 ms of a 512-row prompt pass)
+            ops.rows_gather(qkv[:, nq:nq + nk], ident, out=cache.k[i, row, :L])
+            ops.rows_gather(qkv[:, nq + nk:], ident, out=cache.v[i, row, :L])
         else:
             cache.k[i, :, :L].copy_(qkv[:, nq:nq + nk].view(B, L, nk))
             cache.v[i, :, :L].copy_(qkv[:, nq + nk:].view(B, L, nk))
