@@ -60,8 +60,10 @@ def parse():
                     "BASELINE's LLaMA-3-8B: only the cos / sin TABLES differ, every kernel is the same; said in config.workload")
     ap.add_argument("--ragged", type=float, default=0.0, metavar="SHARE", help="ragged batches with this mean padding share (sample lengths uniform in "
                     "[1 - 2 SHARE, 1] x seq, right-padded to the longest): `value` then counts VALID tokens/s; NOT the headline config")
-    ap.add_argument("--compact-rows", default="auto", choices=("auto", "on", "off"), help="padding-free decoder rows (model.config.mm355_compact_rows): "
+    ap.add_argument("--compact-rows", default="auto", choices=("auto", "on", "off", "exact"), help="padding-free decoder rows (model.config.mm355_compact_rows): "
                     "auto = from 8 %% padding")
+    ap.add_argument("--alloc-roundup", type=int, default=0, metavar="DIV", help="experiment: torch caching allocator roundup_power2_divisions (sizes that "
+                    "change from step to step under --compact-rows exact then fall into few block classes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -529,6 +531,8 @@ def main():
         # docstring gives; rank 0 of the child job prints the ONE JSON line on this process's stdout
         return self_launch(args.gpus)
     torch.cuda.set_device(local)
+    if args.alloc_roundup > 0:
+        torch.cuda.memory._set_allocator_settings(f"roundup_power2_divisions:{args.alloc_roundup}")
     dev = torch.device("cuda", local)
     for kv in args.set_variant:
         import metamorph_amd.functional as F_
@@ -618,7 +622,7 @@ def main():
     n_pool = max(1, args.pool)
     pool = [make_batch(args.batch, args.seq, args.image_tokens, None if args.host_inputs else dev, seed=1234 + rank + 1000 * j,
                        frames=args.frames, all_generation=args.all_generation, ragged=args.ragged) for j in range(n_pool)]
-    model.config.mm355_compact_rows = {"auto": "auto", "on": True, "off": False}[args.compact_rows]
+    model.config.mm355_compact_rows = {"auto": "auto", "on": True, "off": False, "exact": "exact"}[args.compact_rows]
     # valid spliced rows of every pool batch (mask rows + the image rows the splice inserts): what `value` counts under --ragged
     pool_valid = [int(b_[2].sum()) + args.batch * args.frames * (args.image_tokens - 1) for b_ in pool]
     valid_timed = [0]

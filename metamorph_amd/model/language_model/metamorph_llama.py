@@ -391,8 +391,11 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
             need = (n_valid_rows + step_rows - 1) // step_rows * step_rows
             hwm = self._compact_hwm.get((B, L), 0)
             rows = min(max(need, hwm), (B * L + 255) // 256 * 256)
-            if mode is True or rows <= 0.875 * B * L:                # "auto": at least an eighth of the rows saved
-                self._compact_hwm[(B, L)] = rows
+            if mode == "exact":                                      # this batch's own count (256-row granule): sizes change from step to step
+                rows = min((n_valid_rows + 255) // 256 * 256, (B * L + 255) // 256 * 256)
+            if mode is True or mode == "exact" or rows <= 0.875 * B * L:   # "auto": at least an eighth of the rows saved
+                if mode != "exact":
+                    self._compact_hwm[(B, L)] = rows
                 c2p_d, p2c_d = pd["c2p"][:rows], pd["p2c"]            # uploaded with the rest of the plan (one pinned, asynchronous copy)
         self._decoder_rows = (int(c2p_d.shape[0]) if c2p_d is not None else B * L, B * L)     # (rows the decoder ran on, padded rows): introspection
         meta = F.LayerMeta(B, L, Hq, Hkv, d, cfg.intermediate_size, cfg.rms_norm_eps, cos, sin, pd["seqlens"],

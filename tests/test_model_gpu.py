@@ -1244,6 +1244,48 @@ def test_padding_free_rows_equal_the_padded_path(side):
           f"worst rel diff {worst[0]:.2e} ({worst[1]})")
 
 
+def test_padding_free_row_count_modes():
+    """The compact row count across steps of one batch shape: "auto" / True keep the high-water mark of the batches seen (constant tensor
+    sizes), "exact" follows every batch (256-row granule); either way the loss is that of the padded layout, bit for bit."""
+    cfg = OracleConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       vocab_size=32002, v_layers=1, v_intermediate=144, v_image=56, num_image_tokens=16, tokenizer_model_max_length=1024,
+                       image_start_id=32000)
+    sd = init_state_dict(cfg, seed=23, dtype=torch.bfloat16)
+
+    def batch(lens, seed):
+        g = torch.Generator().manual_seed(seed)
+        n_ids = 600                                               # every batch padded to the same 615 spliced rows
+        ids = torch.zeros((3, n_ids), dtype=torch.long)
+        labels = torch.full((3, n_ids), -100, dtype=torch.long)
+        mask = torch.zeros((3, n_ids), dtype=torch.bool)
+        for b, n in enumerate(lens):
+            row = torch.randint(3, 31999, (n,), generator=g)
+            row[0] = 1
+            row[5], row[6], row[7] = 32000, -200, 32001
+            ids[b, :n], mask[b, :n] = row, True
+            labels[b, n // 2:n] = row[n // 2:]
+        return dict(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), images=torch.randn(3, 3, 56, 56, generator=g).to(DEV).bfloat16())
+
+    batches = [batch([600, 300, 80], 1), batch([600, 100, 40], 2), batch([600, 500, 400], 3)]      # 1025 / 785 / 1545 valid rows of 1845
+    seen = {}
+    for mode in (False, True, "exact"):
+        model = hip_model(cfg, sd)
+        model.config.mm355_compact_rows = mode
+        with torch.no_grad():
+            seen[mode] = []
+            for bt in batches + batches[:1]:
+                out = model(**bt)
+                # (prompt-side images only: no image-AR rows, `loss` itself is the reference's NaN -- the language loss and the hidden rows carry the comparison)
+                seen[mode].append(((model.loss_language, out.hidden_states.clone()), model._decoder_rows[0]))
+        del model
+    assert [r for _, r in seen[False]] == [1845] * 4
+    assert [r for _, r in seen[True]] == [1280, 1280, 1792, 1792], seen[True]       # steps of max(256, ceil256(1845 / 16)) = 256 rows; never shrinks
+    assert [r for _, r in seen["exact"]] == [1280, 1024, 1792, 1280], seen["exact"]
+    for mode in (True, "exact"):
+        assert all(a[0] == b[0] and torch.equal(a[1], b[1]) for (a, _), (b, _) in zip(seen[False], seen[mode])), mode
+    assert all(a[0] == a[0] and a[0] > 0 for a, _ in seen[False])   # finite language losses
+
+
 def test_padding_free_rows_under_gradient_checkpointing_are_bit_identical():
     """Per-layer recompute (`gradient_checkpointing_enable()`, every reference launch script) re-runs a layer's forward kernels on the same
     compact rows: loss and every gradient equal the non-recomputing compact run bit for bit."""
