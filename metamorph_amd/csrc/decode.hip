@@ -1096,8 +1096,10 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
                                                                 int* __restrict__ counters, int kvdiv) {
     constexpr int SB = 4;
     constexpr int NB = G >= 8 ? 2 : (G >= 4 ? 4 : 8);                       // K / V rows per lane in flight (128 registers per thread at 16 waves per CU)
+    constexpr int NBK = G == 1 ? 16 : NB;                                       // one query head: all sixteen K rows of a lane at once,
+    constexpr int VPRE = G == 1 ? 16 : 0;                                       //   and its V rows issued before the softmax barriers (G = 2 spills with either)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    float (*sq)[128] = (float (*)[128])lds_f;                                   // [G][128] query rows (fp32, pre-scaled)
+    float (*sq)[128] = (float (*)[128])lds_f;                                   // [G][128] (rounds 4-5: query rows; unused since q goes straight into registers)
     float (*sp)[G][CH] = (float (*)[G][CH])(lds_f + G * 128);                   // [SB][G][CH] scores, then probabilities
     float (*redm)[G][4] = (float (*)[G][4])(lds_f + G * 128 + SB * G * CH);     // [SB][G][4] per-wave maxima
     float (*reds)[G][4] = (float (*)[G][4])(lds_f + G * 128 + SB * G * CH + SB * G * 4);
@@ -1106,37 +1108,67 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
     const int grp = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, sb = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
     const int kv_len = kv_lens[b];
+#if defined(MM355_AD_STOP) && MM355_AD_STOP == 0                                 // TIMING-ONLY builds (tools/build_ad_stop.sh): the kernel cut short after a phase
+    if (kv_len >= 0) return;
+#endif
     const int ngr_live = (kv_len + SB * CH - 1) / (SB * CH);                    // groups that hold keys
     const int rec = d + 2;
     float* wrec = ws + (((int64_t)b * Hq + hk * G) * ngroup + grp) * rec;
     const int k0 = (grp * SB + sb) * CH;
     const bool active = k0 < kv_len;                                            // this sub-block's chunk holds keys
+    // Round 6: where the time of this kernel goes.  At one sequence and a 512-row cache it moved 2 MB in 10.5 us, and the obvious reading -- a
+    // chain of trips to HBM: q through LDS, two batches of K rows, three barriers of softmax, two batches of V rows -- was WRONG: with every
+    // load of a thread issued up front (q straight into registers, sixteen K rows, the V rows before the softmax barriers) it took 11-14 us.
+    // The workgroup is bound by INSTRUCTION ISSUE: sixteen waves on one CU = four per SIMD, each running the whole stream, and
+    //   * the sub-blocks whose 256-key chunk lies beyond the cache ran it too, every lane masked off (half the waves at 512 rows): they now
+    //     skip the score, softmax and PV phases (wave-uniform branches; only the barriers are shared) -- their partials were never read;
+    //   * a load under a LANE predicate is a branch, and hipcc sank the whole address computation, an integer division by kvdiv included,
+    //     into each of the 32 branches (~50 instructions per load): rows are now loaded unconditionally from clamped addresses (a row beyond
+    //     the cache reads the last cached row, a chunk of d beyond the head reads chunk 0 -- finite values that meet a score of -inf, a
+    //     probability of 0 or a store nobody makes) from two base pointers computed once;
+    //   * q goes straight into the lanes' registers (no LDS copy, one barrier less).
+    // Same products and the same order of additions per output as before: bit-identical results.
+    const int dc8_t = ((t & 15) * 8 < d) ? (t & 15) * 8 : 0;                   // (lane & 15 == t & 15: both phases address the same chunk)
+    const uint16_t* const kbase = kc + (int64_t)b * bs_kv + (int64_t)(hk / kvdiv) * d + dc8_t;
+    const uint16_t* const vbase = vc + (int64_t)b * bs_kv + (int64_t)(hk / kvdiv) * d + dc8_t;
+    (void)sq;
     if (grp * SB * CH < kv_len) {
-        for (int i = tid; i < G * d; i += 1024) {
-            const int g = i / d, c = i % d;
-            sq[g][c] = bf2f(q[(int64_t)b * ld_q + (int64_t)(hk * G + g) * d + c]) * scale;
-        }
-        __syncthreads();
-        // ---- scores (two batches of eight K rows per lane: 128 registers per thread at 16 waves per CU)
-        {
+        // ---- scores (batches of NB K rows per lane: 128 registers per thread at 16 waves per CU)
+        if (active) {
             const int dc = lane & 15, kq = lane >> 4;
             float qreg[G][8];
+            {
+                // one 16-B load where q allows it, else eight 2-byte ones (q carries no alignment contract)
+                const bool qvec = ((((uintptr_t)q) | ((uintptr_t)ld_q * 2u)) & 15u) == 0;
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+                for (int g = 0; g < G; ++g) {
+                    const uint16_t* qp = q + (int64_t)b * ld_q + (int64_t)(hk * G + g) * d + dc8_t;
+                    u32x4 qh;
+                    if (qvec) {
+                        qh = *(const u32x4*)qp;
+                    } else {
+                        uint32_t w[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qreg[g][e] = (dc * 8 < d) ? sq[g][dc * 8 + e] : 0.f;
+                        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)qp[2 * e] | ((uint32_t)qp[2 * e + 1] << 16);
+                        qh = u32x4{w[0], w[1], w[2], w[3]};
+                    }
+                    float qf[8];
+                    unpack8(qh, qf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qreg[g][e] = (dc * 8 < d) ? qf[e] * scale : 0.f;
+                }
+            }
 #pragma unroll 1
-            for (int h = 0; h < 16 / NB; ++h) {
-                u32x4 kraw[NB];
+            for (int h = 0; h < 16 / NBK; ++h) {
+                u32x4 kraw[NBK];
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int kk = k0 + wave * 64 + (h * NB + i) * 4 + kq;
-                    kraw[i] = (kk < kv_len && dc * 8 < d) ? *(const u32x4*)(kc + (int64_t)b * bs_kv + (int64_t)kk * ld_kv + (int64_t)(hk / kvdiv) * d + dc * 8)
-                                                          : u32x4{0u, 0u, 0u, 0u};
+                for (int i = 0; i < NBK; ++i) {
+                    const int kk = k0 + wave * 64 + (h * NBK + i) * 4 + kq;
+                    kraw[i] = *(const u32x4*)(kbase + (int64_t)min(kk, kv_len - 1) * ld_kv);
                 }
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int kl = wave * 64 + (h * NB + i) * 4 + kq;
+                for (int i = 0; i < NBK; ++i) {
+                    const int kl = wave * 64 + (h * NBK + i) * 4 + kq;
                     const int kk = k0 + kl;
                     float kf[8];
                     unpack8(kraw[i], kf);
@@ -1154,28 +1186,44 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
                 }
             }
         }
+        u32x4 vpre[VPRE ? VPRE : 1];
+        if constexpr (VPRE > 0) {                            // the first V rows of the PV phase (its thread mapping), in flight across the softmax barriers
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < VPRE; ++i) vpre[i] = *(const u32x4*)(vbase + (int64_t)min(k0 + (t >> 4) + i * 16, kv_len - 1) * ld_kv);
+            }
+        }
         __syncthreads();
+#if defined(MM355_AD_STOP) && MM355_AD_STOP == 1
+        if (kv_len >= 0) return;
+#endif
         const int key = k0 + t;
         float sc[G];
+        if (active) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            sc[g] = sp[sb][g][t];
-            const float w = wave_max(sc[g]);
-            if (lane == 0) redm[sb][g][wave] = w;
+            for (int g = 0; g < G; ++g) {
+                sc[g] = sp[sb][g][t];
+                const float w = wave_max(sc[g]);
+                if (lane == 0) redm[sb][g][wave] = w;
+            }
         }
         __syncthreads();
-        float mx[G];
+        if (active) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            mx[g] = fmaxf(fmaxf(redm[sb][g][0], redm[sb][g][1]), fmaxf(redm[sb][g][2], redm[sb][g][3]));
-            const float p = (key < kv_len) ? __expf(sc[g] - mx[g]) : 0.f;
-            sp[sb][g][t] = p;                                 // (own slot: read above by this thread only)
-            const float w = wave_sum(p);
-            if (lane == 0) reds[sb][g][wave] = w;
+            for (int g = 0; g < G; ++g) {
+                const float mxg = fmaxf(fmaxf(redm[sb][g][0], redm[sb][g][1]), fmaxf(redm[sb][g][2], redm[sb][g][3]));
+                const float p = (key < kv_len) ? __expf(sc[g] - mxg) : 0.f;
+                sp[sb][g][t] = p;                             // (own slot: read above by this thread only)
+                const float w = wave_sum(p);
+                if (lane == 0) reds[sb][g][wave] = w;
+            }
         }
         __syncthreads();
-        // ---- o = sum_key p[key] V[key]: thread = (16-B chunk of d, key group of 16), two batches of eight V rows
-        {
+#if defined(MM355_AD_STOP) && MM355_AD_STOP == 2
+        if (kv_len >= 0) return;
+#endif
+        // ---- o = sum_key p[key] V[key]: thread = (16-B chunk of d, key group of 16), batches of NB V rows
+        if (active) {
             const int dc = t & 15, kg = t >> 4;
             float acc[G][8];
 #pragma unroll
@@ -1183,27 +1231,28 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
             const int kend = min(CH, kv_len - k0);
+            auto pv = [&](const u32x4& vr, int kk) {
+                float vf[8];
+                unpack8(vr, vf);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float p = (kk < kend) ? sp[sb][g][kk] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
+                }
+            };
+            if constexpr (VPRE > 0) {
+#pragma unroll
+                for (int i = 0; i < VPRE; ++i) pv(vpre[i], kg + i * 16);
+            }
+            constexpr int NBV = (16 - VPRE) < NB ? (16 - VPRE ? 16 - VPRE : 1) : NB;
 #pragma unroll 1
-            for (int h = 0; h < 16 / NB; ++h) {
-                u32x4 vraw[NB];
+            for (int r0 = VPRE; r0 < 16; r0 += NBV) {
+                u32x4 vraw[NBV];
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int kk = kg + (h * NB + i) * 16;
-                    vraw[i] = (kk < kend && dc * 8 < d) ? *(const u32x4*)(vc + (int64_t)b * bs_kv + (int64_t)(k0 + kk) * ld_kv + (int64_t)(hk / kvdiv) * d + dc * 8)
-                                                        : u32x4{0u, 0u, 0u, 0u};
-                }
+                for (int i = 0; i < NBV; ++i) vraw[i] = *(const u32x4*)(vbase + (int64_t)min(k0 + kg + (r0 + i) * 16, kv_len - 1) * ld_kv);
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int kk = kg + (h * NB + i) * 16;
-                    float vf[8];
-                    unpack8(vraw[i], vf);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const float p = (kk < kend) ? sp[sb][g][kk] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
-                    }
-                }
+                for (int i = 0; i < NBV; ++i) pv(vraw[i], kg + (r0 + i) * 16);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -1216,6 +1265,9 @@ __global__ __launch_bounds__(1024) void attn_decode_wide_kernel(const uint16_t* 
                 }
         }
         __syncthreads();
+#if defined(MM355_AD_STOP) && MM355_AD_STOP == 3
+        if (kv_len >= 0) return;
+#endif
         // ---- the four chunks of this group -> one (m, l, o[d]) per query head, in a fixed order
         for (int i = tid; i < G * d; i += 1024) {
             const int g = i / d, c = i % d;
