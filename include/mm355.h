@@ -77,6 +77,27 @@ int64_t mm355_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t K);
 int mm355_gemm_splitk_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr, float* workspace,
                            int64_t workspace_floats, void* stream);
+/* The split projection with the launch that FOLLOWS it on the decode / prompt path folded into the reduce launch (a launch costs 3 - 5 us whatever
+ * it does; the decode step of more than 16 sequences had thirteen per layer, nine with these).  Each form rounds the slice sums to bf16 where
+ * mm355_gemm_splitk_bf16 stores them and continues with the arithmetic of the kernel it replaces: the bits of the launch sequence.  A shape that
+ * is not split runs that sequence inside the library.  Reference: HF LlamaDecoderLayer at decode shape, metamorph_llama.py:665-717.
+ *   _norm:        C[M][N] = bf16(A . B^T + residual) (rows N apart), Y[M][N] = RMSNorm(C; norm_w, eps)   == gemm_splitk -> rmsnorm_fwd
+ *                 (o projection -> post-attention norm; down projection -> the next layer's input norm).  workspace: mm355_gemm_splitk_ws_floats.
+ *   _swiglu:      act[M][I] = SiLU(g) * u, [g | u] = X . Wgu[2 I][K]^T                                    == gemm_splitk -> swiglu_fwd
+ *                 workspace: mm355_gemm_splitk_swiglu_ws_floats(M, I, K) floats (never 0: the unsplit sequence parks its bf16 g | u rows there).
+ *   _rope_append: one new q|k|v row per sequence: q rotated at positions[m] (device) -> qkv[m][0 .. Hq d), rotated k and v -> cache row
+ *                 positions[m]; the k | v columns of qkv are not written                                   == gemm_splitk -> rope_kv_append
+ *                 workspace: mm355_gemm_splitk_ws_floats(M, (Hq + 2 Hkv) d, K).  M <= 65535, d % 16 == 0. */
+int mm355_gemm_splitk_norm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t M, int64_t N,
+                                int64_t K, const mm355_bf16* residual, int64_t ldr, const mm355_bf16* norm_w, float eps, mm355_bf16* Y,
+                                float* workspace, int64_t workspace_floats, void* stream);
+int64_t mm355_gemm_splitk_swiglu_ws_floats(int64_t M, int64_t I, int64_t K);
+int mm355_gemm_splitk_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* act, int64_t ld_act,
+                                  int64_t M, int64_t I, int64_t K, float* workspace, int64_t workspace_floats, void* stream);
+int mm355_gemm_splitk_rope_append_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                                       int64_t M, int64_t Hq, int64_t Hkv, int64_t d, int64_t K, const mm355_bf16* cos_t,
+                                       const mm355_bf16* sin_t, const int32_t* positions, mm355_bf16* k_cache, mm355_bf16* v_cache,
+                                       int64_t ld_kv, int64_t batch_stride_kv, float* workspace, int64_t workspace_floats, void* stream);
 
 /* Fused gate|up projection + SwiGLU of the LLaMA MLP (reference: HF LlamaMLP `down_proj(act_fn(gate_proj(x)) * up_proj(x))`, reached at
  * metamorph_llama.py:349-359):  gu[M][2 I] = X[M][K] . Wgu[2 I][K]^T  (gate columns 0..I-1, up columns I..2I-1, exactly what

@@ -1431,6 +1431,129 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---- the reduce launch carrying what FOLLOWS a split projection on the decode / prompt path (round 6: a launch costs 3 - 5 us whatever it
+// does -- profiles/r6_attn_decode_phases.log -- and a layer of the wide decode step had thirteen of them).  Each form rounds the slice sums
+// to bf16 exactly where splitk_reduce_kernel stores them and continues with the arithmetic of the kernel it replaces: the same bits as the
+// launch sequence.
+MM_DEV void splitk_sum8(const float* __restrict__ p, int S, int64_t plane, float (&v)[8]) {
+    const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    for (int s = 1; s < S; ++s) {
+        const f32x4 b0 = *(const f32x4*)(p + s * plane), b1 = *(const f32x4*)(p + s * plane + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+}
+// out = bf16(sums + residual) and y = RMSNorm(out; w, eps): one workgroup per row, the row in registers (rmsnorm_fwd_kernel's layout,
+// reduction order and roundings)
+template <int VPT>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ part, int S, int M, int N, const uint16_t* __restrict__ res,
+                                                                 int64_t ldr, uint16_t* __restrict__ out, int64_t ldc, const uint16_t* __restrict__ w,
+                                                                 uint16_t* __restrict__ y, int64_t ldy, float eps) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const int nv = N >> 3;
+    const int64_t plane = (int64_t)M * N;
+    float xv[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * 256;
+        if (v < nv) {
+            float t[8];
+            splitk_sum8(part + row * N + v * 8, S, plane, t);
+            if (res) {
+                float r[8];
+                unpack8(*(const u32x4*)(res + row * ldr + v * 8), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += r[e];
+            }
+            const u32x4 o = pack8(t);
+            *(u32x4*)(out + row * ldc + v * 8) = o;
+            unpack8(o, xv[i]);                               // the norm reads the ROUNDED row, as the separate launch does
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+        }
+    }
+    ss = block_sum<256>(ss, red);
+    const float rstd = rsqrtf(ss / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = threadIdx.x + i * 256;
+        if (v < nv) {
+            float wv[8], o[8];
+            unpack8(*(const u32x4*)(w + v * 8), wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * round_bf(xv[i][e] * rstd);
+            *(u32x4*)(y + row * ldy + v * 8) = pack8(o);
+        }
+    }
+}
+// act[m][c] = SiLU(g) * u of the bf16-rounded sums g = column c, u = column I + c (swiglu_fwd_kernel's arithmetic)
+__global__ __launch_bounds__(256) void splitk_reduce_swiglu_kernel(const float* __restrict__ part, int S, int M, int I, uint16_t* __restrict__ act,
+                                                                   int64_t ld_act) {
+    const int iv = I >> 3, N = 2 * I;
+    const int64_t total = (int64_t)M * iv, plane = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / iv;
+        const int c = (int)(i % iv) * 8;
+        float g[8], u[8], o[8];
+        splitk_sum8(part + m * N + c, S, plane, g);
+        splitk_sum8(part + m * N + I + c, S, plane, u);
+        unpack8(pack8(g), g);
+        unpack8(pack8(u), u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = round_bf(g[e] / (1.0f + __expf(-g[e]))) * u[e];
+        *(u32x4*)(act + m * ld_act + c) = pack8(o);
+    }
+}
+// q|k|v sums of one new row per sequence: q rotated at positions[m] -> qkv[m][0 .. Hq d), rotated k and v -> cache row positions[m]
+// (rope_kv_append_kernel's arithmetic on the bf16-rounded sums; the k | v columns of qkv are not written)
+__global__ __launch_bounds__(256) void splitk_reduce_rope_append_kernel(const float* __restrict__ part, int S, int M, int Hq, int Hkv, int d,
+                                                                        uint16_t* __restrict__ qkv, int64_t ld, const uint16_t* __restrict__ cos_t,
+                                                                        const uint16_t* __restrict__ sin_t, const int32_t* __restrict__ positions,
+                                                                        uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int64_t ld_kv,
+                                                                        int64_t bs_kv) {
+    const int b = blockIdx.y;
+    const int pos = positions[b];
+    const int half = d >> 1, vph = half >> 3;
+    const int H = Hq + Hkv, N = (Hq + 2 * Hkv) * d;
+    const int64_t plane = (int64_t)M * N;
+    const float* prow = part + (int64_t)b * N;
+    uint16_t* krow = kc + (int64_t)b * bs_kv + (int64_t)pos * ld_kv;
+    uint16_t* vrow = vc + (int64_t)b * bs_kv + (int64_t)pos * ld_kv;
+    const int rot = H * vph, cpy = Hkv * d / 8;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rot + cpy; i += gridDim.x * 256) {
+        if (i < rot) {
+            const int v = i % vph, hd = i / vph;
+            float x1[8], x2[8], c[8], sn[8], y1[8], y2[8];
+            splitk_sum8(prow + (int64_t)hd * d + v * 8, S, plane, x1);
+            splitk_sum8(prow + (int64_t)hd * d + half + v * 8, S, plane, x2);
+            unpack8(pack8(x1), x1);
+            unpack8(pack8(x2), x2);
+            unpack8(*(const u32x4*)(cos_t + (int64_t)pos * d + v * 8), c);
+            unpack8(*(const u32x4*)(sin_t + (int64_t)pos * d + v * 8), sn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                y1[e] = round_bf(x1[e] * c[e]) + round_bf(-x2[e] * sn[e]);
+                y2[e] = round_bf(x2[e] * c[e]) + round_bf(x1[e] * sn[e]);
+            }
+            const u32x4 o1 = pack8(y1), o2 = pack8(y2);
+            if (hd < Hq) {
+                uint16_t* p1 = qkv + (int64_t)b * ld + (int64_t)hd * d + v * 8;
+                *(u32x4*)p1 = o1; *(u32x4*)(p1 + half) = o2;
+            } else {
+                uint16_t* kd = krow + (int64_t)(hd - Hq) * d + v * 8;
+                *(u32x4*)kd = o1; *(u32x4*)(kd + half) = o2;
+            }
+        } else {
+            const int j = i - rot;
+            float t[8];
+            splitk_sum8(prow + (int64_t)H * d + j * 8, S, plane, t);
+            *(u32x4*)(vrow + j * 8) = pack8(t);
+        }
+    }
+}
+
 // slices for a prompt-pass problem: enough workgroups (64 x 128 tiles x slices) to put ~3 on every CU, at least 8 K tiles per slice
 int splitk_slices(int64_t M, int64_t N, int64_t K) {
     if (K % 64 || N % 8 || M > 4096) return 1;
@@ -1447,6 +1570,41 @@ extern "C" int64_t mm355_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t K) 
     return S > 1 ? (int64_t)S * M * N : 0;
 }
 
+// the K slices of A . B^T as fp32 partials workspace[slice][M][N]; `slices` = how many were written (the caller reduces them)
+static int splitk_partials(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int S, float* workspace,
+                           int64_t workspace_floats, hipStream_t stream, int& slices) {
+    if ((lda & 7) || (ldb & 7) || !mm_aligned16(A) || !mm_aligned16(B) || !workspace || !mm_aligned16(workspace) ||
+        workspace_floats < (int64_t)S * M * N)
+        return MM355_EINVAL;
+    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.C = workspace; a.lda = lda; a.ldb = ldb; a.ldc = N;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = MM355_GEMM_OUT_F32;
+    const int64_t nk = K / 64;
+    a.kslice = (int)((nk + S - 1) / S) * 64;
+    // tiles of 64 x 128 (four waves); up to 32 rows: 32 x 128 -- half the A-tile LDS and MFMAs on padding rows (the decode step of 17 - 32
+    // sequences: 5.33 -> 5.10 ms; more slices, narrower or 2-wave tiles bought nothing or lost: profiles/r6_splitk_tile_sweep.log).  Every
+    // output element sums its K slice in the same order under either tile: the same bits.
+    constexpr int BN = 128;
+    constexpr int LDS = 2 * (64 + BN) * 128;
+    a.ntn = (int)((N + BN - 1) / BN);
+    slices = (int)((K + a.kslice - 1) / a.kslice);
+    if (M <= 32) {
+        auto kern = gemm_nt_kernel<32, BN, 1, 4, true, 0, false>;
+        static std::atomic<uint64_t> lds_ok{0};
+        if (mm_ensure_dynamic_lds((const void*)kern, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+        a.ntm = 1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn), (unsigned)slices), dim3(256), 2 * (32 + BN) * 128, stream, a);
+    } else {
+        auto kern = gemm_nt_kernel<64, BN, 1, 4, true, 0, false>;
+        static std::atomic<uint64_t> lds_ok{0};
+        if (mm_ensure_dynamic_lds((const void*)kern, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
+        a.ntm = (int)((M + 63) / 64);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn), (unsigned)slices), dim3(256), LDS, stream, a);
+    }
+    return mm_launch_status();
+}
+
 extern "C" int mm355_gemm_splitk_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t ldc,
                                       int64_t M, int64_t N, int64_t K, const mm355_bf16* residual, int64_t ldr, float* workspace,
                                       int64_t workspace_floats, void* stream) {
@@ -1458,24 +1616,90 @@ extern "C" int mm355_gemm_splitk_bf16(const mm355_bf16* A, int64_t lda, const mm
     if ((lda & 7) || (ldb & 7) || (ldc & 7) || (residual && (ldr & 7)) || !mm_aligned16(A) || !mm_aligned16(B) || !mm_aligned16(C) ||
         (residual && !mm_aligned16(residual)) || !workspace || !mm_aligned16(workspace) || workspace_floats < (int64_t)S * M * N)
         return MM355_EINVAL;
-    if (M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return MM355_EINVAL;
-    GemmArgs a = {};
-    a.A = A; a.B = B; a.C = workspace; a.lda = lda; a.ldb = ldb; a.ldc = N;
-    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = MM355_GEMM_OUT_F32;
-    const int64_t nk = K / 64;
-    a.kslice = (int)((nk + S - 1) / S) * 64;
-    constexpr int BM = 64, BN = 128;
-    auto kern = gemm_nt_kernel<BM, BN, 1, 4, true, 0, false>;
-    constexpr int LDS = 2 * (BM + BN) * 128;
-    static std::atomic<uint64_t> lds_ok{0};
-    if (mm_ensure_dynamic_lds((const void*)kern, LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
-    a.ntm = (int)((M + BM - 1) / BM);
-    a.ntn = (int)((N + BN - 1) / BN);
-    const int slices = (int)((K + a.kslice - 1) / a.kslice);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn), (unsigned)slices), dim3(256), LDS, (hipStream_t)stream, a);
+    int slices = 0;
+    const int rc = splitk_partials(A, lda, B, ldb, M, N, K, S, workspace, workspace_floats, (hipStream_t)stream, slices);
+    if (rc != MM355_OK) return rc;
     const int64_t vecs = M * (N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((vecs + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, slices, (int)M, (int)N, (const uint16_t*)residual, ldr, (uint16_t*)C, ldc);
+    return mm_launch_status();
+}
+
+// ---- split projection + the launch that follows it (see the fused reduce kernels above).  A shape that would not be split runs the plain
+// launch sequence inside the library: same results either way.
+extern "C" int mm355_gemm_splitk_norm_bf16(const mm355_bf16* A, int64_t lda, const mm355_bf16* B, int64_t ldb, mm355_bf16* C, int64_t M, int64_t N,
+                                           int64_t K, const mm355_bf16* residual, int64_t ldr, const mm355_bf16* norm_w, float eps, mm355_bf16* Y,
+                                           float* workspace, int64_t workspace_floats, void* stream) {
+    (void)hipGetLastError();
+    if (!A || !B || !C || !Y || !norm_w || M <= 0 || N <= 0 || K <= 0 || (N & 7)) return MM355_EINVAL;
+    if (!mm_aligned16(C) || !mm_aligned16(Y) || !mm_aligned16(norm_w) || (residual && ((ldr & 7) || !mm_aligned16(residual)))) return MM355_EINVAL;
+    const int S = splitk_slices(M, N, K);
+    if (S <= 1) {
+        const int rc = mm355_gemm_bf16(A, lda, B, ldb, C, N, M, N, K, nullptr, residual, ldr, 0, residual ? MM355_GEMM_RESIDUAL : 0u, 0, stream);
+        return rc != MM355_OK ? rc : mm355_rmsnorm_fwd(C, norm_w, Y, M, N, eps, stream);
+    }
+    const int nv = (int)(N >> 3);
+    if (nv > 8 * 256) return MM355_EUNSUPPORTED;            // (the row lives in registers: mm355_rmsnorm_fwd's own limit)
+    int slices = 0;
+    const int rc = splitk_partials(A, lda, B, ldb, M, N, K, S, workspace, workspace_floats, (hipStream_t)stream, slices);
+    if (rc != MM355_OK) return rc;
+#define RN(VPT) hipLaunchKernelGGL((splitk_reduce_norm_kernel<VPT>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, slices, \
+                                   (int)M, (int)N, (const uint16_t*)residual, ldr, (uint16_t*)C, N, (const uint16_t*)norm_w, (uint16_t*)Y, N, eps)
+    if (nv <= 256) RN(1); else if (nv <= 512) RN(2); else if (nv <= 1024) RN(4); else RN(8);
+#undef RN
+    return mm_launch_status();
+}
+
+extern "C" int64_t mm355_gemm_splitk_swiglu_ws_floats(int64_t M, int64_t I, int64_t K) {
+    if (M <= 0 || I <= 0 || K <= 0) return 0;
+    const int S = splitk_slices(M, 2 * I, K);
+    return S > 1 ? (int64_t)S * M * 2 * I : M * I;          // not split: the bf16 [M][2 I] gate | up rows of the plain sequence
+}
+extern "C" int mm355_gemm_splitk_swiglu_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wgu, int64_t ldw, mm355_bf16* act, int64_t ld_act,
+                                             int64_t M, int64_t I, int64_t K, float* workspace, int64_t workspace_floats, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wgu || !act || !workspace || M <= 0 || I <= 0 || K <= 0 || (I & 7) || (ld_act & 7) || !mm_aligned16(act) || !mm_aligned16(workspace))
+        return MM355_EINVAL;
+    if (workspace_floats < mm355_gemm_splitk_swiglu_ws_floats(M, I, K)) return MM355_EINVAL;
+    const int64_t N = 2 * I;
+    const int S = splitk_slices(M, N, K);
+    if (S <= 1) {
+        if (ld_act != I) return MM355_EUNSUPPORTED;
+        mm355_bf16* gu = (mm355_bf16*)workspace;
+        const int rc = mm355_gemm_bf16(X, ldx, Wgu, ldw, gu, N, M, N, K, nullptr, nullptr, 0, 0, 0u, 0, stream);
+        return rc != MM355_OK ? rc : mm355_swiglu_fwd(gu, act, M, I, stream);
+    }
+    int slices = 0;
+    const int rc = splitk_partials(X, ldx, Wgu, ldw, M, N, K, S, workspace, workspace_floats, (hipStream_t)stream, slices);
+    if (rc != MM355_OK) return rc;
+    const int64_t vecs = M * (I / 8);
+    hipLaunchKernelGGL(splitk_reduce_swiglu_kernel, dim3((unsigned)std::min<int64_t>((vecs + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, slices, (int)M, (int)I, (uint16_t*)act, ld_act);
+    return mm_launch_status();
+}
+
+extern "C" int mm355_gemm_splitk_rope_append_bf16(const mm355_bf16* X, int64_t ldx, const mm355_bf16* Wqkv, int64_t ldw, mm355_bf16* qkv, int64_t ld_qkv,
+                                                  int64_t M, int64_t Hq, int64_t Hkv, int64_t d, int64_t K, const mm355_bf16* cos_t,
+                                                  const mm355_bf16* sin_t, const int32_t* positions, mm355_bf16* k_cache, mm355_bf16* v_cache,
+                                                  int64_t ld_kv, int64_t batch_stride_kv, float* workspace, int64_t workspace_floats, void* stream) {
+    (void)hipGetLastError();
+    if (!X || !Wqkv || !qkv || !cos_t || !sin_t || !positions || !k_cache || !v_cache || M <= 0 || Hq <= 0 || Hkv <= 0 || d <= 0 || K <= 0 ||
+        (d & 15) || (ld_qkv & 7) || (ld_kv & 7) || (batch_stride_kv & 7) || M > 65535 || !mm_aligned16(qkv) || !mm_aligned16(k_cache) ||
+        !mm_aligned16(v_cache) || !mm_aligned16(cos_t) || !mm_aligned16(sin_t))
+        return MM355_EINVAL;
+    const int64_t N = (Hq + 2 * Hkv) * d;
+    const int S = splitk_slices(M, N, K);
+    if (S <= 1) {
+        const int rc = mm355_gemm_bf16(X, ldx, Wqkv, ldw, qkv, ld_qkv, M, N, K, nullptr, nullptr, 0, 0, 0u, 0, stream);
+        return rc != MM355_OK ? rc : mm355_rope_kv_append(qkv, ld_qkv, M, Hq, Hkv, d, cos_t, sin_t, positions, k_cache, v_cache, ld_kv, batch_stride_kv, stream);
+    }
+    int slices = 0;
+    const int rc = splitk_partials(X, ldx, Wqkv, ldw, M, N, K, S, workspace, workspace_floats, (hipStream_t)stream, slices);
+    if (rc != MM355_OK) return rc;
+    const int64_t work = (Hq + Hkv) * (d / 16) + Hkv * d / 8;
+    hipLaunchKernelGGL(splitk_reduce_rope_append_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, slices, (int)M, (int)Hq, (int)Hkv, (int)d, (uint16_t*)qkv, ld_qkv, (const uint16_t*)cos_t,
+                       (const uint16_t*)sin_t, positions, (uint16_t*)k_cache, (uint16_t*)v_cache, ld_kv, batch_stride_kv);
     return mm_launch_status();
 }
 

@@ -40,7 +40,10 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             # latency chain over K there)
             "prefill_splitk": True,
             # decode step of MORE than 16 sequences: one pass over the weights through the split-K GEMM instead of one GEMV pass per 16 rows
-            "decode_wide_gemm": True}
+            "decode_wide_gemm": True,
+            # ... with RoPE + cache append, the two RMSNorms and SwiGLU folded into the reduce launches of the split projections (nine launches per
+            # layer instead of thirteen; same bits)
+            "decode_wide_fused": True}
 
 
 def set_variant(name, value):
@@ -873,8 +876,29 @@ def _decode_rows_gemm(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_
     """17 new rows and more (one per sequence) through every decoder layer in ONE pass over the weights (round 6; rounds 5: chunks of 16 rows,
     i.e. the 15 GB read once per chunk).  The GEMV kernels hold one 16-row MFMA operand; beyond it the projections take the split-K GEMM of
     the prompt pass (mm355_gemm_splitk_bf16: 64 x 128 tiles x K slices -- at 32 rows a weight-streaming problem with ~3 workgroups per CU),
-    RoPE + cache append, attention per row at its own length, SwiGLU as their own launches: nine launches per layer for any number of rows."""
+    attention per row at its own length; RoPE + cache append, the two RMSNorms and SwiGLU ride in the reduce launches of the split projections
+    (VARIANTS["decode_wide_fused"]; as launches of their own -- thirteen per layer instead of nine -- when off: same bits)."""
     nq = meta.Hq * meta.d
+    if VARIANTS["decode_wide_fused"] and meta.d % 16 == 0:
+        # what follows a split projection rides in its reduce launch (mm355_gemm_splitk_{rope_append,norm,swiglu}_bf16): 9 launches per layer
+        n1 = None
+        for i, layer in enumerate(layers):
+            params_ready(layer)
+            att, mlp = layer.self_attn, layer.mlp
+            wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
+            wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
+            if n1 is None:
+                n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
+            qkv = ops.gemm_splitk_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i])
+            o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, kv_bound, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
+            x2, n2 = ops.gemm_splitk_norm(o, att.o_proj.weight, layer.post_attention_layernorm.weight, meta.eps, residual=x)
+            act = ops.gemm_splitk_swiglu(n2, wgu, meta.I)
+            if i + 1 < len(layers):
+                params_ready(layers[i + 1])                   # (its input norm weight is read by this layer's last launch)
+                x, n1 = ops.gemm_splitk_norm(act, mlp.down_proj.weight, layers[i + 1].input_layernorm.weight, meta.eps, residual=x2)
+            else:
+                x = ops.gemm_splitk(act, mlp.down_proj.weight, residual=x2)
+        return x
     for i, layer in enumerate(layers):
         params_ready(layer)
         att, mlp = layer.self_attn, layer.mlp

@@ -109,6 +109,63 @@ def gemm_splitk(a, b, residual=None, out=None):
     return out
 
 
+def _splitk_ws(n_floats, device):
+    return torch.empty((max(int(n_floats), 4),), device=device, dtype=torch.float32)
+
+
+def gemm_splitk_norm(a, b, norm_w, eps, residual=None):
+    """(c, y): c[M, N] = a . b^T (+ residual) through the split-K GEMM, y = RMSNorm(c; norm_w, eps) formed by the reduce launch
+    (mm355_gemm_splitk_norm_bf16: the bits of gemm_splitk -> rmsnorm_fwd, one launch less)."""
+    _chk_dev(a, b, norm_w, residual)
+    pa, M, K, lda = _rows2d(a)
+    pb, N, Kb, ldb = _rows2d(b)
+    assert K == Kb and a.dtype == BF16 and b.dtype == BF16 and norm_w.numel() == N
+    c = torch.empty((M, N), device=a.device, dtype=BF16)
+    y = torch.empty((M, N), device=a.device, dtype=BF16)
+    pr, ldr = 0, 0
+    if residual is not None:
+        pr, Mr, Nr, ldr = _rows2d(residual)
+        assert (Mr, Nr) == (M, N)
+    n_ws = int(_L().mm355_gemm_splitk_ws_floats(M, N, K))
+    ws = _splitk_ws(n_ws, a.device)
+    _lib.check(_L().mm355_gemm_splitk_norm_bf16(pa, lda, pb, ldb, c.data_ptr(), M, N, K, pr, ldr, norm_w.data_ptr(), float(eps), y.data_ptr(),
+                                                ws.data_ptr(), n_ws, _stream()), f"mm355_gemm_splitk_norm_bf16 M={M} N={N} K={K}")
+    return c, y
+
+
+def gemm_splitk_swiglu(x, wgu, I):
+    """act[M, I] = SiLU(g) * u, [g | u] = x . wgu^T through the split-K GEMM, SwiGLU in the reduce launch (mm355_gemm_splitk_swiglu_bf16: the
+    bits of gemm_splitk -> swiglu_fwd)."""
+    _chk_dev(x, wgu)
+    px, M, K, ldx = _rows2d(x)
+    pw, N, Kw, ldw = _rows2d(wgu)
+    assert K == Kw and N == 2 * I and x.dtype == BF16 and wgu.dtype == BF16
+    act = torch.empty((M, I), device=x.device, dtype=BF16)
+    n_ws = int(_L().mm355_gemm_splitk_swiglu_ws_floats(M, I, K))
+    ws = _splitk_ws(n_ws, x.device)
+    _lib.check(_L().mm355_gemm_splitk_swiglu_bf16(px, ldx, pw, ldw, act.data_ptr(), act.stride(0), M, I, K, ws.data_ptr(), n_ws, _stream()),
+               f"mm355_gemm_splitk_swiglu_bf16 M={M} I={I} K={K}")
+    return act
+
+
+def gemm_splitk_rope_append(x, wqkv, Hq, Hkv, d, cos, sin, positions, k_cache, v_cache):
+    """One new q|k|v row per sequence through the split-K GEMM; RoPE at positions[m] (int32, device) and the KV-cache append in the reduce
+    launch (mm355_gemm_splitk_rope_append_bf16: the bits of gemm_splitk -> rope_kv_append_).  Returns the row buffer [M, (Hq+2Hkv)*d] whose
+    q columns are valid."""
+    _chk_dev(x, wqkv, cos, sin, positions, k_cache, v_cache)
+    px, M, K, ldx = _rows2d(x)
+    pw, N, Kw, ldw = _rows2d(wqkv)
+    assert K == Kw and N == (Hq + 2 * Hkv) * d and positions.dtype == torch.int32
+    assert k_cache.stride() == v_cache.stride() and k_cache.stride(2) == 1
+    out = torch.empty((M, N), device=x.device, dtype=BF16)
+    n_ws = int(_L().mm355_gemm_splitk_ws_floats(M, N, K))
+    ws = _splitk_ws(n_ws, x.device)
+    _lib.check(_L().mm355_gemm_splitk_rope_append_bf16(px, ldx, pw, ldw, out.data_ptr(), out.stride(0), M, Hq, Hkv, d, K, cos.data_ptr(), sin.data_ptr(),
+                                                       positions.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1),
+                                                       k_cache.stride(0), ws.data_ptr(), n_ws, _stream()), "mm355_gemm_splitk_rope_append_bf16")
+    return out
+
+
 def gemm_pair_supported(a0, b0, a1, b1):
     """Both problems fit mm355_gemm_pair_bf16 (plain NT operands, whole pairs of K tiles, 31-bit operand offsets)."""
     return (a0.shape[1] == b0.shape[1] and a1.shape[1] == b1.shape[1]

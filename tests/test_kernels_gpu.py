@@ -889,6 +889,16 @@ def test_gemm_splitk_against_the_plain_kernel_and_fp64(ops, shape):
             assert torch.equal(got, plain)
 
 
+@pytest.mark.parametrize("M", [17, 32])
+def test_gemm_splitk_32_row_tiles_give_the_bits_of_64_row_tiles(ops, M):
+    """Up to 32 rows the split-K launch takes 32 x 128 tiles instead of 64 x 128 (the decode step of 17 - 32 sequences): every output element
+    sums its K slice in the same order under either tile -- the rows of an M-row call equal the same rows inside a 64-row call (64-row tiles,
+    same number of slices) bit for bit, on all four LLaMA-3-8B projections."""
+    for (N, K) in ((6144, 4096), (4096, 4096), (4096, 14336), (28672, 4096)):
+        a, b = rnd(64, K, seed=M + N).to(DEV), rnd(N, K, seed=K, scale=0.03).to(DEV)
+        assert torch.equal(ops.gemm_splitk(a[:M], b), ops.gemm_splitk(a, b)[:M]), (M, N, K)
+
+
 def test_cosine_loss(ops):
     Rr, C = 21, 1152
     p, t = rnd(Rr, C, seed=1), R.l2_normalize(rnd(Rr, C, seed=2).float()).bfloat16()
@@ -1016,6 +1026,39 @@ def test_gemv_rejects_many_rows(ops):
     from metamorph_amd.lib import Mm355Error
     with pytest.raises(Mm355Error):
         ops.gemv(rnd(17, 64, seed=1).to(DEV), rnd(16, 64, seed=2).to(DEV))
+
+
+@pytest.mark.parametrize("M", [17, 32, 64, 130])
+def test_gemm_splitk_fused_reduce_launches_equal_the_launch_sequences(ops, M):
+    """mm355_gemm_splitk_{norm,swiglu,rope_append}_bf16 (what follows a split projection folded into its reduce launch) against
+    gemm_splitk -> rmsnorm_fwd / swiglu_fwd / rope_kv_append_: bit for bit, on shapes that are split (LLaMA-3-8B widths: K = 4096 / 14336)
+    and on shapes that are not (few K tiles: the library runs the plain sequence itself)."""
+    for (N, K) in ((4096, 14336), (4096, 4096), (512, 256)):
+        a, b, r = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=0.03).to(DEV), rnd(M, N, seed=3).to(DEV)
+        nw = (1.0 + 0.1 * rnd(N, seed=4)).bfloat16().to(DEV)
+        c0 = ops.gemm_splitk(a, b, residual=r)
+        y0 = ops.rmsnorm_fwd(c0, nw, 1e-5)
+        c1, y1 = ops.gemm_splitk_norm(a, b, nw, 1e-5, residual=r)
+        assert torch.equal(c0, c1) and torch.equal(y0, y1), ("norm", N, K)
+        c2, y2 = ops.gemm_splitk_norm(a, b, nw, 1e-5)
+        assert torch.equal(c2, ops.gemm_splitk(a, b)) and torch.equal(y2, ops.rmsnorm_fwd(c2, nw, 1e-5)), ("norm, no residual", N, K)
+    for (I, K) in ((14336, 4096), (256, 128)):
+        x, w = rnd(M, K, seed=5).to(DEV), rnd(2 * I, K, seed=6, scale=0.05).to(DEV)
+        assert torch.equal(ops.gemm_splitk_swiglu(x, w, I), ops.swiglu_fwd(ops.gemm_splitk(x, w), I)), ("swiglu", I, K)
+    for (Hq, Hkv, d, K) in ((32, 8, 128, 4096), (4, 2, 64, 128)):
+        if M > 64 and K == 4096:
+            continue                                                    # (one row per sequence: decode batches)
+        N, Lmax = (Hq + 2 * Hkv) * d, 50
+        x, w = rnd(M, K, seed=7).to(DEV), rnd(N, K, seed=8, scale=0.05).to(DEV)
+        cos, sin = ops.rope_table(Lmax, d, 10000.0, DEV)
+        pos = torch.tensor([(7 * m + 3) % Lmax for m in range(M)], dtype=torch.int32, device=DEV)
+        k0, v0 = rnd(M, Lmax, Hkv * d, seed=9).to(DEV), rnd(M, Lmax, Hkv * d, seed=10).to(DEV)
+        k1, v1 = k0.clone(), v0.clone()
+        qkv = ops.gemm_splitk(x, w)
+        ops.rope_kv_append_(qkv, Hq, Hkv, d, cos, sin, pos, k0, v0)
+        got = ops.gemm_splitk_rope_append(x, w, Hq, Hkv, d, cos, sin, pos, k1, v1)
+        assert torch.equal(got[:, :Hq * d], qkv[:, :Hq * d]), ("q rows", Hq, d)
+        assert torch.equal(k1, k0) and torch.equal(v1, v0), ("cache rows", Hq, d)
 
 
 @pytest.mark.parametrize("variant", [0, 1])

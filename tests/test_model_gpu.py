@@ -780,6 +780,46 @@ def test_config_fields_of_real_checkpoints_are_supported_or_refused_by_name():
             MetaMorphLlamaForCausalLM(MetaMorphConfig(**base, **{field: True}))
 
 
+def test_wide_decode_fused_reduce_launches_give_the_same_bits(monkeypatch):
+    """More than 16 sequences per step: RoPE + cache append, both RMSNorms and SwiGLU folded into the reduce launches of the split projections
+    (nine launches per layer) against the same step with them as launches of their own (thirteen): every score of every step bit for bit,
+    on widths that ARE split (hidden 1024 / intermediate 2048: two K slices) -- and fewer launches counted."""
+    import metamorph_amd.functional as F
+    cfg = tiny_cfg(hidden_size=1024, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=2, num_image_tokens=4)   # d = 128
+    model = hip_model(cfg, init_state_dict(cfg, seed=5, dtype=torch.bfloat16)).eval()
+    B = 20
+    g = torch.Generator().manual_seed(3)
+    lens = [9 + 2 * b for b in range(B)]
+    n = max(lens)
+    ids = torch.randint(3, 127000, (B, n), generator=g)
+    mask = torch.zeros(B, n, dtype=torch.bool)
+    for b, L in enumerate(lens):
+        mask[b, n - L:] = True
+    ids[~mask] = 128001
+    kw = dict(use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009, pad_token_id=128001, return_dict_in_generate=True,
+              output_scores=True)
+    monkeypatch.setitem(F.VARIANTS, "decode_graph", False)
+    runs, counts = {}, {}
+    names = ("gemm_splitk", "gemm_splitk_norm", "gemm_splitk_swiglu", "gemm_splitk_rope_append", "rmsnorm_fwd", "swiglu_fwd", "rope_kv_append_", "attn_decode")
+    for fused in (True, False):
+        seen = []
+        with monkeypatch.context() as mp:
+            mp.setitem(F.VARIANTS, "decode_wide_fused", fused)
+            for name in names:
+                orig = getattr(F.ops, name)
+                mp.setattr(F.ops, name, lambda *a, _o=orig, _n=name, **k: (seen.append(_n), _o(*a, **k))[1])
+            runs[fused] = model.generate(inputs=ids.to(DEV), attention_mask=mask.to(DEV), **kw)
+        counts[fused] = {nm: seen.count(nm) for nm in names}
+    assert torch.equal(runs[True].sequences, runs[False].sequences)
+    for step, (x, y) in enumerate(zip(runs[True].scores, runs[False].scores)):
+        assert torch.equal(x, y), (step, float((x - y).abs().max()))
+    steps, NL = len(runs[True].scores) - 1, cfg.num_hidden_layers
+    assert counts[True]["gemm_splitk_rope_append"] == steps * NL and counts[True]["gemm_splitk_swiglu"] == steps * NL
+    assert counts[True]["gemm_splitk_norm"] == steps * (2 * NL - 1) and counts[True]["rope_kv_append_"] == 0
+    assert counts[False]["gemm_splitk_norm"] == 0 and counts[False]["rope_kv_append_"] == steps * NL
+    print(f"\n   B={B}, {steps} cached steps: fused {counts[True]}; unfused {counts[False]}")
+
+
 @pytest.mark.parametrize("B", [3, 8, 11, 19, 35])
 def test_batched_decode_is_one_pass_and_equals_every_sequence_alone(B, monkeypatch):
     """The cached step of a batch (reference: the whole batch goes to ONE forward per step, metamorph_llama.py:711-717) takes all B rows
