@@ -43,7 +43,10 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             "decode_wide_gemm": True,
             # ... with RoPE + cache append, the two RMSNorms and SwiGLU folded into the reduce launches of the split projections (nine launches per
             # layer instead of thirteen; same bits)
-            "decode_wide_fused": True}
+            "decode_wide_fused": True,
+            # the prompt pass of ONE sequence (a few hundred rows): the same reduce launches (RoPE + the K / V rows straight into the cache, both
+            # RMSNorms), attention reading K / V from the cache rows -- same bits as the prefill_splitk pass, five launches per layer less
+            "prefill_fused": True}
 
 
 def set_variant(name, value):
@@ -815,6 +818,11 @@ def decoder_prefill(x, layers, meta, cache, row=0):
     assert B == 1 or (B == cache.batch and row == 0)
     meta.prompt_pass = VARIANTS["prefill_splitk"] and not torch.is_grad_enabled() and x.shape[0] <= 4096
     ident = torch.arange(L, device=x.device, dtype=torch.int32) if B == 1 else None
+    if (B == 1 and meta.prompt_pass and VARIANTS["prefill_fused"] and meta.d % 16 == 0 and meta.pos_offset is None and meta.p2c is None
+            and ops.gemm_splitk_splits(L, (meta.Hq + 2 * meta.Hkv) * meta.d, x.shape[1])):
+        x = _prefill_layers_fused(x, layers, meta, cache, row, ident)
+        cache.set_length(L, row)
+        return x
     for i, layer in enumerate(layers):
         params_ready(layer)
         x, saved = decoder_layer_forward(x, layer, meta)
@@ -832,6 +840,39 @@ def decoder_prefill(x, layers, meta, cache, row=0):
         cache.set_length(L, row)
     else:
         cache.set_length(L)
+    return x
+
+
+def _prefill_layers_fused(x, layers, meta, cache, row, ident):
+    """decoder_prefill for one sequence of a few hundred rows, with what follows a split projection in its reduce launch: q|k|v -> RoPE at the
+    row's position -> rotated k and v straight into the cache rows (mm355_gemm_splitk_rope_append_bf16 with a batch stride of 0: every row of
+    the call belongs to the same sequence), attention reads K / V from the cache rows, o / down + residual + the RMSNorm that follows
+    (mm355_gemm_splitk_norm_bf16).  The bits of decoder_layer_forward's prompt pass (rope_qk_ and rope_kv_append share their arithmetic)."""
+    L = x.shape[0]
+    nq = meta.Hq * meta.d
+    n1 = None
+    for i, layer in enumerate(layers):
+        params_ready(layer)
+        att, mlp = layer.self_attn, layer.mlp
+        wqkv = fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
+        wgu = fused_weight([mlp.gate_proj.weight, mlp.up_proj.weight])
+        if n1 is None:
+            n1 = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, meta.eps)
+        kc, vc = cache.k[i, row], cache.v[i, row]                             # [max_len, width]
+        rows_k = kc.as_strided((L, kc.shape[0], kc.shape[1]), (0, kc.stride(0), 1))
+        rows_v = vc.as_strided((L, vc.shape[0], vc.shape[1]), (0, vc.stride(0), 1))
+        qkv = ops.gemm_splitk_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, meta.cos, meta.sin, ident, rows_k, rows_v)
+        o, _ = ops.attn_fwd(qkv[:, :nq], kc[:L], vc[:L], 1, L, meta.Hq, meta.Hkv, meta.d, meta.scale, True, meta.seqlens)
+        x2, n2 = ops.gemm_splitk_norm(o, att.o_proj.weight, layer.post_attention_layernorm.weight, meta.eps, residual=x)
+        if VARIANTS["fuse_swiglu"] and ops.gemm_swiglu_supported(n2, wgu, meta.I):
+            _, act = ops.gemm_swiglu(n2, wgu, meta.I)
+        else:
+            act = ops.swiglu_fwd(ops.gemm(n2, wgu), meta.I)
+        if i + 1 < len(layers):
+            params_ready(layers[i + 1])
+            x, n1 = ops.gemm_splitk_norm(act, mlp.down_proj.weight, layers[i + 1].input_layernorm.weight, meta.eps, residual=x2)
+        else:
+            x = ops.gemm_splitk(act, mlp.down_proj.weight, residual=x2)
     return x
 
 

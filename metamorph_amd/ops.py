@@ -109,6 +109,11 @@ def gemm_splitk(a, b, residual=None, out=None):
     return out
 
 
+def gemm_splitk_splits(M, N, K):
+    """mm355_gemm_splitk_bf16 would cut this problem into K slices (else it forwards to the plain kernel)."""
+    return int(_L().mm355_gemm_splitk_ws_floats(M, N, K)) > 0
+
+
 def _splitk_ws(n_floats, device):
     return torch.empty((max(int(n_floats), 4),), device=device, dtype=torch.float32)
 

@@ -574,6 +574,36 @@ def test_prompt_pass_split_k_equals_the_plain_projections():
     assert int(outs[True][3].argmax()) == int(outs[False][3].argmax())
 
 
+def test_prompt_pass_fused_reduce_launches_give_the_same_bits():
+    """The prompt pass of one sequence with RoPE + the cache rows and both RMSNorms in the reduce launches of the split projections, attention
+    reading K / V from the cache (functional.VARIANTS["prefill_fused"]) against the same pass with them as launches of their own: hidden rows
+    and cached K / V rows bit for bit (h = 1024, 300 and 77 rows: split widths); the rows of the cache behind the prompt stay untouched."""
+    from metamorph_amd import functional as F
+    cfg = tiny_cfg(hidden_size=1024, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=2, num_hidden_layers=3)
+    model = hip_model(cfg, init_state_dict(cfg, seed=29, dtype=torch.bfloat16)).eval()
+    for L0 in (300, 77):
+        g = torch.Generator().manual_seed(L0)
+        emb = (torch.randn(L0, cfg.hidden_size, generator=g) * 0.5).bfloat16().to(DEV)
+        outs = {}
+        with torch.no_grad():
+            for on in (True, False):
+                old = F.set_variant("prefill_fused", on)
+                try:
+                    _, meta = model._decode_meta(L0)
+                    cos, sin = model.model.rope_tables(L0 + 4, DEV)
+                    meta.cos, meta.sin = cos, sin
+                    cache = F.KVCache(cfg.num_hidden_layers, L0 + 4, meta.Hkv * meta.d, DEV)
+                    cache.k.fill_(7.0); cache.v.fill_(-7.0)
+                    x = F.decoder_prefill(emb.clone(), model.model.layers, meta, cache)
+                    assert meta.prompt_pass and cache.lengths == [L0]
+                    outs[on] = (x.clone(), cache.k.clone(), cache.v.clone())
+                finally:
+                    F.set_variant("prefill_fused", old)
+        for a, b, what in zip(outs[True], outs[False], ("hidden rows", "cache k", "cache v")):
+            assert torch.equal(a, b), (L0, what, float((a.float() - b.float()).abs().max()))
+        assert float(outs[True][1][:, 0, L0:].min()) == 7.0 and float(outs[True][2][:, 0, L0:].max()) == -7.0
+
+
 def test_cached_image_mode_head_matches_reference_loop_step():
     """Image mode: vision_head -> L2 norm -> mm_projector on the last row; cached head == llm_forward(decoding=True)."""
     cfg, model = _decode_model()
@@ -799,6 +829,7 @@ def test_wide_decode_fused_reduce_launches_give_the_same_bits(monkeypatch):
     kw = dict(use_customize_greedy=False, do_sample=False, max_new_tokens=6, eos_token_id=128009, pad_token_id=128001, return_dict_in_generate=True,
               output_scores=True)
     monkeypatch.setitem(F.VARIANTS, "decode_graph", False)
+    monkeypatch.setitem(F.VARIANTS, "prefill_fused", False)      # (the prompt passes would add their own fused launches to the counts)
     runs, counts = {}, {}
     names = ("gemm_splitk", "gemm_splitk_norm", "gemm_splitk_swiglu", "gemm_splitk_rope_append", "rmsnorm_fwd", "swiglu_fwd", "rope_kv_append_", "attn_decode")
     for fused in (True, False):
