@@ -1215,7 +1215,15 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(GemmArgs a) {
 template <bool TA, bool TB, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef MM355_PP_PERSIST                                      // TIMING experiment (tools/build_pp_persist.sh): one workgroup per CU walks the tiles
+    const int total = a.ntm * a.ntn;
+    for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+        gemm_pp_tile<TA, TB, ABL>(a, bid, smem);
+        __syncthreads();
+    }
+#else
     gemm_pp_tile<TA, TB, ABL>(a, blockIdx.x, smem);
+#endif
 }
 
 // Two independent row-major problems in ONE grid: workgroups [0, n0) work on a0, the rest on a1.  A launch is executed in
@@ -1249,7 +1257,11 @@ int launch_gemm_pp_t(GemmArgs a, hipStream_t s) {
     if (mm_ensure_dynamic_lds((const void*)gemm_pp_kernel<TA, TB, ABL>, PP_LDS, lds_ok) != MM355_OK) return MM355_ELAUNCH;
     const int64_t total = pp_prepare(a);
     if (total <= 0 || total > 0x7fffffff) return MM355_EINVAL;
+#ifdef MM355_PP_PERSIST
+    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, ABL>), dim3((unsigned)std::min<int64_t>(total, MM355_PP_PERSIST)), dim3(512), PP_LDS, s, a);
+#else
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, ABL>), dim3((unsigned)total), dim3(512), PP_LDS, s, a);
+#endif
     return mm_launch_status();
 }
 
