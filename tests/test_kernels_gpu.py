@@ -1085,6 +1085,23 @@ def test_attn_decode(ops, case, variant):
         close(out[b], ref, 1e-2, 1e-2, f"attn_decode {case} sample {b}")
 
 
+def test_attn_decode_takes_a_q_view_without_16_byte_alignment(ops):
+    """The kernel loads a lane's q fragment with one 16-B load where q allows it and with 2-byte loads otherwise (q carries no alignment
+    contract in include/mm355.h): a q view that starts 2 bytes into its rows gives the bits of the aligned copy."""
+    B, Hq, Hkv, d = 3, 32, 8, 128
+    g = torch.Generator().manual_seed(5)
+    wide = (torch.randn(B, Hq * d + 8, generator=g) * 0.7).bfloat16().to(DEV)
+    q_off = wide[:, 1:1 + Hq * d]
+    assert q_off.data_ptr() % 16 != 0
+    kc = (torch.randn(B, 2048, Hkv * d, generator=g) * 0.7).bfloat16().to(DEV)
+    vc = (torch.randn(B, 2048, Hkv * d, generator=g) * 0.7).bfloat16().to(DEV)
+    for lens, bound in (([700, 64, 1], 1024), ([1500, 700, 1], 2048)):      # one key group (one head per workgroup) / two (the GQA group per workgroup)
+        kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        a = ops.attn_decode(q_off, kc, vc, kv, bound, Hq, Hkv, d, d ** -0.5)
+        b = ops.attn_decode(q_off.contiguous(), kc, vc, kv, bound, Hq, Hkv, d, d ** -0.5)
+        assert torch.equal(a, b), bound
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 8, 128), (8, 32, 8, 128), (3, 16, 8, 128), (2, 32, 4, 64), (16, 32, 8, 128)])
 def test_attn_decode_heads_spread_over_workgroups_is_bit_identical(ops, shape):
     """With a bound of <= 1024 cached rows the product launch gives every query head (or pair of heads) of a GQA group its own workgroup;
