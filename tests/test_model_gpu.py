@@ -577,11 +577,11 @@ def test_prompt_pass_split_k_equals_the_plain_projections():
 def test_prompt_pass_fused_reduce_launches_give_the_same_bits():
     """The prompt pass of one sequence with RoPE + the cache rows and both RMSNorms in the reduce launches of the split projections, attention
     reading K / V from the cache (functional.VARIANTS["prefill_fused"]) against the same pass with them as launches of their own: hidden rows
-    and cached K / V rows bit for bit (h = 1024, 300 and 77 rows: split widths); the rows of the cache behind the prompt stay untouched."""
+    and cached K / V rows bit for bit (h = 1024; 300, 77 and 40 rows: split widths); the rows of the cache behind the prompt stay untouched."""
     from metamorph_amd import functional as F
     cfg = tiny_cfg(hidden_size=1024, intermediate_size=2048, num_attention_heads=8, num_key_value_heads=2, num_hidden_layers=3)
     model = hip_model(cfg, init_state_dict(cfg, seed=29, dtype=torch.bfloat16)).eval()
-    for L0 in (300, 77):
+    for L0 in (300, 77, 40):                                       # (40 rows: gate|up takes the split-K GEMM too)
         g = torch.Generator().manual_seed(L0)
         emb = (torch.randn(L0, cfg.hidden_size, generator=g) * 0.5).bfloat16().to(DEV)
         outs = {}
