@@ -313,7 +313,9 @@ int mm355_cast_f32_bf16_2d(const float* in, int64_t ld_in, mm355_bf16* out, int6
 /* ------------------------------------------------------------------------------------------------
  * Decode shape (greedy_decode / generate with a KV cache; reference metamorph_llama.py:502-597, which
  * re-runs the prefix every step).  HBM-bound streaming kernels.
- *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows (else MM355_EUNSUPPORTED: use mm355_gemm_bf16).  Up to four rows run on the
+ *   gemv: y[M,N] = x[M,K] . W[N,K]^T for M <= 16 new rows -- and for 17 .. 32 rows on WIDE weights (more than 1280 groups of 16 weight rows, i.e.
+ *         N > 20480 for gemv, I > 10240 for gemv_swiglu without norm_w: gate|up, lm_head), where a second group of 16 x rows rides on the same
+ *         weight fragments -- else MM355_EUNSUPPORTED: use mm355_gemm_bf16 / mm355_gemm_splitk_bf16.  Up to four rows run on the
  *         vector ALU with the x rows parked in LDS (windows of 4096 columns), so that only weight loads sit in the in-order
  *         vector-memory queue: one or two rows as an fp32 fma chain, three and four on v_dot2c_f32_bf16; 5 .. 16 rows on
  *         v_mfma_f32_16x16x32_bf16, the weight rows loaded coalesced and re-laid out into fragments through wave-private LDS.  flags

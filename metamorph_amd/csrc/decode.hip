@@ -191,16 +191,21 @@ MM_DEV void unit_rows(const GemvFusedArgs& a, int unit, int (&rows)[4]) {
     }
 }
 
-template <int MODE, bool PRENORM, int GR, bool WLDS = false, int XK = 0>
+// RG = 2 (round 6, 17 .. 32 x rows on the shapes whose waves share one K range, XK == 1: gate|up, lm_head): a SECOND group of 16 x rows rides
+// on the same weight fragments -- every fragment read back from the re-layout buffer feeds two MFMAs, the x windows hold 32 rows (35 KB),
+// the weights are streamed once.  (Sharing weights between WORKGROUPS through L2 was measured and lost: profiles/r6_gemv_row_groups.log.)
+// Each x row's column of D is computed exactly as in a 16-row call: the bits of the 16-row calls on the row slices.
+template <int MODE, bool PRENORM, int GR, bool WLDS = false, int XK = 0, int RG = 1>
 __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     static_assert(!WLDS || GR == 1, "the LDS re-layout is written for one group of 16 rows per wave");
     static_assert(XK == 0 || (WLDS && !PRENORM), "x windows come with the coalesced weight stream");
+    static_assert(RG == 1 || (RG == 2 && XK == 1 && GR == 1), "two x row groups: one K range per workgroup, x windows in LDS");
     const GemvFusedArgs& a = g.f;
     constexpr int WROW = 512 + 32;                           // WLDS: bytes per weight row of a 256-column block in LDS (+ 32: every 16-lane group the hardware services together
                                                              // reads 16 different 16-byte slots of the 256-byte bank row; + 16 leaves two-way conflicts: tests/test_host_logic.py)
     __shared__ __attribute__((aligned(16))) unsigned char wl[WLDS ? NT / 64 : 1][WLDS ? 16 * WROW : 16];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];          // PRENORM: [M][xs_stride] normalised x rows (bf16)
-    __shared__ float part[NT / 64][GR][64][4];
+    __shared__ float part[RG == 1 ? NT / 64 : 1][GR][64][4];
     __shared__ float red[NT / 64];
     __shared__ float rstd_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         }
     }
     const uint16_t* xp = a.x + (int64_t)min(fr, M - 1) * a.ldx + fq * 8;
+    const uint16_t* xp1 = a.x + (int64_t)min(16 + fr, M - 1) * a.ldx + fq * 8;      // RG == 2: the lane's row of the second group
     const uint32_t xo = (uint32_t)min(fr, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)fq * 16u;
     // buffer descriptors: a load whose offset lies beyond num_records returns zeros WITHOUT touching memory -- the branch-free way to
     // skip the prefetch behind the last block (a branch around a prefetch makes hipcc wait for it at the merge: no pipelining)
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     // 16 rows x 256 columns, rows XROW bytes apart (the fragment reads are those of the weight re-layout: conflict-free); every thread
     // stages 2 XK vectors per block, loaded two blocks ahead and stored behind the barrier that retires the buffer's previous block.  All
     // waves run the same number of block pairs (nbu: the longest slice), a wave past its own slice multiplies zero weights.
-    constexpr int XROW = 512 + 32, XVN = XK ? 2 * XK : 1;
+    constexpr int XROW = 512 + 32, XVN = XK ? 2 * XK * RG : 1;
     uint32_t xsb[XVN], xld[XVN];
     int xnb[XVN];
     int nbu = nb;
@@ -287,11 +293,11 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         for (int q = 0; q < XK; ++q) nbu = max(nbu, max(min((nst * (q + 1)) / XK, complete) - (nst * q) / XK, 0) / U);
 #pragma unroll
         for (int i = 0; i < XVN; ++i) {
-            const int vi = threadIdx.x + NT * i, q = vi >> 9, m = (vi >> 5) & 15, c = vi & 31;
+            const int vi = threadIdx.x + NT * i, qr = vi >> 9, q = qr / RG, m = (qr % RG) * 16 + ((vi >> 5) & 15), c = vi & 31;
             const int q0 = (nst * q) / XK, q1 = min((nst * (q + 1)) / XK, complete);
-            xnb[i] = m < M ? max(q1 - q0, 0) / U : 0;
+            xnb[i] = m < M ? max(q1 - q0, 0) / U : 0;          // (a row beyond M: the load is skipped and returns zeros, which are stored)
             xsb[i] = (uint32_t)min(m, M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)(q0 * 32 + c * 8) * 2u;
-            xld[i] = (uint32_t)((q * 16 + m) * XROW + c * 16);
+            xld[i] = (uint32_t)((q * 16 * RG + m) * XROW + c * 16);
         }
     }
     auto xstage_load = [&](u32x4 (&r)[XVN], int b) {
@@ -300,10 +306,10 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
     };
     auto xstage_store = [&](const u32x4 (&r)[XVN], int b) {
 #pragma unroll
-        for (int i = 0; i < XVN; ++i) *(u32x4*)(xs + (size_t)(b & 1) * XK * 16 * XROW + xld[i]) = r[i];
+        for (int i = 0; i < XVN; ++i) *(u32x4*)(xs + (size_t)(b & 1) * XK * 16 * RG * XROW + xld[i]) = r[i];
     };
-    auto xfrag = [&](u32x4 (&xv)[U], int b) {
-        const unsigned char* base = xs + (size_t)((b & 1) * XK + ks) * 16 * XROW + min(fr, M - 1) * XROW + fq * 16;
+    auto xfrag = [&](u32x4 (&xv)[U], int b, int rg = 0) {
+        const unsigned char* base = xs + (size_t)((b & 1) * XK + ks) * 16 * RG * XROW + (RG == 1 ? min(fr, M - 1) : rg * 16 + fr) * XROW + fq * 16;
 #pragma unroll
         for (int u = 0; u < U; ++u) xv[u] = *(const u32x4*)(base + u * 64);
     };
@@ -349,9 +355,11 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             *(u32x4*)(xs + (int64_t)(i / npad) * g.xs_stride + (nv + i % npad) * 16) = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
-    f32x4 acc[GR][2];
+    f32x4 acc[GR][2], acc1[2];                               // acc1: the second x row group (RG == 2)
 #pragma unroll
     for (int gi = 0; gi < GR; ++gi) acc[gi][0] = acc[gi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[0] = acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int mm_block = 0;                                        // RG == 2: the block whose second-group x fragments mm() reads itself
     auto mm = [&](const u32x4 (&w)[GR][U], const u32x4 (&xv)[U]) {
         if constexpr (WLDS) {
             unsigned char* my = wl[wave];                    // (one wave's LDS operations execute in order: no barrier)
@@ -363,6 +371,13 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 acc[0][u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u]), __builtin_bit_cast(bf16x8, xv[u]), acc[0][u & 1], 0, 0, 0);
+            if constexpr (RG == 2) {                          // the same weight fragments against x rows 16 .. 31
+                u32x4 x1[U];
+                xfrag(x1, mm_block, 1);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    acc1[u & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u]), __builtin_bit_cast(bf16x8, x1[u]), acc1[u & 1], 0, 0, 0);
+            }
             return;
         }
 #pragma unroll
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             loadw(wb, s + U, skb);
             __builtin_amdgcn_sched_barrier(0);
             xfrag(xa, bk);
+            mm_block = bk;
             mm(wa, xa);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                                 // every wave is done with buffer 0's block
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             loadw(wa, s + 2 * U, ska);
             __builtin_amdgcn_sched_barrier(0);
             xfrag(xb, bk + 1);
+            mm_block = bk + 1;
             mm(wb, xb);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                                 // ... with buffer 1's; and block bk + 2 is in buffer 0 for everyone
@@ -421,6 +438,11 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         for (int gi = 0; gi < GR; ++gi) {
             const u32x4 wv = *(const u32x4*)(wp[gi] + off);
             acc[gi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xv), acc[gi][0], 0, 0, 0);
+            if constexpr (RG == 2) {
+                u32x4 xw = *(const u32x4*)(xp1 + off);
+                xw = in ? xw : z4;
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xw), acc1[0], 0, 0, 0);
+            }
         }
     }
     f32x4 dd[GR];
@@ -442,11 +464,13 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
         }
     }
     // lane (m = fr, unit fq) of group gi: D rows 4 fq .. 4 fq + 3 = the four outputs of unit (grp0 + gi) * 4 + fq for x row m
-    const int m = fr;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+    const int m = rg * 16 + fr;
     if (m >= M) return;
 #pragma unroll
     for (int gi = 0; gi < GR; ++gi) {
-        const f32x4 d = dd[gi];
+        const f32x4 d = rg == 0 ? dd[gi] : acc1[0] + acc1[1];
         unit_rows<MODE>(a, (grp0 + gi) * 4 + fq, rows);
         if constexpr (MODE == 0) {
             const uint32_t flags = g.flags;
@@ -495,6 +519,7 @@ __global__ __launch_bounds__(NT) void gemv_mfma_kernel(GemvMfmaArgs g) {
             }
         }
     }
+    }
 }
 
 // groups of 16 rows per wave (GR: the x fragments are re-used GR times) and waves per group block (KS: the K split) by the number of weight
@@ -514,6 +539,7 @@ int launch_gemv_mfma_gr(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_
     const int bpw = (NT / 64) / g.ks;
     const unsigned grid = (unsigned)((blocks + bpw - 1) / bpw);
     if (prenorm) {
+        if (g.f.M > 16) return MM355_EUNSUPPORTED;
         g.xs_stride = (((g.f.K + 31) >> 5) * 32 + 8) * 2;    // whole 32-column steps + 16 B per row: the 16 x rows of a fragment read fall on different banks
         const int lds = g.f.M * g.xs_stride;
         if (lds > 140 * 1024) return MM355_EUNSUPPORTED;
@@ -525,6 +551,17 @@ int launch_gemv_mfma_gr(GemvMfmaArgs& g, int64_t units, bool prenorm, hipStream_
             // measured (profiles/r5_gemv_rows.log): the windows win wherever the waves of a workgroup share one K range (wide weights:
             // gate|up 47 -> 42 us at 8 rows, 53 -> 42 at 16, lm_head 208 -> 174) and, with K split over the waves, from nine rows on
             // (down 26.8 -> 23.6 at 16); below that the per-block barriers of four slices cost more than the L2 reads they replace
+            if (g.f.M > 16) {                                // 17 .. 32 rows: two x row groups per workgroup, shapes with one K range per workgroup only
+                if constexpr (MODE == 2) return MM355_EUNSUPPORTED;
+                else {
+                    if (g.ks != 1 || g.f.M > 32) return MM355_EUNSUPPORTED;
+                    static std::atomic<uint64_t> ok2{0};
+                    constexpr int XL2 = 2 * 1 * 16 * 2 * 544;
+                    if (mm_ensure_dynamic_lds((const void*)gemv_mfma_kernel<MODE, false, 1, true, 1, 2>, XL2, ok2) != MM355_OK) return MM355_ELAUNCH;
+                    hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, 1, true, 1, 2>), dim3(grid), dim3(NT), XL2, s, g);
+                    return mm_launch_status();
+                }
+            }
             if (g.ks > 1 && g.f.M <= 8) { hipLaunchKernelGGL((gemv_mfma_kernel<MODE, false, 1, true>), dim3(grid), dim3(NT), 0, s, g); return mm_launch_status(); }
             const int xlds = 2 * g.ks * 16 * 544;
 #define GX(KSC) do { static std::atomic<uint64_t> okx{0};                                                                                      \
@@ -1356,7 +1393,7 @@ extern "C" int mm355_gemv_bf16(const mm355_bf16* x, int64_t ldx, const mm355_bf1
                                int64_t K, const mm355_bf16* bias, const mm355_bf16* residual, int64_t ldr, uint32_t flags, void* stream) {
     (void)hipGetLastError();   // drop any stale, unrelated runtime status before we launch
     if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0) return MM355_EINVAL;
-    if (M > 16) return MM355_EUNSUPPORTED;                   // more rows: mm355_gemm_bf16
+    if (M > 32) return MM355_EUNSUPPORTED;                   // more rows: mm355_gemm_bf16 (17 .. 32: wide weights only, see launch_gemv_mfma_gr)
     if ((K & 7) || (ldx & 7) || (ldw & 7) || !mm_aligned16(x) || !mm_aligned16(W)) return MM355_EINVAL;
     if ((flags & MM355_GEMM_BIAS) && !bias) return MM355_EINVAL;
     if ((flags & MM355_GEMM_RESIDUAL) && !residual) return MM355_EINVAL;
@@ -1476,7 +1513,7 @@ extern "C" int mm355_gemv_swiglu_bf16(const mm355_bf16* x, int64_t ldx, const mm
                                       int64_t M, int64_t I, int64_t K, const mm355_bf16* norm_w, float eps, void* stream) {
     (void)hipGetLastError();
     if (!x || !Wgu || !act || M <= 0 || I <= 0 || K <= 0) return MM355_EINVAL;
-    if (M > 16 || (I & 1)) return MM355_EUNSUPPORTED;
+    if (M > 32 || (I & 1)) return MM355_EUNSUPPORTED;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || (ld_act & 1) || !mm_aligned16(x) || !mm_aligned16(Wgu) || (((uintptr_t)act) & 3u)) return MM355_EINVAL;
     if (norm_w && !mm_aligned16(norm_w)) return MM355_EINVAL;
     if (I > 0x3fffffff || K > 0x7fffffff) return MM355_EINVAL;

@@ -43,7 +43,7 @@ VARIANTS = {"dw_tn": False, "dw_pair": True, "norm_t": True, "fuse_swiglu": True
             "decode_wide_gemm": True,
             # ... with RoPE + cache append, the two RMSNorms and SwiGLU folded into the reduce launches of the split projections (nine launches per
             # layer instead of thirteen; same bits)
-            "decode_wide_fused": True,
+            "decode_wide_fused": True, "decode_wide_gu_gemv": True,
             # the prompt pass of ONE sequence (a few hundred rows): the same reduce launches (RoPE + the K / V rows straight into the cache, both
             # RMSNorms), attention reading K / V from the cache rows -- same bits as the prefill_splitk pass, five launches per layer less
             "prefill_fused": True}
@@ -763,7 +763,7 @@ class BilinearL2NormFn(Function):
 
 
 def linear(x2d, module):
-    if (x2d.shape[0] <= 16 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad))
+    if (x2d.shape[0] <= 32 and not (torch.is_grad_enabled() and (x2d.requires_grad or module.weight.requires_grad))
             and ops.gemv_supported(x2d, module.weight.data)):
         # decode shape: a handful of rows, inference only -> stream the weight once (mm355_gemv_bf16)
         return ops.gemv(x2d, module.weight.data, bias=None if module.bias is None else module.bias.data)
@@ -930,6 +930,7 @@ def _decode_rows_gemm(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_
     if VARIANTS["decode_wide_fused"] and meta.d % 16 == 0:
         # what follows a split projection rides in its reduce launch (mm355_gemm_splitk_{rope_append,norm,swiglu}_bf16): 9 launches per layer
         n1 = None
+        gu_gemv = VARIANTS["decode_wide_gu_gemv"] and x.shape[0] <= 32 and meta.I % 2 == 0 and ops.gemv_rows32_units(meta.I // 2)
         for i, layer in enumerate(layers):
             params_ready(layer)
             att, mlp = layer.self_attn, layer.mlp
@@ -940,7 +941,10 @@ def _decode_rows_gemm(x, layers, meta, cos, sin, k, v, pos_dev, len_dev, ws, kv_
             qkv = ops.gemm_splitk_rope_append(n1, wqkv, meta.Hq, meta.Hkv, meta.d, cos, sin, pos_dev, k[i], v[i])
             o = ops.attn_decode(qkv[:, :nq], k[i], v[i], len_dev, kv_bound, meta.Hq, meta.Hkv, meta.d, meta.scale, workspace=ws)
             x2, n2 = ops.gemm_splitk_norm(o, att.o_proj.weight, layer.post_attention_layernorm.weight, meta.eps, residual=x)
-            act = ops.gemm_splitk_swiglu(n2, wgu, meta.I)
+            if gu_gemv:
+                act = ops.gemv_swiglu(n2, wgu, meta.I)        # up to 32 rows: the weight stream of the 16-row kernel, a second x row group on its fragments
+            else:
+                act = ops.gemm_splitk_swiglu(n2, wgu, meta.I)
             if i + 1 < len(layers):
                 params_ready(layers[i + 1])                   # (its input norm weight is read by this layer's last launch)
                 x, n1 = ops.gemm_splitk_norm(act, mlp.down_proj.weight, layers[i + 1].input_layernorm.weight, meta.eps, residual=x2)

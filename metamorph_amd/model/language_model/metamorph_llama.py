@@ -696,7 +696,7 @@ class MetaMorphLlamaForCausalLM(PreTrainedModel, GenerationMixin, MetaMorphMetaF
     def _rows_logits(self, rows, return_hidden=False):
         """final norm + lm_head -> fp32 logits [n, V] (reference :349-359 final norm, :393-399); return_hidden: (logits, normed rows)."""
         hid = self.model.norm(rows)
-        if hid.shape[0] <= 16 and ops.gemv_supported(hid, self.lm_head.weight.data):
+        if hid.shape[0] <= 32 and ops.gemv_supported(hid, self.lm_head.weight.data):     # (17 .. 32 rows: wide weights only -- the lm_head is one)
             logits = ops.gemv(hid.contiguous(), self.lm_head.weight.data,
                               out=torch.empty((hid.shape[0], self.lm_head.weight.shape[0]), device=rows.device, dtype=torch.float32))
         else:

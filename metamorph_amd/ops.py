@@ -250,14 +250,20 @@ def gemm_nn_supported(a, bt):
 
 
 def gemv_supported(x, w):
-    """mm355_gemv_bf16 takes this (x [M <= 16, K], w [N, K]) pair: up to 4 rows always; 5 - 16 rows (the MFMA form) only while the weight and
+    """mm355_gemv_bf16 takes this (x [M, K], w [N, K]) pair: up to 4 rows always; 5 - 16 rows (the MFMA form; 17 - 32 on wide weights) only while the weight and
     the x rows are addressable with 32-bit byte offsets (< 3.75 GiB; gemv_mfma_addressable in csrc/decode.hip) -- beyond that the call
     returns MM355_EUNSUPPORTED and callers use the GEMM."""
     _, M, K, ldx = _rows2d(x)
     _, N, _, ldw = _rows2d(w)
-    if M > 16:
+    if M > 32 or (M > 16 and not gemv_rows32_units((N + 3) // 4)):
         return False
     return M <= 4 or ((N - 1) * ldw * 2 + K * 2 < 0xf0000000 and (M - 1) * ldx * 2 + K * 2 < 0xf0000000)
+
+
+def gemv_rows32_units(units):
+    """17 .. 32 rows ride on the MFMA GEMVs (two x row groups per workgroup) on shapes whose workgroups each own one K range -- more than
+    1280 groups of four 4-row units (gemv_mfma_shape in csrc/decode.hip): gate|up (I / 2 units), lm_head (V / 4); not q|k|v, o, down."""
+    return (units + 3) // 4 > 1280
 
 
 def gemv(x, w, out=None, bias=None, residual=None, gelu=None):

@@ -1061,6 +1061,35 @@ def test_gemm_splitk_fused_reduce_launches_equal_the_launch_sequences(ops, M):
         assert torch.equal(k1, k0) and torch.equal(v1, v0), ("cache rows", Hq, d)
 
 
+@pytest.mark.parametrize("M", [17, 24, 32])
+def test_gemv_second_row_group_on_wide_weights(ops, M):
+    """17 .. 32 rows on the MFMA GEMVs (round 6): on weights wide enough that every workgroup owns one K range (gate|up, lm_head) a second
+    group of 16 x rows rides on the same weight fragments -- the weights are streamed once.  Every row equals the 16-row call on its slice bit
+    for bit (plain, bias + GELU, residual, fp32 output; the SwiGLU epilogue against gemv -> swiglu_fwd); narrower weights are refused (the
+    callers take the split-K GEMM there)."""
+    from metamorph_amd.lib import Mm355Error
+    N, K = 20992, 1032                                                      # 1312 groups of 16 weight rows; K with a tail step
+    x, w, b, r = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=0.05).to(DEV), rnd(N, seed=3).to(DEV), rnd(M, N, seed=4).to(DEV)
+    sl = (slice(0, 16), slice(16, M))
+    pad16 = lambda t: t if t.shape[0] == 16 else torch.cat([t, t.new_zeros(16 - t.shape[0], t.shape[1])], 0)      # (every slice as a 16-row call: the MFMA form)
+    rows16 = lambda f: torch.cat([f(pad16(x[c]), pad16(r[c]))[:x[c].shape[0]] for c in sl], 0)
+    got = ops.gemv(x, w)
+    close(got, x.float().cpu() @ w.float().cpu().t(), 1e-2, 0.02, f"gemv {M}x{N}x{K}")
+    assert torch.equal(got, rows16(lambda xx, rr: ops.gemv(xx, w)))
+    assert torch.equal(ops.gemv(x, w, bias=b, gelu="erf"), rows16(lambda xx, rr: ops.gemv(xx, w, bias=b, gelu="erf")))
+    assert torch.equal(ops.gemv(x, w, residual=r), rows16(lambda xx, rr: ops.gemv(xx, w, residual=rr)))
+    of = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    assert torch.equal(ops.gemv(x, w, out=of), rows16(lambda xx, rr: ops.gemv(xx, w, out=torch.empty(16, N, device=DEV, dtype=torch.float32))))
+    I, K2 = 10496, 4096                                                     # I / 8 = 1312 groups
+    x2, w2 = rnd(M, K2, seed=5).to(DEV), rnd(2 * I, K2, seed=6, scale=0.05).to(DEV)
+    assert torch.equal(ops.gemv_swiglu(x2, w2, I), torch.cat([ops.gemv_swiglu(pad16(x2[c]), w2, I)[:x2[c].shape[0]] for c in sl], 0))
+    assert torch.equal(ops.gemv_swiglu(x2, w2, I), ops.swiglu_fwd(torch.cat([ops.gemv(pad16(x2[c]), w2)[:x2[c].shape[0]] for c in sl], 0), I))
+    with pytest.raises(Mm355Error):
+        ops.gemv(x, w[:4096])                                               # 256 groups: K is split over the waves of a workgroup there
+    with pytest.raises(Mm355Error):
+        ops.gemv_swiglu(x2, w2, I, norm_w=(1.0 + 0.1 * rnd(K2, seed=7)).bfloat16().to(DEV), eps=1e-5)   # the folded norm keeps 16 rows
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", [(1, 8, 2, 128, [700]), (3, 4, 4, 64, [1, 256, 300]), (2, 32, 4, 128, [513, 77]), (1, 16, 16, 72, [40]),
                                   (2, 8, 2, 128, [2500, 1030]), (2, 16, 2, 128, [1024, 1025]), (1, 4, 2, 64, [4000]), (3, 32, 8, 128, [128, 129, 127])])
