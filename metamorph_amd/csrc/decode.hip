@@ -1461,7 +1461,10 @@ static int attn_decode_impl(const mm355_bf16* q, int64_t ld_q, const mm355_bf16*
     if (B > 65535 || Hkv > 65535) return MM355_EINVAL;
     if (variant < 0 || variant > 2) return MM355_EINVAL;      // 2 = variant 0 with the whole GQA group in one workgroup whatever the bound
     const int64_t G0_ = Hq / Hkv;
-    if (variant == 0 && max_kv_len <= 4 * CH && (G0_ == 2 || G0_ == 4 || G0_ == 8)) {
+    // (beyond 16 sequences every CU already holds two 1024-thread workgroups: spreading the group only multiplies the K / V loads and their
+    // unpacking -- measured at 32 / 64 sequences of ~520 rows: 31.1 / 55.6 us spread against 21.2 / 39.0 with the group in one workgroup;
+    // 16 sequences: 17.2 against 18.8.  Same arithmetic per head either way.)
+    if (variant == 0 && max_kv_len <= 4 * CH && (G0_ == 2 || G0_ == 4 || G0_ == 8) && B * Hq <= 512) {
         // a cache bound of <= 1024 rows is ONE key group: its lone workgroup per head group finishes without records or fences, so the
         // GQA group can be spread over more workgroups -- one query head each (two from 64 workgroups on): 32 workgroups instead of 8 for
         // one LLaMA-3-8B sample, 21 -> 10.5 us per launch (profiles/r5_attn_decode_heads_per_workgroup.log); the K / V rows are read by

@@ -1450,7 +1450,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 MM_DEV void splitk_sum8(const float* __restrict__ p, int S, int64_t plane, float (&v)[8]) {
     const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
     v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-    for (int s = 1; s < S; ++s) {
+    int s = 1;
+    for (; s + 3 < S; s += 4) {                              // four slices' loads in flight at once; added in slice order
+        f32x4 b0[4], b1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b0[j] = *(const f32x4*)(p + (s + j) * plane); b1[j] = *(const f32x4*)(p + (s + j) * plane + 4); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[0] += b0[j].x; v[1] += b0[j].y; v[2] += b0[j].z; v[3] += b0[j].w; v[4] += b1[j].x; v[5] += b1[j].y; v[6] += b1[j].z; v[7] += b1[j].w;
+        }
+    }
+    for (; s < S; ++s) {
         const f32x4 b0 = *(const f32x4*)(p + s * plane), b1 = *(const f32x4*)(p + s * plane + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }

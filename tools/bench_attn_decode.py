@@ -26,7 +26,7 @@ def t(fn, it=int(os.environ.get("IT", 50))):
     return s.elapsed_time(e) / it * 1e3
 
 
-for B in (1, 8):
+for B in [int(b) for b in os.environ.get("BS", "1,8").split(",")]:
     for kv in [int(v) for v in os.environ.get("KVS", "100,256,500,600,1000,1100,2000,4000").split(",")]:
         cap = kv + 8
         q = (torch.randn(B, Hq * d, device=DEV) * 0.5).bfloat16()
